@@ -1,0 +1,182 @@
+/*
+ * ro_stft.h -- C ABI of the MI355X-native STFT / waterfall / bolid-scan path.
+ *
+ * This is the drop-in boundary for radio-observer's hot path.  Each entry point
+ * names the reference interface (file:line under the reference tree) it
+ * replaces.  Plain C types only: pointers, sizes, PODs.  No exceptions cross
+ * this boundary; every call returns RO_OK (0) or a negative RO_ERR_* code and
+ * ro_last_error() gives the text (the reference's own convention is
+ * log-and-return, src/FFTBackend.cpp:194, src/WAVStream.cpp:209-213).
+ *
+ * One handle = one stream = one HIP stream; a handle is not thread-safe, which
+ * mirrors the reference's single-caller rule for Backend::process()
+ * (src/WAVStream.cpp:115-123, src/JackFrontend.cpp:15-39).
+ *
+ * There is NO CPU fallback behind this ABI: without a gfx950 device every
+ * compute entry point fails with RO_ERR_HIP.
+ */
+#ifndef RO_STFT_H
+#define RO_STFT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RO_OK               0
+#define RO_ERR_INVALID     (-1)   /* bad argument / shape mismatch                */
+#define RO_ERR_UNSUPPORTED (-2)   /* e.g. bins not a supported power of two       */
+#define RO_ERR_HIP         (-3)   /* HIP runtime error or no device               */
+#define RO_ERR_NOMEM       (-4)
+#define RO_ERR_STATE       (-5)   /* call not valid in the handle's current state */
+
+#define RO_ABI_VERSION 1
+
+/* window function; the reference hard-codes the 4-term Nuttall
+ * (src/FFTBackend.cpp:165-184) and keeps Hann as dead code (:157-163). */
+enum { RO_WINDOW_NUTTALL = 0, RO_WINDOW_HANN = 1, RO_WINDOW_CUSTOM = 2 };
+
+/* sample formats accepted by push / resident runs.
+ *  F32: interleaved float32 I,Q -- RawStream's wire format (src/RawStream.cpp:33,61-62)
+ *  I16: interleaved int16 I,Q, un-normalised -- WAVStream (src/WAVStream.cpp:119-120)
+ *  F64: {double real; double imag;} -- struct Complex (src/Backend.h:26-29);
+ *       host-side only, narrowed to float32 while staging (lossless for every
+ *       frontend the reference has: int16 WAV, float32 raw/JACK). */
+enum { RO_IQ_F32 = 0, RO_IQ_I16 = 1, RO_IQ_F64 = 2 };
+
+/* bin ranges of BolidRecorder::start (src/BolidRecorder.cpp:84-102), in
+ * fft-shifted row columns. */
+typedef struct ro_bands {
+    int32_t low_noise;     /* lowNoiseBin_      */
+    int32_t noise_width;   /* noiseWidth_       */
+    int32_t low_detect;    /* lowDetectBin_     */
+    int32_t detect_width;  /* detectWidth_      */
+    int32_t avg_bins;      /* averageBinRange_  */
+} ro_bands_t;
+
+/* what BolidRecorder::update computes per row before its state machine
+ * (src/BolidRecorder.cpp:121-132): n = noise(), p = peak(), a = average(). */
+typedef struct ro_scan_record {
+    float   noise;
+    int32_t peak;
+    float   average;
+} ro_scan_record_t;
+
+/* Construction parameters = WaterfallBackend::make's config keys
+ * (src/WaterfallBackend.cpp:620-646) plus device-side options. */
+typedef struct ro_stft_config {
+    uint32_t     struct_size;      /* sizeof(ro_stft_config_t), for ABI growth     */
+    int32_t      bins;             /* "bins"     default 32768                      */
+    int32_t      overlap;          /* "overlap"  default 0; clamped to [0,bins-1]   */
+    int32_t      sample_rate;      /* StreamInfo::sampleRate, default 48000         */
+    int32_t      window_kind;      /* RO_WINDOW_*                                   */
+    const float *window_table;     /* RO_WINDOW_CUSTOM: bins floats (host)          */
+    double       iq_gain;          /* "iq_gain": added to Q (src/FFTBackend.cpp:79) */
+    int32_t      iq_phase_shift;   /* must be 0 (non-zero is UB in the reference)   */
+    int32_t      device;           /* HIP device ordinal                            */
+    int32_t      max_batch_rows;   /* streaming: rows per launch (0 = default)      */
+    int32_t      enable_scan;      /* compute ro_scan_record_t per row              */
+    ro_bands_t   bands;            /* used when enable_scan                         */
+    int32_t      tile_first_col;   /* compact band tile [tile_first_col, +tile_cols)*/
+    int32_t      tile_cols;        /* 0 = no tile                                   */
+} ro_stft_config_t;
+
+typedef struct ro_stft ro_stft_t;
+
+/* ---- library ------------------------------------------------------------- */
+int         ro_abi_version(void);
+const char *ro_last_error(void);          /* thread-local text of the last failure */
+int         ro_device_count(void);        /* <0 on HIP error                        */
+
+/* ---- pure host helpers: FFTBackend's public arithmetic -------------------- */
+/* FFTBackend::FFTBackend overlap clamp, src/FFTBackend.cpp:108-109 */
+int     ro_clamp_overlap(int bins, int overlap);
+/* fftSampleRate_, src/FFTBackend.cpp:150-151 */
+float   ro_fft_sample_rate(int sample_rate, int bins, int overlap);
+/* FFTBackend::frequencyToBin, src/FFTBackend.h:159-178 */
+int     ro_frequency_to_bin(int bins, int sample_rate, float frequency);
+/* FFTBackend::binToFrequency, src/FFTBackend.h:134-147 */
+float   ro_bin_to_frequency(int bins, int sample_rate, int bin);
+/* FFTBackend::timeToFFTSamples, src/FFTBackend.h:197-200 */
+int     ro_time_to_fft_samples(double seconds, float fft_sample_rate);
+/* rows produced by FFTBackend::process for a stream of `samples`, :211-257 */
+int64_t ro_row_count(int64_t samples, int bins, int overlap);
+/* window table as FFTBackend::startStream builds it, :156-186 */
+int     ro_window_table(int kind, int bins, float *out);
+/* 1 if `bins` has a kernel in this build */
+int     ro_bins_supported(int bins);
+
+/* ---- handle --------------------------------------------------------------- */
+/* FFTBackend::FFTBackend + startStream (src/FFTBackend.cpp:103-127, :144-189)
+ * + WaterfallBackend::startStream's buffer sizing (src/WaterfallBackend.cpp:573-594). */
+int ro_stft_create(const ro_stft_config_t *cfg, ro_stft_t **out);
+/* FFTBackend::~FFTBackend, src/FFTBackend.cpp:130-141 */
+int ro_stft_destroy(ro_stft_t *h);
+int ro_stft_get_window(const ro_stft_t *h, float *out /* bins floats, host */);
+int ro_stft_hop(const ro_stft_t *h);
+int ro_stft_bins(const ro_stft_t *h);
+int ro_stft_device_name(const ro_stft_t *h, char *buf, size_t len);
+int ro_stft_set_bands(ro_stft_t *h, const ro_bands_t *bands);
+
+/* ---- resident path (benchmarks, multi-GPU shards) --------------------------
+ * Replaces, for rows [first_row, first_row+rows) of a stream that is already in
+ * HBM, the whole of FFTBackend::process's row loop (src/FFTBackend.cpp:211-257)
+ * and WaterfallBackend::processFFT's magnitude/shift (src/WaterfallBackend.cpp:485-505).
+ *   d_iq        device pointer to sample 0 of the stream, `format` F32 or I16
+ *   samples     number of complex samples addressable at d_iq
+ *   d_rows      device, rows x row_stride floats (row_stride >= bins); may be NULL
+ *               only if d_tile is given
+ *   d_tile      device, rows x tile_cols floats, or NULL
+ *   d_records   device, rows records, or NULL (needs enable_scan)
+ *   stream      hipStream_t as void* (NULL = the handle's own stream)
+ * The call is asynchronous on `stream`. */
+int ro_stft_run_resident(ro_stft_t *h, const void *d_iq, int format, int64_t samples,
+                         int64_t first_row, int64_t rows,
+                         float *d_rows, int64_t row_stride,
+                         float *d_tile, ro_scan_record_t *d_records, void *stream);
+
+/* BolidRecorder::noise/peak/average over rows already in HBM
+ * (src/BolidRecorder.cpp:121-132, :313-347). */
+int ro_stft_scan_resident(ro_stft_t *h, const float *d_rows, int64_t row_stride, int64_t rows,
+                          ro_scan_record_t *d_records, void *stream);
+
+/* Times `iters` back-to-back launches of the resident path with HIP events on
+ * the launch stream; ms_out[i] = duration of launch i (STFT kernel + scan kernel
+ * when records are requested).  kernel_ms_out (optional, 2 floats) receives the
+ * average STFT-kernel-only and scan-kernel-only durations. Synchronous. */
+int ro_stft_time_resident(ro_stft_t *h, const void *d_iq, int format, int64_t samples,
+                          int64_t first_row, int64_t rows,
+                          float *d_rows, int64_t row_stride,
+                          float *d_tile, ro_scan_record_t *d_records, void *stream,
+                          int iters, float *ms_out, float *kernel_ms_out);
+
+/* ---- streaming path (the Backend::process boundary) -------------------------
+ * ro_stft_push   = FFTBackend::process (src/FFTBackend.cpp:192-279): takes one
+ *                  Frontend::process() call worth of samples (any count), stages
+ *                  them, and runs the kernels whenever max_batch_rows rows are
+ *                  complete.  *rows_ready = rows waiting in the output queue.
+ * ro_stft_flush  = run the kernels on every complete row staged so far
+ *                  (WaterfallBackend::endStream, src/WaterfallBackend.cpp:600-607;
+ *                  samples short of a hop are dropped, like the reference).
+ * ro_stft_fetch  = hand rows to the Recorder side in stream order
+ *                  (replaces the synchronous Recorder::update() per row,
+ *                  src/WaterfallBackend.cpp:534-536): up to max_rows rows, columns
+ *                  [first_col, first_col+cols) of each, plus scan records.
+ *                  *first_row_index = stream index of the first row returned. */
+int ro_stft_push(ro_stft_t *h, const void *iq, int format, int64_t samples, int64_t *rows_ready);
+int ro_stft_flush(ro_stft_t *h, int64_t *rows_ready);
+int ro_stft_fetch(ro_stft_t *h, int64_t max_rows, int first_col, int cols,
+                  float *rows_out, ro_scan_record_t *records_out,
+                  int64_t *first_row_index, int64_t *rows_got);
+/* FFTBackend::startStream's reset of inMark_/info_ (src/FFTBackend.cpp:148-153) */
+int ro_stft_reset(ro_stft_t *h);
+/* counters in the spirit of FFTBackend::logProcessingTimes (src/FFTBackend.h:208-229) */
+int ro_stft_stats(const ro_stft_t *h, int64_t *samples_in, int64_t *rows_out,
+                  int64_t *launches, double *kernel_ms_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RO_STFT_H */

@@ -1,0 +1,117 @@
+// ro_fft_device.h -- in-register radix-R butterflies and the Stockham stage
+// plumbing shared by every STFT kernel instantiation (gfx950 only).
+//
+// Layout of one transform:  N = R0*R1*R2(*R3) points, T threads, P = N/T
+// points per thread held in registers as float2 v[P].  Stage s (radix R,
+// Ns = product of earlier radices) follows the autosort recurrence
+//     in :  v[b*R + r] = x[j + r*(N/R)] * w(r*(j mod Ns)/(Ns*R)),   j = tid + T*b
+//     out:  y[(j/Ns)*Ns*R + (j mod Ns) + r*Ns] = DFT_R(v)[r]
+// so every LDS / global access of a wavefront is 64 consecutive elements.
+// The exchange between stages goes through LDS; the element index i is padded
+// to i + (i>>5) so that the stride-R writes of the first stage hit 32 different
+// banks (ds_write_b32/b64 bank = dword address mod 32).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <utility>
+
+namespace ro {
+
+// cos(k*pi/16), k = 0..8
+#define RO_C1 0.98078528040323044913f
+#define RO_C2 0.92387953251128675613f
+#define RO_C3 0.83146961230254523708f
+#define RO_C4 0.70710678118654752440f
+#define RO_C5 0.55557023301960222474f
+#define RO_C6 0.38268343236508977173f
+#define RO_C7 0.19509032201612826785f
+
+template <int M> struct W32;   // exp(-2*pi*i*M/32) = (c, -s)
+template <> struct W32<1>  { static constexpr float c = RO_C1, s = RO_C7; };
+template <> struct W32<2>  { static constexpr float c = RO_C2, s = RO_C6; };
+template <> struct W32<3>  { static constexpr float c = RO_C3, s = RO_C5; };
+template <> struct W32<5>  { static constexpr float c = RO_C5, s = RO_C3; };
+template <> struct W32<6>  { static constexpr float c = RO_C6, s = RO_C2; };
+template <> struct W32<7>  { static constexpr float c = RO_C7, s = RO_C1; };
+template <> struct W32<9>  { static constexpr float c = -RO_C7, s = RO_C1; };
+template <> struct W32<10> { static constexpr float c = -RO_C6, s = RO_C2; };
+template <> struct W32<11> { static constexpr float c = -RO_C5, s = RO_C3; };
+template <> struct W32<13> { static constexpr float c = -RO_C3, s = RO_C5; };
+template <> struct W32<14> { static constexpr float c = -RO_C2, s = RO_C6; };
+template <> struct W32<15> { static constexpr float c = -RO_C1, s = RO_C7; };
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// d * exp(-2*pi*i*M/32)
+template <int M> __device__ __forceinline__ float2 mul_w32(float2 d)
+{
+    if constexpr (M == 0) {
+        return d;
+    } else if constexpr (M == 8) {            // * (-i)
+        return make_float2(d.y, -d.x);
+    } else if constexpr (M == 4) {            // * (1 - i)/sqrt2
+        return make_float2((d.x + d.y) * RO_C4, (d.y - d.x) * RO_C4);
+    } else if constexpr (M == 12) {           // * (-1 - i)/sqrt2
+        return make_float2((d.y - d.x) * RO_C4, -(d.x + d.y) * RO_C4);
+    } else {
+        constexpr float c = W32<M>::c, s = W32<M>::s;
+        return make_float2(d.x * c + d.y * s, d.y * c - d.x * s);
+    }
+}
+
+// Scheduling leash.  hipcc's scheduler interleaves all independent butterflies of a
+// level (4 temporaries each) and the 1024-thread kernel no longer fits its 128 VGPRs.
+// tie() makes x look recomputed from dep (no instruction is emitted), which chains
+// every SEQ_G-th butterfly behind the previous one in program order: at most SEQ_G
+// butterflies' temporaries are live, and four waves per SIMD cover the lost ILP.
+constexpr int SEQ_G = 2;
+
+__device__ __forceinline__ void tie(float &x, const float &dep) { asm volatile("" : "+v"(x) : "v"(dep)); }
+
+// One decimation-in-frequency level of a size-R sub-transform: butterfly I.
+template <int R, int I> __device__ __forceinline__ void dif_bfly(float2 *v, const float *&tok)
+{
+    if constexpr (I % SEQ_G == 0) tie(v[I].x, *tok);
+    float2 a = v[I], b = v[I + R / 2];
+    v[I] = cadd(a, b);
+    v[I + R / 2] = mul_w32<I * (32 / R)>(csub(a, b));
+    tok = &v[I + R / 2].y;
+}
+
+template <int R, int... Is>
+__device__ __forceinline__ void dif_level(float2 *v, const float *&tok, std::integer_sequence<int, Is...>)
+{
+    (dif_bfly<R, Is>(v, tok), ...);
+}
+
+template <int R> __device__ __forceinline__ void dif_rec(float2 *v, const float *&tok)
+{
+    if constexpr (R >= 2) {
+        dif_level<R>(v, tok, std::make_integer_sequence<int, R / 2>{});
+        dif_rec<R / 2>(v, tok);
+        dif_rec<R / 2>(v + R / 2, tok);
+    }
+}
+
+// In-place DFT of R points (R in {2,4,8,16,32}); result k sits at v[bitrev_R(k)].
+template <int R> __device__ __forceinline__ void dif(float2 *v)
+{
+    const float *tok = &v[R - 1].y;
+    dif_rec<R>(v, tok);
+}
+
+template <int R> __host__ __device__ constexpr int bitrev(int k)
+{
+    int r = 0;
+    for (int b = 1; b < R; b <<= 1) { r = (r << 1) | (k & 1); k >>= 1; }
+    return r;
+}
+
+__device__ __forceinline__ constexpr int lds_pad(int i) { return i + (i >> 5); }
+
+}  // namespace ro

@@ -1,0 +1,47 @@
+// ro_kernels.h -- host-visible launch interface of the gfx950 kernels (internal,
+// not part of the C ABI; see include/ro_stft.h for that).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ro_stft.h"
+
+#define RO_FMT_F32 RO_IQ_F32
+#define RO_FMT_I16 RO_IQ_I16
+
+namespace ro {
+
+struct StftArgs {
+    const void   *iq;          // sample 0 of the stream (device)
+    const float  *window;      // bins floats (device)
+    const float2 *twiddles;    // per-stage tables (device), see stft_fill_twiddles
+    float        *rows_out;    // rows x row_stride, or nullptr
+    float        *tile_out;    // rows x tile_cols, or nullptr
+    int64_t       first_row;
+    int64_t       rows;
+    int64_t       row_stride;
+    int           hop;
+    int           tile_first;
+    int           tile_cols;
+    float         gain;
+};
+
+struct ScanArgs {
+    const float      *rows_in;
+    ro_scan_record_t *records;
+    int64_t           rows;
+    int64_t           row_stride;
+    int               bins;
+    int               low_noise, noise_width;
+    int               low_detect, detect_width;
+    int               avg_bins;
+};
+
+bool       stft_supported(int bins);
+int        stft_twiddle_count(int bins);          // float2 entries, <0 if unsupported
+bool       stft_radices(int bins, int radices[4]);
+hipError_t launch_stft(int bins, int fmt, const StftArgs &a, hipStream_t s);
+hipError_t launch_scan(const ScanArgs &a, hipStream_t s);
+
+}  // namespace ro

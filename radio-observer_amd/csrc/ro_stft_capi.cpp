@@ -1,0 +1,636 @@
+// ro_stft_capi.cpp -- implementation of the C ABI in include/ro_stft.h.
+//
+// Host side of the MI355X STFT path: owns the window / twiddle tables in HBM,
+// the streaming staging buffers, and launches the kernels of ro_kernels.hip.
+// There is no CPU compute path in this file: rows only ever come out of the
+// HIP kernels.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
+
+#include "../../include/ro_stft.h"
+#include "ro_kernels.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(RO_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));       \
+    } while (0)
+
+// window tables: same arithmetic as FFTBackend::startStream (src/FFTBackend.cpp:156-186):
+// float coefficients, double pi = 4*atan(1), (float)i and (float)(bins-1) widened to double,
+// evaluation in double, one narrowing on store.
+void build_window(int kind, int bins, float *w)
+{
+    const double pi = 4.0 * std::atan(1.0);
+    const double denom = (double)(float)(bins - 1);
+    if (kind == RO_WINDOW_HANN) {
+        for (int i = 0; i < bins; ++i)
+            w[i] = (float)(0.5 * (1.0 - std::cos(2.0 * pi * (double)(float)i / denom)));
+        return;
+    }
+    const float a0 = 0.355768f, a1 = 0.487396f, a2 = 0.144232f, a3 = 0.012604f;
+    for (int i = 0; i < bins; ++i) {
+        const double x = (double)(float)i;
+        w[i] = (float)((double)a0 - (double)a1 * std::cos(2.0 * pi * x / denom) +
+                       (double)a2 * std::cos(4.0 * pi * x / denom) -
+                       (double)a3 * std::cos(6.0 * pi * x / denom));
+    }
+}
+
+// per-stage twiddle tables in the layout apply_twiddles() reads:
+//   stage with radix R after sub-transforms of length NS: entry (r-1)*NS + k = exp(-2 pi i r k / (NS R))
+// evaluated in long double and rounded once to float.
+std::vector<float2> build_twiddles(int bins)
+{
+    int radix[4];
+    std::vector<float2> tw;
+    if (!ro::stft_radices(bins, radix)) return tw;
+    const long double two_pi = 8.0L * atanl(1.0L);
+    long ns = radix[0];
+    for (int s = 1; s < 4; ++s) {
+        const int R = radix[s];
+        if (R <= 1) continue;
+        for (int r = 1; r < R; ++r)
+            for (long k = 0; k < ns; ++k) {
+                const long double ang = -two_pi * (long double)((long long)r * k) / (long double)(ns * R);
+                tw.push_back(make_float2((float)cosl(ang), (float)sinl(ang)));
+            }
+        ns *= R;
+    }
+    return tw;
+}
+
+struct Batch {
+    int64_t first_row = 0;
+    int64_t rows = 0;
+    std::vector<float> data;                   // rows x bins
+    std::vector<ro_scan_record_t> records;     // rows (empty when scan disabled)
+    int64_t consumed = 0;                      // rows already fetched
+};
+
+}  // namespace
+
+struct ro_stft {
+    ro_stft_config_t cfg{};
+    int bins = 0, overlap = 0, hop = 0;
+    int device = 0;
+    std::string device_name;
+    std::vector<float> window;
+    float *d_window = nullptr;
+    float2 *d_twiddles = nullptr;
+    hipStream_t stream = nullptr;
+
+    // streaming state
+    int batch_rows = 0;
+    std::vector<float> staged;                 // interleaved f32 I,Q not yet consumed
+    int64_t stream_sample0 = 0;                // stream index of staged[0]
+    int64_t rows_emitted = 0;                  // stream index of the next row to compute
+    float *d_iq = nullptr;                     // batch input  ((batch_rows-1)*hop + bins samples)
+    float *d_rows = nullptr;                   // batch output (batch_rows x bins)
+    ro_scan_record_t *d_records = nullptr;
+    std::deque<Batch> ready;
+    int64_t rows_ready = 0;
+    int64_t stat_samples = 0, stat_rows = 0, stat_launches = 0;
+    double stat_kernel_ms = 0.0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int check_bands(const ro_stft *h, const ro_bands_t &b)
+{
+    if (b.noise_width <= 0 || b.detect_width <= 0 || b.avg_bins <= 0)
+        return fail(RO_ERR_INVALID, "bands: widths and avg_bins must be positive");
+    if (b.low_noise < 0 || b.low_noise + b.noise_width > h->bins)
+        return fail(RO_ERR_INVALID, "bands: noise band [%d,+%d) outside [0,%d)", b.low_noise,
+                    b.noise_width, h->bins);
+    if (b.low_detect < 0 || b.low_detect + b.detect_width > h->bins)
+        return fail(RO_ERR_INVALID, "bands: detect band [%d,+%d) outside [0,%d)", b.low_detect,
+                    b.detect_width, h->bins);
+    return RO_OK;
+}
+
+int validate_resident(const ro_stft *h, const void *d_iq, int format, int64_t samples,
+                      int64_t first_row, int64_t rows, const float *d_rows, int64_t row_stride,
+                      const float *d_tile, const ro_scan_record_t *d_records)
+{
+    if (!h) return fail(RO_ERR_INVALID, "null handle");
+    if (format != RO_IQ_F32 && format != RO_IQ_I16)
+        return fail(RO_ERR_INVALID, "resident input must be RO_IQ_F32 or RO_IQ_I16 (got %d)", format);
+    if (rows < 0 || first_row < 0) return fail(RO_ERR_INVALID, "negative row range");
+    if (rows == 0) return RO_OK;
+    if (!d_iq) return fail(RO_ERR_INVALID, "null input pointer");
+    if (!d_rows && !d_tile) return fail(RO_ERR_INVALID, "no output requested (rows and tile both null)");
+    if (d_rows && row_stride < h->bins)
+        return fail(RO_ERR_INVALID, "row_stride %lld < bins %d", (long long)row_stride, h->bins);
+    if (d_tile && h->cfg.tile_cols <= 0) return fail(RO_ERR_INVALID, "tile output requested but tile_cols == 0");
+    if (d_records && !h->cfg.enable_scan) return fail(RO_ERR_INVALID, "records requested but enable_scan == 0");
+    if (d_records && !d_rows) return fail(RO_ERR_INVALID, "records need full rows (d_rows)");
+    // every workgroup reads samples [r*hop, r*hop + bins): the last one must stay inside the buffer
+    const int64_t last = (first_row + rows - 1) * (int64_t)h->hop + h->bins;
+    if (last > samples)
+        return fail(RO_ERR_INVALID, "rows [%lld,+%lld) need %lld samples, buffer holds %lld",
+                    (long long)first_row, (long long)rows, (long long)last, (long long)samples);
+    if (rows > (int64_t)0x0fffffff) return fail(RO_ERR_INVALID, "too many rows in one launch");
+    return RO_OK;
+}
+
+ro::StftArgs make_stft_args(const ro_stft *h, const void *d_iq, int64_t first_row, int64_t rows,
+                            float *d_rows, int64_t row_stride, float *d_tile)
+{
+    ro::StftArgs a{};
+    a.iq = d_iq;
+    a.window = h->d_window;
+    a.twiddles = h->d_twiddles;
+    a.rows_out = d_rows;
+    a.tile_out = d_tile;
+    a.first_row = first_row;
+    a.rows = rows;
+    a.row_stride = row_stride;
+    a.hop = h->hop;
+    a.tile_first = h->cfg.tile_first_col;
+    a.tile_cols = h->cfg.tile_cols;
+    a.gain = (float)h->cfg.iq_gain;
+    return a;
+}
+
+ro::ScanArgs make_scan_args(const ro_stft *h, const float *d_rows, int64_t row_stride, int64_t rows,
+                            ro_scan_record_t *d_records)
+{
+    ro::ScanArgs s{};
+    s.rows_in = d_rows;
+    s.records = d_records;
+    s.rows = rows;
+    s.row_stride = row_stride;
+    s.bins = h->bins;
+    s.low_noise = h->cfg.bands.low_noise;
+    s.noise_width = h->cfg.bands.noise_width;
+    s.low_detect = h->cfg.bands.low_detect;
+    s.detect_width = h->cfg.bands.detect_width;
+    s.avg_bins = h->cfg.bands.avg_bins;
+    return s;
+}
+
+// run one batch of the streaming path: rows [rows_emitted, +rows) from the staged samples
+int run_stream_batch(ro_stft *h, int64_t rows)
+{
+    if (rows <= 0) return RO_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    const int64_t need = (rows - 1) * (int64_t)h->hop + h->bins;       // samples
+    HIP_TRY(hipMemcpyAsync(h->d_iq, h->staged.data(), (size_t)need * 2 * sizeof(float),
+                           hipMemcpyHostToDevice, h->stream));
+    ro::StftArgs a = make_stft_args(h, h->d_iq, 0, rows, h->d_rows, h->bins, nullptr);
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    HIP_TRY(ro::launch_stft(h->bins, RO_IQ_F32, a, h->stream));
+    if (h->cfg.enable_scan) {
+        ro::ScanArgs s = make_scan_args(h, h->d_rows, h->bins, rows, h->d_records);
+        HIP_TRY(ro::launch_scan(s, h->stream));
+    }
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+
+    Batch b;
+    b.first_row = h->rows_emitted;
+    b.rows = rows;
+    b.data.resize((size_t)rows * h->bins);
+    HIP_TRY(hipMemcpyAsync(b.data.data(), h->d_rows, b.data.size() * sizeof(float),
+                           hipMemcpyDeviceToHost, h->stream));
+    if (h->cfg.enable_scan) {
+        b.records.resize((size_t)rows);
+        HIP_TRY(hipMemcpyAsync(b.records.data(), h->d_records, (size_t)rows * sizeof(ro_scan_record_t),
+                               hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->stat_kernel_ms += ms;
+    h->stat_launches += 1;
+    h->stat_rows += rows;
+
+    // drop the samples no later row needs: the next row starts rows*hop further on
+    const int64_t consumed = rows * (int64_t)h->hop;
+    h->staged.erase(h->staged.begin(), h->staged.begin() + (size_t)consumed * 2);
+    h->stream_sample0 += consumed;
+    h->rows_emitted += rows;
+    h->rows_ready += rows;
+    h->ready.push_back(std::move(b));
+    return RO_OK;
+}
+
+int64_t staged_complete_rows(const ro_stft *h)
+{
+    const int64_t have = (int64_t)(h->staged.size() / 2);
+    if (have < h->bins) return 0;
+    return (have - h->bins) / h->hop + 1;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// library
+// ---------------------------------------------------------------------------
+extern "C" int ro_abi_version(void) { return RO_ABI_VERSION; }
+extern "C" const char *ro_last_error(void) { return g_error.c_str(); }
+
+extern "C" int ro_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(RO_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+// ---------------------------------------------------------------------------
+// host helpers (FFTBackend's scalar arithmetic; float/double mixing as in the reference)
+// ---------------------------------------------------------------------------
+extern "C" int ro_clamp_overlap(int bins, int overlap)
+{
+    if (overlap < 0) return 0;                       // src/FFTBackend.cpp:108
+    if (overlap >= bins) return bins - 1;            // :109
+    return overlap;
+}
+
+extern "C" float ro_fft_sample_rate(int sample_rate, int bins, int overlap)
+{
+    return (float)sample_rate / (float)(bins - ro_clamp_overlap(bins, overlap));   // :150-151
+}
+
+extern "C" int ro_frequency_to_bin(int bins, int sample_rate, float frequency)
+{
+    // src/FFTBackend.h:169-175: float quotient, double sum and product, truncation, clamp
+    const float sr = (float)sample_rate, n = (float)bins;
+    const int bin = (int)((double)n * ((double)(frequency / sr) + 0.5));
+    if (bin < 0) return 0;
+    if (bin >= bins) return bins - 1;
+    return bin;
+}
+
+extern "C" float ro_bin_to_frequency(int bins, int sample_rate, int bin)
+{
+    // src/FFTBackend.h:141-145: float quotient, the rest in double, narrowed on return
+    const float b = (float)bin, sr = (float)sample_rate, n = (float)bins;
+    return (float)((double)sr * (-0.5 + (double)(b / n)));
+}
+
+extern "C" int ro_time_to_fft_samples(double seconds, float fft_sample_rate)
+{
+    return (int)(seconds * (double)fft_sample_rate);             // src/FFTBackend.h:197-200
+}
+
+extern "C" int64_t ro_row_count(int64_t samples, int bins, int overlap)
+{
+    const int64_t hop = bins - ro_clamp_overlap(bins, overlap);
+    if (samples < bins) return 0;
+    return (samples - bins) / hop + 1;
+}
+
+extern "C" int ro_window_table(int kind, int bins, float *out)
+{
+    if (!out || bins < 2) return fail(RO_ERR_INVALID, "ro_window_table: bad arguments");
+    if (kind != RO_WINDOW_NUTTALL && kind != RO_WINDOW_HANN)
+        return fail(RO_ERR_INVALID, "ro_window_table: kind %d has no formula", kind);
+    build_window(kind, bins, out);
+    return RO_OK;
+}
+
+extern "C" int ro_bins_supported(int bins) { return ro::stft_supported(bins) ? 1 : 0; }
+
+// ---------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------
+extern "C" int ro_stft_create(const ro_stft_config_t *cfg, ro_stft_t **out)
+{
+    if (!cfg || !out) return fail(RO_ERR_INVALID, "ro_stft_create: null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(ro_stft_config_t))
+        return fail(RO_ERR_INVALID, "ro_stft_create: struct_size %u != %zu", cfg->struct_size,
+                    sizeof(ro_stft_config_t));
+    if (!ro::stft_supported(cfg->bins))
+        return fail(RO_ERR_UNSUPPORTED, "bins = %d has no kernel (powers of two 256..32768)", cfg->bins);
+    if (cfg->iq_phase_shift != 0)
+        return fail(RO_ERR_UNSUPPORTED, "iq_phase_shift != 0 is undefined behaviour in the reference "
+                                        "(src/FFTBackend.cpp:67-71) and is not supported");
+    if (cfg->sample_rate <= 0) return fail(RO_ERR_INVALID, "sample_rate must be positive");
+    if (cfg->window_kind == RO_WINDOW_CUSTOM && !cfg->window_table)
+        return fail(RO_ERR_INVALID, "RO_WINDOW_CUSTOM needs window_table");
+    if (cfg->window_kind < RO_WINDOW_NUTTALL || cfg->window_kind > RO_WINDOW_CUSTOM)
+        return fail(RO_ERR_INVALID, "unknown window_kind %d", cfg->window_kind);
+    if (cfg->tile_cols < 0 || cfg->tile_first_col < 0 || cfg->tile_first_col + cfg->tile_cols > cfg->bins)
+        return fail(RO_ERR_INVALID, "tile [%d,+%d) outside [0,%d)", cfg->tile_first_col, cfg->tile_cols,
+                    cfg->bins);
+
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(RO_ERR_HIP, "device %d not present (%d devices)", cfg->device, ndev);
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    ro_stft *h = new (std::nothrow) ro_stft();
+    if (!h) return fail(RO_ERR_NOMEM, "out of host memory");
+    h->cfg = *cfg;
+    h->cfg.window_table = nullptr;
+    h->bins = cfg->bins;
+    h->overlap = ro_clamp_overlap(cfg->bins, cfg->overlap);
+    h->hop = h->bins - h->overlap;
+    h->device = cfg->device;
+    if (cfg->enable_scan) {
+        int rc = check_bands(h, cfg->bands);
+        if (rc != RO_OK) { delete h; return rc; }
+    }
+
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, cfg->device);
+    if (e != hipSuccess) { delete h; return fail(RO_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e)); }
+    h->device_name = prop.name;
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+        delete h;
+        return fail(RO_ERR_UNSUPPORTED, "device %d is %s; this library is built for gfx950 only",
+                    cfg->device, prop.gcnArchName);
+    }
+
+    h->window.resize(h->bins);
+    if (cfg->window_kind == RO_WINDOW_CUSTOM)
+        std::memcpy(h->window.data(), cfg->window_table, sizeof(float) * h->bins);
+    else
+        build_window(cfg->window_kind, h->bins, h->window.data());
+    std::vector<float2> tw = build_twiddles(h->bins);
+    if ((int)tw.size() != ro::stft_twiddle_count(h->bins)) {
+        delete h;
+        return fail(RO_ERR_STATE, "internal: twiddle table size mismatch");
+    }
+
+#define CREATE_TRY(expr)                                                                   \
+    do {                                                                                   \
+        hipError_t e2_ = (expr);                                                           \
+        if (e2_ != hipSuccess) {                                                           \
+            int rc2_ = fail(RO_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e2_));   \
+            ro_stft_destroy(h);                                                            \
+            return rc2_;                                                                   \
+        }                                                                                  \
+    } while (0)
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreate(&h->ev0));
+    CREATE_TRY(hipEventCreate(&h->ev1));
+    CREATE_TRY(hipMalloc(&h->d_window, sizeof(float) * h->bins));
+    CREATE_TRY(hipMalloc(&h->d_twiddles, sizeof(float2) * std::max<size_t>(tw.size(), 1)));
+    CREATE_TRY(hipMemcpy(h->d_window, h->window.data(), sizeof(float) * h->bins, hipMemcpyHostToDevice));
+    if (!tw.empty())
+        CREATE_TRY(hipMemcpy(h->d_twiddles, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice));
+#undef CREATE_TRY
+
+    // streaming buffers are allocated lazily by the first push
+    h->batch_rows = cfg->max_batch_rows > 0 ? cfg->max_batch_rows
+                                            : std::max(1, (64 << 20) / (h->bins * 4));   // ~64 MiB of rows
+    *out = h;
+    return RO_OK;
+}
+
+extern "C" int ro_stft_destroy(ro_stft_t *h)
+{
+    if (!h) return RO_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->d_window) (void)hipFree(h->d_window);
+    if (h->d_twiddles) (void)hipFree(h->d_twiddles);
+    if (h->d_iq) (void)hipFree(h->d_iq);
+    if (h->d_rows) (void)hipFree(h->d_rows);
+    if (h->d_records) (void)hipFree(h->d_records);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return RO_OK;
+}
+
+extern "C" int ro_stft_get_window(const ro_stft_t *h, float *out)
+{
+    if (!h || !out) return fail(RO_ERR_INVALID, "null argument");
+    std::memcpy(out, h->window.data(), sizeof(float) * h->bins);
+    return RO_OK;
+}
+
+extern "C" int ro_stft_hop(const ro_stft_t *h) { return h ? h->hop : fail(RO_ERR_INVALID, "null handle"); }
+extern "C" int ro_stft_bins(const ro_stft_t *h) { return h ? h->bins : fail(RO_ERR_INVALID, "null handle"); }
+
+extern "C" int ro_stft_device_name(const ro_stft_t *h, char *buf, size_t len)
+{
+    if (!h || !buf || len == 0) return fail(RO_ERR_INVALID, "null argument");
+    std::snprintf(buf, len, "%s", h->device_name.c_str());
+    return RO_OK;
+}
+
+extern "C" int ro_stft_set_bands(ro_stft_t *h, const ro_bands_t *bands)
+{
+    if (!h || !bands) return fail(RO_ERR_INVALID, "null argument");
+    int rc = check_bands(h, *bands);
+    if (rc != RO_OK) return rc;
+    h->cfg.bands = *bands;
+    h->cfg.enable_scan = 1;
+    return RO_OK;
+}
+
+// ---------------------------------------------------------------------------
+// resident path
+// ---------------------------------------------------------------------------
+extern "C" int ro_stft_run_resident(ro_stft_t *h, const void *d_iq, int format, int64_t samples,
+                                    int64_t first_row, int64_t rows, float *d_rows, int64_t row_stride,
+                                    float *d_tile, ro_scan_record_t *d_records, void *stream)
+{
+    int rc = validate_resident(h, d_iq, format, samples, first_row, rows, d_rows, row_stride, d_tile,
+                               d_records);
+    if (rc != RO_OK || rows == 0) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    ro::StftArgs a = make_stft_args(h, d_iq, first_row, rows, d_rows, row_stride, d_tile);
+    HIP_TRY(ro::launch_stft(h->bins, format, a, s));
+    if (d_records) {
+        ro::ScanArgs sc = make_scan_args(h, d_rows, row_stride, rows, d_records);
+        HIP_TRY(ro::launch_scan(sc, s));
+    }
+    h->stat_launches += 1;
+    h->stat_rows += rows;
+    return RO_OK;
+}
+
+extern "C" int ro_stft_scan_resident(ro_stft_t *h, const float *d_rows, int64_t row_stride, int64_t rows,
+                                     ro_scan_record_t *d_records, void *stream)
+{
+    if (!h || !d_rows || !d_records) return fail(RO_ERR_INVALID, "null argument");
+    if (!h->cfg.enable_scan) return fail(RO_ERR_STATE, "scan bands not configured");
+    if (rows < 0 || row_stride < h->bins) return fail(RO_ERR_INVALID, "bad rows / row_stride");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    ro::ScanArgs sc = make_scan_args(h, d_rows, row_stride, rows, d_records);
+    HIP_TRY(ro::launch_scan(sc, s));
+    return RO_OK;
+}
+
+extern "C" int ro_stft_time_resident(ro_stft_t *h, const void *d_iq, int format, int64_t samples,
+                                     int64_t first_row, int64_t rows, float *d_rows, int64_t row_stride,
+                                     float *d_tile, ro_scan_record_t *d_records, void *stream, int iters,
+                                     float *ms_out, float *kernel_ms_out)
+{
+    int rc = validate_resident(h, d_iq, format, samples, first_row, rows, d_rows, row_stride, d_tile,
+                               d_records);
+    if (rc != RO_OK) return rc;
+    if (iters <= 0 || !ms_out) return fail(RO_ERR_INVALID, "iters must be positive and ms_out non-null");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    std::vector<hipEvent_t> ev((size_t)iters * 3);
+    for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+    ro::StftArgs a = make_stft_args(h, d_iq, first_row, rows, d_rows, row_stride, d_tile);
+    ro::ScanArgs sc = make_scan_args(h, d_rows, row_stride, rows, d_records);
+    for (int i = 0; i < iters; ++i) {
+        HIP_TRY(hipEventRecord(ev[3 * i], s));
+        HIP_TRY(ro::launch_stft(h->bins, format, a, s));
+        HIP_TRY(hipEventRecord(ev[3 * i + 1], s));
+        if (d_records) HIP_TRY(ro::launch_scan(sc, s));
+        HIP_TRY(hipEventRecord(ev[3 * i + 2], s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    double k0 = 0.0, k1 = 0.0;
+    for (int i = 0; i < iters; ++i) {
+        float t = 0.f, t0 = 0.f, t1 = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, ev[3 * i], ev[3 * i + 2]));
+        HIP_TRY(hipEventElapsedTime(&t0, ev[3 * i], ev[3 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&t1, ev[3 * i + 1], ev[3 * i + 2]));
+        ms_out[i] = t;
+        k0 += t0;
+        k1 += t1;
+    }
+    if (kernel_ms_out) {
+        kernel_ms_out[0] = (float)(k0 / iters);
+        kernel_ms_out[1] = (float)(k1 / iters);
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    h->stat_launches += iters;
+    h->stat_rows += rows * (int64_t)iters;
+    return RO_OK;
+}
+
+// ---------------------------------------------------------------------------
+// streaming path
+// ---------------------------------------------------------------------------
+extern "C" int ro_stft_push(ro_stft_t *h, const void *iq, int format, int64_t samples, int64_t *rows_ready)
+{
+    if (!h) return fail(RO_ERR_INVALID, "null handle");
+    if (samples < 0 || (samples > 0 && !iq)) return fail(RO_ERR_INVALID, "bad sample buffer");
+    if (format != RO_IQ_F32 && format != RO_IQ_I16 && format != RO_IQ_F64)
+        return fail(RO_ERR_INVALID, "unknown sample format %d", format);
+
+    if (!h->d_iq) {
+        HIP_TRY(hipSetDevice(h->device));
+        const size_t in_samples = (size_t)(h->batch_rows - 1) * h->hop + h->bins;
+        HIP_TRY(hipMalloc(&h->d_iq, in_samples * 2 * sizeof(float)));
+        HIP_TRY(hipMalloc(&h->d_rows, (size_t)h->batch_rows * h->bins * sizeof(float)));
+        HIP_TRY(hipMalloc(&h->d_records, (size_t)h->batch_rows * sizeof(ro_scan_record_t)));
+    }
+
+    // the caller's buffer is only valid during the call (src/WAVStream.cpp:113,123): copy now.
+    const size_t old = h->staged.size();
+    h->staged.resize(old + (size_t)samples * 2);
+    float *dst = h->staged.data() + old;
+    if (format == RO_IQ_F32) {
+        std::memcpy(dst, iq, (size_t)samples * 2 * sizeof(float));
+    } else if (format == RO_IQ_I16) {
+        const int16_t *s = static_cast<const int16_t *>(iq);
+        for (int64_t i = 0; i < samples * 2; ++i) dst[i] = (float)s[i];       // src/WAVStream.cpp:119-120
+    } else {
+        const double *s = static_cast<const double *>(iq);                     // struct Complex
+        for (int64_t i = 0; i < samples * 2; ++i) dst[i] = (float)s[i];
+    }
+    h->stat_samples += samples;
+
+    while (staged_complete_rows(h) >= h->batch_rows) {
+        int rc = run_stream_batch(h, h->batch_rows);
+        if (rc != RO_OK) return rc;
+    }
+    if (rows_ready) *rows_ready = h->rows_ready;
+    return RO_OK;
+}
+
+extern "C" int ro_stft_flush(ro_stft_t *h, int64_t *rows_ready)
+{
+    if (!h) return fail(RO_ERR_INVALID, "null handle");
+    while (h->d_iq) {
+        const int64_t n = std::min<int64_t>(staged_complete_rows(h), h->batch_rows);
+        if (n <= 0) break;
+        int rc = run_stream_batch(h, n);
+        if (rc != RO_OK) return rc;
+    }
+    if (rows_ready) *rows_ready = h->rows_ready;
+    return RO_OK;
+}
+
+extern "C" int ro_stft_fetch(ro_stft_t *h, int64_t max_rows, int first_col, int cols, float *rows_out,
+                             ro_scan_record_t *records_out, int64_t *first_row_index, int64_t *rows_got)
+{
+    if (!h || !rows_got) return fail(RO_ERR_INVALID, "null argument");
+    if (max_rows < 0) return fail(RO_ERR_INVALID, "negative max_rows");
+    if (rows_out && (first_col < 0 || cols <= 0 || first_col + cols > h->bins))
+        return fail(RO_ERR_INVALID, "columns [%d,+%d) outside [0,%d)", first_col, cols, h->bins);
+    if (records_out && !h->cfg.enable_scan) return fail(RO_ERR_STATE, "scan records requested but scan is off");
+    int64_t got = 0;
+    if (first_row_index) *first_row_index = h->ready.empty() ? h->rows_emitted
+                                                             : h->ready.front().first_row + h->ready.front().consumed;
+    while (got < max_rows && !h->ready.empty()) {
+        Batch &b = h->ready.front();
+        const int64_t take = std::min(max_rows - got, b.rows - b.consumed);
+        for (int64_t r = 0; r < take; ++r) {
+            const float *src = b.data.data() + (size_t)(b.consumed + r) * h->bins + first_col;
+            if (rows_out) std::memcpy(rows_out + (size_t)(got + r) * cols, src, sizeof(float) * cols);
+            if (records_out) records_out[got + r] = b.records[(size_t)(b.consumed + r)];
+        }
+        b.consumed += take;
+        got += take;
+        if (b.consumed == b.rows) h->ready.pop_front();
+    }
+    h->rows_ready -= got;
+    *rows_got = got;
+    return RO_OK;
+}
+
+extern "C" int ro_stft_reset(ro_stft_t *h)
+{
+    if (!h) return fail(RO_ERR_INVALID, "null handle");
+    h->staged.clear();
+    h->ready.clear();
+    h->stream_sample0 = 0;
+    h->rows_emitted = 0;
+    h->rows_ready = 0;
+    return RO_OK;
+}
+
+extern "C" int ro_stft_stats(const ro_stft_t *h, int64_t *samples_in, int64_t *rows_out, int64_t *launches,
+                             double *kernel_ms_total)
+{
+    if (!h) return fail(RO_ERR_INVALID, "null handle");
+    if (samples_in) *samples_in = h->stat_samples;
+    if (rows_out) *rows_out = h->stat_rows;
+    if (launches) *launches = h->stat_launches;
+    if (kernel_ms_total) *kernel_ms_total = h->stat_kernel_ms;
+    return RO_OK;
+}

@@ -1,0 +1,36 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def ro():
+    """The product package (directory name has a hyphen, hence importlib)."""
+    return importlib.import_module("radio-observer_amd")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle -- the checker, never the thing under test."""
+    import ro_oracle
+    ro_oracle.lib()
+    return ro_oracle
+
+
+@pytest.fixture(scope="session")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    return torch
