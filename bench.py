@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py -- spectra/s of the MI355X STFT / waterfall / bolid-scan hot path.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched by the driver as
+      python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the env), RCCL = backend "nccl".
+
+Workload (BASELINE.json configs[2..3], "C3/C4"): synthetic IQ resident in HBM, 48 kHz,
+FFT bins = 32768, overlap = 24576 (75 %), Nuttall window, R = 16384 rows per step per GPU
+(T = 32768 + 8192*(R-1) samples = 1.07 GB float32 I/Q in, 2.15 GB of float32 magnitude
+rows out), sigma=1 Gaussian noise + CW carrier 30 sigma at +10.6 kHz; every step also runs
+BolidRecorder's per-row noise/peak/average scan with radio-observer.json's bands.
+
+A "step" = one pass of the hot path over that batch: the fused window->FFT->|X|->shift
+kernel plus the scan kernel, inputs already in HBM.  With N > 1 every rank owns one time
+chunk of R rows (weak scaling, no collective inside the transform) and each step ends with
+the RCCL all-gather of that step's waterfall band tile + scan records -- the stitch the
+reference's FITS writer needs -- overlapped with the next step's compute on a side stream.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BINS, OVERLAP, FS = 32768, 24576, 48000
+HOP = BINS - OVERLAP
+HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+ALG_BYTES_PER_ROW = HOP * 8 + BINS * 4     # hop*8 in + bins*4 out = 196608 B
+# radio-observer.json:62-87
+JSON_SNAPSHOT = (10100.0, 11000.0)
+JSON_BOLID = dict(min_detect=10300.0, max_detect=10900.0, min_noise=9000.0, max_noise=9600.0,
+                  avg_freq_range=40.0)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--rows", type=int, default=16384, help="rows per step per GPU")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-parity", action="store_true")
+    p.add_argument("--pmc-traffic", type=float, default=None,
+                   help="HBM bytes per launch from a separate rocprofv3 --pmc run (see profiles/)")
+    return p.parse_args()
+
+
+def make_bands(ro):
+    f2b = lambda f: ro.frequency_to_bin(BINS, FS, f)
+    lo_d, hi_d = sorted((f2b(JSON_BOLID["min_detect"]), f2b(JSON_BOLID["max_detect"])))
+    lo_n, hi_n = sorted((f2b(JSON_BOLID["min_noise"]), f2b(JSON_BOLID["max_noise"])))
+    avg = f2b(JSON_BOLID["avg_freq_range"]) - f2b(0.0)
+    return ro.Bands(low_noise=lo_n, noise_width=hi_n - lo_n, low_detect=lo_d, detect_width=hi_d - lo_d,
+                    avg_bins=avg)
+
+
+def synth_iq(torch, samples, seed, device):
+    """sigma=1 complex noise + 30 sigma carrier at +10.6 kHz, float32 interleaved [samples, 2]."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    iq = torch.randn((samples, 2), generator=g, device=device, dtype=torch.float32)
+    # carrier phase computed modulo the period so float32 stays exact enough at 1e8 samples
+    t = torch.arange(samples, device=device, dtype=torch.int64)
+    period_num = 10600 * t % FS                       # phase = 2 pi * (10600 t mod 48000) / 48000
+    ph = period_num.to(torch.float64) * (2.0 * np.pi / FS)
+    iq[:, 0] += (30.0 * torch.cos(ph)).to(torch.float32)
+    iq[:, 1] += (30.0 * torch.sin(ph)).to(torch.float32)
+    del t, period_num, ph
+    return iq
+
+
+def cpu_baseline(iq_host, w, bands, budget_s):
+    """Oracle (oracle/ro_oracle.c, -O2, one thread) on a bounded prefix of the same input."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ro_oracle as O
+    O.lib()
+    max_rows = O.row_count(iq_host.shape[0], BINS, OVERLAP)
+    done, chunk = 0, 256
+    t0 = time.perf_counter()
+    while done < max_rows and time.perf_counter() - t0 < budget_s:
+        n = min(chunk, max_rows - done)
+        rows = O.stft(iq_host, BINS, OVERLAP, w=w, first_row=done, max_rows=n)
+        O.scan_rows(rows, bands.low_noise, bands.noise_width, bands.low_detect, bands.detect_width,
+                    bands.avg_bins)
+        done += n
+    dt = time.perf_counter() - t0
+    return done, dt
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be started by torch.distributed.run with %d ranks"
+                     % (a.gpus, a.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    ro = importlib.import_module("radio-observer_amd")
+    R = a.rows
+    samples = BINS + HOP * (R - 1)
+    bands = make_bands(ro)
+    snap_lo = ro.frequency_to_bin(BINS, FS, JSON_SNAPSHOT[0])
+    snap_hi = ro.frequency_to_bin(BINS, FS, JSON_SNAPSHOT[1])
+    tile = (snap_lo, snap_hi - snap_lo) if world > 1 else None
+
+    iq = synth_iq(torch, samples, 0xC3 + rank, dev)       # this rank's time chunk
+    rows = torch.empty((R, BINS), dtype=torch.float32, device=dev)
+    recs = [torch.zeros((R, 3), dtype=torch.float32, device=dev) for _ in range(2)]   # ro_scan_record_t = 12 B
+    st = ro.Stft(bins=BINS, overlap=OVERLAP, sample_rate=FS, device=local_rank, bands=bands, tile=tile)
+    stream = torch.cuda.current_stream()
+    sptr = stream.cuda_stream
+
+    gather = None
+    if world > 1:
+        tcols = tile[1]
+        tiles = [torch.empty((R, tcols), dtype=torch.float32, device=dev) for _ in range(2)]
+        g_tiles = [torch.empty((world * R, tcols), dtype=torch.float32, device=dev) for _ in range(2)]
+        g_recs = [torch.empty((world * R, 3), dtype=torch.float32, device=dev) for _ in range(2)]
+        comm_stream = torch.cuda.Stream(device=dev)
+        comm_done = [None, None]
+        gather = True
+
+    def step(i):
+        b = i & 1
+        if gather:
+            if comm_done[b] is not None:
+                stream.wait_event(comm_done[b])            # tile buffer b is free again
+            st.run_resident(iq, ro.RO_IQ_F32, samples, 0, R, rows, d_tile=tiles[b], d_records=recs[b],
+                            stream=sptr)
+            ready = torch.cuda.Event()
+            ready.record(stream)
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(ready)
+                dist.all_gather_into_tensor(g_tiles[b], tiles[b])
+                dist.all_gather_into_tensor(g_recs[b], recs[b])
+                ev = torch.cuda.Event()
+                ev.record(comm_stream)
+                comm_done[b] = ev
+        else:
+            st.run_resident(iq, ro.RO_IQ_F32, samples, 0, R, rows, d_records=recs[b], stream=sptr)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for i in range(a.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- kernel durations with HIP events on the launch stream (same launches as the timed loop)
+    ms_all, k_stft, k_scan = st.time_resident(iq, ro.RO_IQ_F32, samples, 0, R, rows, max(a.steps, 5),
+                                              d_records=recs[0], stream=sptr)
+    torch.cuda.synchronize(dev)
+
+    out = None
+    if rank == 0:
+        total_rows = R * world * a.steps
+        value = total_rows / dt
+        achieved = ALG_BYTES_PER_ROW * R / (k_stft * 1e-3) / 1e9
+        out = {
+            "metric": "FFT rows/sec (spectra/sec), N=32768 75% overlap, incl. per-row bolid scan",
+            "value": value, "unit": "rows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C3/C4: synthetic IQ 48 kHz, FFT bins=32768, overlap=24576 (75%), "
+                                   "Nuttall window, waterfall magnitude rows + BolidRecorder scan",
+                       "rows_per_step_per_gpu": R, "samples_per_step_per_gpu": samples,
+                       "input": "float32 I/Q resident in HBM", "output": "float32 rows in HBM",
+                       "parallelism": "time-chunk per GPU" + ("; all-gather of band tile [%d,+%d) + scan "
+                                                              "records per step, overlapped" % tile if tile else "")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": a.pmc_traffic,
+                         "kernel": "stft_kernel<32768>", "kernel_ms": k_stft,
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_ROW * R,
+                         "scan_kernel_ms": k_scan},
+            "device": st.device_name,
+        }
+
+        # ---- device copy bandwidth for context (float32 copy of the row buffer)
+        c = torch.empty_like(rows)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            c.copy_(rows)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        out["device_copy_GBs"] = 2 * rows.numel() * 4 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del c
+
+        # ---- parity spot check of this run's output (oracle = checker only)
+        if not a.no_parity:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import ro_oracle as O
+            pick = [0, 1, R // 2, R - 1]
+            worst = 0.0
+            scan_ok = True
+            rec_host = recs[0].cpu().numpy().view(np.uint8).reshape(R, 12)
+            rec_host = np.frombuffer(rec_host.tobytes(), dtype=ro.capi.SCAN_DTYPE)
+            for r in pick:
+                seg = iq[r * HOP:r * HOP + BINS].cpu().numpy()
+                want = O.stft(seg, BINS, OVERLAP, w=st.window)[0]
+                got = rows[r].cpu().numpy()
+                worst = max(worst, float(np.abs(got.astype(np.float64) - want).max() / want.max()))
+                n, p, av = O.scan_rows(got[None, :], bands.low_noise, bands.noise_width, bands.low_detect,
+                                       bands.detect_width, bands.avg_bins)
+                scan_ok &= (n[0] == rec_host["noise"][r] and p[0] == rec_host["peak"][r]
+                            and av[0] == rec_host["average"][r])
+            out["parity"] = {"rows_checked": pick, "max_err_rel_to_row_max": worst, "tolerance": 1e-5,
+                             "scan_records_bit_exact": bool(scan_ok)}
+
+        # ---- CPU baseline (rank 0, N=1 only): the oracle port on the host cores of this box
+        if world == 1 and not a.no_cpu_baseline:
+            n_cpu = min(R, 8192)
+            host = iq[:BINS + HOP * (n_cpu - 1)].cpu().numpy()
+            done, cdt = cpu_baseline(host, st.window, bands, a.cpu_seconds)
+            out["cpu_baseline"] = {"value": done / cdt, "unit": "rows/s", "cores": 1, "kind": "port",
+                                   "sample": "first %d rows of the same input (%.1f s): oracle/ro_oracle.c -O2, "
+                                             "FP64 radix-2 FFT + scan, single thread; host has %d cores"
+                                             % (done, cdt, os.cpu_count() or 0)}
+        print(json.dumps(out), flush=True)
+
+    st.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
