@@ -126,9 +126,9 @@ int ro_stft_set_bands(ro_stft_t *h, const ro_bands_t *bands);
  * and WaterfallBackend::processFFT's magnitude/shift (src/WaterfallBackend.cpp:485-505).
  *   d_iq        device pointer to sample 0 of the stream, `format` F32 or I16
  *   samples     number of complex samples addressable at d_iq
- *   d_rows      device, rows x row_stride floats (row_stride >= bins); may be NULL
- *               only if d_tile is given
- *   d_tile      device, rows x tile_cols floats, or NULL
+ *   d_rows      device, rows x row_stride floats (row_stride >= bins); required
+ *   d_tile      device, rows x tile_cols floats (compact copy of columns
+ *               [tile_first_col, +tile_cols) of d_rows), or NULL
  *   d_records   device, rows records, or NULL (needs enable_scan)
  *   stream      hipStream_t as void* (NULL = the handle's own stream)
  * The call is asynchronous on `stream`. */

@@ -100,9 +100,12 @@ def library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_build.LIB):
-        _build.build()
-    lib = C.CDLL(_build.LIB)
+    path = os.environ.get("RO_STFT_LIB")           # diagnostic builds (tools/ablate.sh) only
+    if not path:
+        path = _build.LIB
+        if not os.path.exists(path):
+            _build.build()
+    lib = C.CDLL(path)
     for name, (res, args) in _EXPORTS.items():
         fn = getattr(lib, name)       # AttributeError here = symbol missing from the .so
         fn.restype = res

@@ -40,56 +40,62 @@ template <> struct W32<13> { static constexpr float c = -RO_C3, s = RO_C5; };
 template <> struct W32<14> { static constexpr float c = -RO_C2, s = RO_C6; };
 template <> struct W32<15> { static constexpr float c = -RO_C1, s = RO_C7; };
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+// Complex values are clang 2-vectors: v2f arithmetic lowers to the packed VALU ops
+// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32, two flops per lane per issue slot), the
+// .yx / .xx swizzles fold into op_sel, and constant pairs live in SGPRs.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// a * w for a twiddle held in registers: (ax wx - ay wy, ay wx + ax wy)
+__device__ __forceinline__ v2f cmul(v2f a, v2f w)
 {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    const v2f t = a * w.xx;
+    return __builtin_elementwise_fma(a.yx, (v2f){-w.y, w.y}, t);
 }
 
-// d * exp(-2*pi*i*M/32)
-template <int M> __device__ __forceinline__ float2 mul_w32(float2 d)
+// d * exp(-2*pi*i*M/32) = (x c + y s, y c - x s)
+template <int M> __device__ __forceinline__ v2f mul_w32(v2f d)
 {
     if constexpr (M == 0) {
         return d;
-    } else if constexpr (M == 8) {            // * (-i)
-        return make_float2(d.y, -d.x);
-    } else if constexpr (M == 4) {            // * (1 - i)/sqrt2
-        return make_float2((d.x + d.y) * RO_C4, (d.y - d.x) * RO_C4);
-    } else if constexpr (M == 12) {           // * (-1 - i)/sqrt2
-        return make_float2((d.y - d.x) * RO_C4, -(d.x + d.y) * RO_C4);
+    } else if constexpr (M == 8) {            // * (-i) = (y, -x)
+        return d.yx * (v2f){1.0f, -1.0f};
     } else {
-        constexpr float c = W32<M>::c, s = W32<M>::s;
-        return make_float2(d.x * c + d.y * s, d.y * c - d.x * s);
+        constexpr float c = (M == 4) ? RO_C4 : (M == 12) ? -RO_C4 : W32<M == 4 || M == 12 ? 1 : M>::c;
+        constexpr float s = (M == 4 || M == 12) ? RO_C4 : W32<M == 4 || M == 12 ? 1 : M>::s;
+        const v2f t = d * (v2f){c, c};
+        return __builtin_elementwise_fma(d.yx, (v2f){s, -s}, t);
     }
 }
 
 // Scheduling leash.  hipcc's scheduler interleaves all independent butterflies of a
-// level (4 temporaries each) and the 1024-thread kernel no longer fits its 128 VGPRs.
+// level (temporaries for each) and the 1024-thread kernel no longer fits its 128 VGPRs.
 // tie() makes x look recomputed from dep (no instruction is emitted), which chains
 // every SEQ_G-th butterfly behind the previous one in program order: at most SEQ_G
 // butterflies' temporaries are live, and four waves per SIMD cover the lost ILP.
-constexpr int SEQ_G = 2;
+#ifndef RO_SEQ_G
+#define RO_SEQ_G 2
+#endif
+constexpr int SEQ_G = RO_SEQ_G;
 
-__device__ __forceinline__ void tie(float &x, const float &dep) { asm volatile("" : "+v"(x) : "v"(dep)); }
+__device__ __forceinline__ void tie(v2f &x, const v2f &dep) { asm volatile("" : "+v"(x) : "v"(dep)); }
 
 // One decimation-in-frequency level of a size-R sub-transform: butterfly I.
-template <int R, int I> __device__ __forceinline__ void dif_bfly(float2 *v, const float *&tok)
+template <int R, int I> __device__ __forceinline__ void dif_bfly(v2f *v, const v2f *&tok)
 {
-    if constexpr (I % SEQ_G == 0) tie(v[I].x, *tok);
-    float2 a = v[I], b = v[I + R / 2];
-    v[I] = cadd(a, b);
-    v[I + R / 2] = mul_w32<I * (32 / R)>(csub(a, b));
-    tok = &v[I + R / 2].y;
+    if constexpr (I % SEQ_G == 0) tie(v[I], *tok);
+    const v2f a = v[I], b = v[I + R / 2];
+    v[I] = a + b;
+    v[I + R / 2] = mul_w32<I * (32 / R)>(a - b);
+    tok = &v[I + R / 2];
 }
 
 template <int R, int... Is>
-__device__ __forceinline__ void dif_level(float2 *v, const float *&tok, std::integer_sequence<int, Is...>)
+__device__ __forceinline__ void dif_level(v2f *v, const v2f *&tok, std::integer_sequence<int, Is...>)
 {
     (dif_bfly<R, Is>(v, tok), ...);
 }
 
-template <int R> __device__ __forceinline__ void dif_rec(float2 *v, const float *&tok)
+template <int R> __device__ __forceinline__ void dif_rec(v2f *v, const v2f *&tok)
 {
     if constexpr (R >= 2) {
         dif_level<R>(v, tok, std::make_integer_sequence<int, R / 2>{});
@@ -99,9 +105,9 @@ template <int R> __device__ __forceinline__ void dif_rec(float2 *v, const float 
 }
 
 // In-place DFT of R points (R in {2,4,8,16,32}); result k sits at v[bitrev_R(k)].
-template <int R> __device__ __forceinline__ void dif(float2 *v)
+template <int R> __device__ __forceinline__ void dif(v2f *v)
 {
-    const float *tok = &v[R - 1].y;
+    const v2f *tok = &v[R - 1];
     dif_rec<R>(v, tok);
 }
 

@@ -16,15 +16,22 @@ struct StftArgs {
     const void   *iq;          // sample 0 of the stream (device)
     const float  *window;      // bins floats (device)
     const float2 *twiddles;    // per-stage tables (device), see stft_fill_twiddles
-    float        *rows_out;    // rows x row_stride, or nullptr
-    float        *tile_out;    // rows x tile_cols, or nullptr
+    float        *rows_out;    // rows x row_stride
     int64_t       first_row;
     int64_t       rows;
     int64_t       row_stride;
     int           hop;
-    int           tile_first;
-    int           tile_cols;
     float         gain;
+    unsigned long long *stamps; // diagnostic builds only (RO_STAMPS), else nullptr
+    int           stagger;     // start delay per workgroup slot, shader cycles (0 = none)
+};
+
+struct TileArgs {
+    const float *rows_in;
+    float       *tile_out;     // rows x cols
+    int64_t      rows;
+    int64_t      row_stride;
+    int          first, cols;
 };
 
 struct ScanArgs {
@@ -43,5 +50,6 @@ int        stft_twiddle_count(int bins);          // float2 entries, <0 if unsup
 bool       stft_radices(int bins, int radices[4]);
 hipError_t launch_stft(int bins, int fmt, const StftArgs &a, hipStream_t s);
 hipError_t launch_scan(const ScanArgs &a, hipStream_t s);
+hipError_t launch_tile(const TileArgs &a, hipStream_t s);
 
 }  // namespace ro

@@ -15,6 +15,42 @@
 #include "ro_kernels.h"
 #include "ro_fft_device.h"
 
+#include <cstdlib>
+#include <type_traits>
+
+// Diagnostic builds only (tools/ablate.sh): -DRO_ABLATE=<bits> removes one phase of the
+// STFT kernel to price it.  1: no twiddle loads, 2: no window loads, 4: no LDS exchange,
+// 8: no butterflies, 16: no row stores, 32: no sample loads.  Results are wrong by design.
+#ifndef RO_ABLATE
+#define RO_ABLATE 0
+#endif
+// cache policy of the row stores (gfx950 aux bits: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef RO_STORE_AUX
+#define RO_STORE_AUX 0
+#endif
+// Diagnostic only: -DRO_STAMPS=1 accumulates s_memtime deltas per phase of the row loop and
+// lets lane 0 of wave 0 of every workgroup write them to StftArgs::stamps (9 x u64 per
+// workgroup + row count).  Never timed, never shipped: the fences change the overlaps.
+#ifndef RO_STAMPS
+#define RO_STAMPS 0
+#endif
+// 1: the row stores are issued at the top of the next iteration, after the window loads
+#ifndef RO_DEFER_STORES
+#define RO_DEFER_STORES 0
+#endif
+// 16-byte sample loads shared by lane pairs (see load_row); 0 = one 8-byte load per sample
+#ifndef RO_PAIRED_LOADS
+#define RO_PAIRED_LOADS 1
+#endif
+// share (percent) of the next row's window coefficients that is prefetched across the transform
+#ifndef RO_WIN_EARLY_PCT
+#define RO_WIN_EARLY_PCT 25
+#endif
+// window coefficients in flight per chunk (two chunks are outstanding)
+#ifndef RO_WIN_CHUNK
+#define RO_WIN_CHUNK 2
+#endif
+
 namespace ro {
 
 // ---------------------------------------------------------------------------
@@ -39,8 +75,9 @@ struct Plan {
 // ---------------------------------------------------------------------------
 // stage helpers (all indices compile-time after unrolling -> v[] stays in VGPRs)
 // ---------------------------------------------------------------------------
-template <int P, int R> __device__ __forceinline__ void butterflies(float2 (&v)[P])
+template <int P, int R> __device__ __forceinline__ void butterflies(v2f (&v)[P])
 {
+    if constexpr (RO_ABLATE & 8) return;
 #pragma unroll
     for (int b = 0; b < P / R; ++b) dif<R>(&v[b * R]);
 }
@@ -50,15 +87,16 @@ template <int P, int R> __device__ __forceinline__ void butterflies(float2 (&v)[
 // per-register part of the address in an SGPR (soffset), and free hardware
 // bounds checking (out-of-range loads give 0, stores are dropped).
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
 }
-__device__ __forceinline__ float2 buf_load_f2(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+__device__ __forceinline__ v2f buf_load_f2(__amdgpu_buffer_rsrc_t r, int voff, int soff)
 {
     u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    return make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
+    return (v2f){__uint_as_float(t.x), __uint_as_float(t.y)};
 }
 __device__ __forceinline__ float buf_load_f(__amdgpu_buffer_rsrc_t r, int voff, int soff)
 {
@@ -68,12 +106,33 @@ __device__ __forceinline__ void buf_store_f(float x, __amdgpu_buffer_rsrc_t r, i
 {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, voff, soff, 0);
 }
+__device__ __forceinline__ void buf_store_f4(float x0, float x1, float x2, float x3,
+                                             __amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    u32x4 t = {__float_as_uint(x0), __float_as_uint(x1), __float_as_uint(x2), __float_as_uint(x3)};
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, RO_STORE_AUX);
+}
 
-// multiply by the inter-stage twiddles of a stage (R, NS); table entry OFF + (r-1)*NS + k.
-// Loaded TW_CHUNK at a time behind scheduling fences: left alone, the scheduler
-// hoists all R-1 loads above the LDS exchange and the row no longer fits the
-// 128-VGPR budget of a 1024-thread workgroup.
-constexpr int TW_CHUNK = 8;
+// 4x4 transpose across the four lanes of a quad (DPP quad_perm, no LDS): afterwards
+// register k of lane a holds what register a of lane k held.
+template <int CTRL> __device__ __forceinline__ float dpp_quad(float x)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ void quad_transpose(float &x0, float &x1, float &x2, float &x3, int lane)
+{
+    const bool hi2 = lane & 2, hi1 = lane & 1;
+    {   // swap the off-diagonal 2x2 blocks with lane ^ 2   (quad_perm [2,3,0,1])
+        const float r0 = dpp_quad<0x4E>(hi2 ? x0 : x2);
+        const float r1 = dpp_quad<0x4E>(hi2 ? x1 : x3);
+        if (hi2) { x0 = r0; x1 = r1; } else { x2 = r0; x3 = r1; }
+    }
+    {   // transpose inside each 2x2 block with lane ^ 1     (quad_perm [1,0,3,2])
+        const float r0 = dpp_quad<0xB1>(hi1 ? x0 : x1);
+        const float r1 = dpp_quad<0xB1>(hi1 ? x2 : x3);
+        if (hi1) { x0 = r0; x2 = r1; } else { x1 = r0; x3 = r1; }
+    }
+}
 
 // Ordering by fake data dependence: returns `off` unchanged, but the compiler must
 // assume it was recomputed from `x`, so loads addressed with the result cannot be
@@ -85,34 +144,65 @@ __device__ __forceinline__ int after(int off, float x)
     return off;
 }
 
-template <int P, int T, int R, int NS, int OFF>
-__device__ __forceinline__ void apply_twiddles(float2 (&v)[P], __amdgpu_buffer_rsrc_t tw, int tid)
+__device__ __forceinline__ v2f tw_load(__amdgpu_buffer_rsrc_t tw, int koff, int entry)
 {
-    constexpr int NCH = (R - 1 + TW_CHUNK - 1) / TW_CHUNK;      // chunks per butterfly
+    if constexpr (RO_ABLATE & 1) return (v2f){0.7f, 0.7f};
+    return buf_load_f2(tw, koff, entry * 8);
+}
+
+// Composed form.  The kernel is bound by its memory pipes, not by the VALU (ablation:
+// removing every butterfly changes nothing, removing the 62 twiddle loads saved 14 %),
+// so for radix 32 only w^1..w^3, w^4, w^8, w^12 and w^16 are loaded (7 instead of 31)
+// and w^(16a+4b+c) = w^(16a) * (w^(4b) * w^c) is built with packed multiplies: at most
+// two extra roundings (~1e-7) on top of the table's correctly rounded entries.
+// The loads are split from their use so that they can be issued BEFORE the LDS exchange
+// of the stage and land while the workgroup sits in its barriers.
+constexpr int TW_SET = 7;     // twiddles held per butterfly: R=32: 7, R=16: 6, R<=8: R-1
+
+template <int P, int T, int R, int NS, int OFF>
+__device__ __forceinline__ void tw_prefetch(v2f (&t)[P / R][TW_SET], __amdgpu_buffer_rsrc_t tw, int tid)
+{
+    static_assert(R == 32 || R == 16 || R <= 8, "unsupported radix");
 #pragma unroll
     for (int b = 0; b < P / R; ++b) {
-        // not before the gather that filled v[] has finished
-        int koff = after(((tid + T * b) & (NS - 1)) * 8, v[b * R + R - 1].y);
-        float2 t[2][TW_CHUNK];
-        // two chunks in flight: chunk c+1 is issued before chunk c is consumed
+        const int koff = ((tid + T * b) & (NS - 1)) * 8;
+        if constexpr (R >= 16) {
 #pragma unroll
-        for (int c = 0; c <= NCH; ++c) {
-            if (c < NCH) {
-                // ... and not before chunk c-2 has been consumed (its registers are reused)
-                if (c >= 2) koff = after(koff, v[b * R + (c - 2) * TW_CHUNK + 1].x);
+            for (int c = 1; c < 4; ++c) t[b][c - 1] = tw_load(tw, koff, OFF + (c - 1) * NS);
 #pragma unroll
-                for (int i = 0; i < TW_CHUNK; ++i) {
-                    const int r = 1 + c * TW_CHUNK + i;
-                    if (r < R) t[c & 1][i] = buf_load_f2(tw, koff, (OFF + (r - 1) * NS) * 8);
+            for (int m = 1; m < 4; ++m) t[b][2 + m] = tw_load(tw, koff, OFF + (4 * m - 1) * NS);
+            if constexpr (R == 32) t[b][6] = tw_load(tw, koff, OFF + (16 - 1) * NS);
+        } else {
+#pragma unroll
+            for (int r = 1; r < R; ++r) t[b][r - 1] = tw_load(tw, koff, OFF + (r - 1) * NS);
+        }
+    }
+}
+
+template <int P, int R>
+__device__ __forceinline__ void tw_apply(v2f (&v)[P], const v2f (&t)[P / R][TW_SET])
+{
+#pragma unroll
+    for (int b = 0; b < P / R; ++b) {
+        v2f *x = &v[b * R];
+        if constexpr (R >= 16) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int r = 4 * m + c;
+                    if (r == 0) {
+                        if constexpr (R == 32) x[16] = cmul(x[16], t[b][6]);
+                        continue;
+                    }
+                    const v2f w = (m == 0) ? t[b][c - 1] : (c == 0) ? t[b][2 + m] : cmul(t[b][2 + m], t[b][c - 1]);
+                    x[r] = cmul(x[r], w);
+                    if constexpr (R == 32) x[16 + r] = cmul(x[16 + r], cmul(w, t[b][6]));
                 }
             }
-            if (c > 0) {
+        } else {
 #pragma unroll
-                for (int i = 0; i < TW_CHUNK; ++i) {
-                    const int r = 1 + (c - 1) * TW_CHUNK + i;
-                    if (r < R) v[b * R + r] = cmul(v[b * R + r], t[(c - 1) & 1][i]);
-                }
-            }
+            for (int r = 1; r < R; ++r) x[r] = cmul(x[r], t[b][r - 1]);
         }
     }
 }
@@ -123,7 +213,7 @@ __device__ __forceinline__ void apply_twiddles(float2 (&v)[P], __amdgpu_buffer_r
 // then one base VGPR + immediate offsets address the whole scatter.  Otherwise each
 // element computes its own address.
 template <int P, int T, int R, int NS, typename E, typename F>
-__device__ __forceinline__ void lds_scatter(E *lds, const float2 (&v)[P], int tid, F pick)
+__device__ __forceinline__ void lds_scatter(E *lds, const v2f (&v)[P], int tid, F pick)
 {
 #pragma unroll
     for (int b = 0; b < P / R; ++b) {
@@ -147,7 +237,7 @@ __device__ __forceinline__ void lds_scatter(E *lds, const float2 (&v)[P], int ti
 // gather for the next stage of radix R:  v[b*R + r] = lds[j + r*(N/R)]; N/R is a
 // multiple of 32 for every plan, so the padded address is base + r*(N/R)*33/32.
 template <int N, int P, int T, int R, typename E, typename F>
-__device__ __forceinline__ void lds_gather(const E *lds, float2 (&v)[P], int tid, F put)
+__device__ __forceinline__ void lds_gather(const E *lds, v2f (&v)[P], int tid, F put)
 {
     static_assert((N / R) % 32 == 0, "gather stride must be a multiple of 32");
 #pragma unroll
@@ -162,24 +252,25 @@ __device__ __forceinline__ void lds_gather(const E *lds, float2 (&v)[P], int tid
 // SPLIT (row too large for LDS as float2): the real plane goes first; gathering it
 // into v[].x leaves v[].y in the old register order for the second scatter.
 template <class PL, int RA, int NS, int RB>
-__device__ __forceinline__ void exchange(void *smem, float2 (&v)[PL::P], int tid)
+__device__ __forceinline__ void exchange(void *smem, v2f (&v)[PL::P], int tid)
 {
     constexpr int N = PL::N, P = PL::P, T = PL::T;
+    if constexpr (RO_ABLATE & 4) return;
     if constexpr (PL::SPLIT) {
         float *lds = reinterpret_cast<float *>(smem);
-        lds_scatter<P, T, RA, NS>(lds, v, tid, [](float2 e) { return e.x; });
+        lds_scatter<P, T, RA, NS>(lds, v, tid, [](v2f e) { return e.x; });
         __syncthreads();
-        lds_gather<N, P, T, RB>(lds, v, tid, [](float2 &d, float s) { d.x = s; });
+        lds_gather<N, P, T, RB>(lds, v, tid, [](v2f &d, float s) { d.x = s; });
         __syncthreads();
-        lds_scatter<P, T, RA, NS>(lds, v, tid, [](float2 e) { return e.y; });
+        lds_scatter<P, T, RA, NS>(lds, v, tid, [](v2f e) { return e.y; });
         __syncthreads();
-        lds_gather<N, P, T, RB>(lds, v, tid, [](float2 &d, float s) { d.y = s; });
+        lds_gather<N, P, T, RB>(lds, v, tid, [](v2f &d, float s) { d.y = s; });
         __syncthreads();
     } else {
-        float2 *lds = reinterpret_cast<float2 *>(smem);
-        lds_scatter<P, T, RA, NS>(lds, v, tid, [](float2 e) { return e; });
+        v2f *lds = reinterpret_cast<v2f *>(smem);
+        lds_scatter<P, T, RA, NS>(lds, v, tid, [](v2f e) { return e; });
         __syncthreads();
-        lds_gather<N, P, T, RB>(lds, v, tid, [](float2 &d, float2 s) { d = s; });
+        lds_gather<N, P, T, RB>(lds, v, tid, [](v2f &d, v2f s) { d = s; });
         __syncthreads();
     }
 }
@@ -190,127 +281,280 @@ __device__ __forceinline__ void exchange(void *smem, float2 (&v)[PL::P], int tid
 template <int FMT> struct Sample;
 template <> struct Sample<RO_FMT_F32> {
     static constexpr int BYTES = 8;
-    static __device__ __forceinline__ float2 load(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+    static __device__ __forceinline__ v2f load(__amdgpu_buffer_rsrc_t r, int voff, int soff)
     {
         return buf_load_f2(r, voff, soff);
+    }
+    // two adjacent samples with one 16-byte load
+    static __device__ __forceinline__ void load_pair(__amdgpu_buffer_rsrc_t r, int voff, int soff, v2f &s0, v2f &s1)
+    {
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+        s0 = (v2f){__uint_as_float(t.x), __uint_as_float(t.y)};
+        s1 = (v2f){__uint_as_float(t.z), __uint_as_float(t.w)};
     }
 };
 template <> struct Sample<RO_FMT_I16> {
     static constexpr int BYTES = 4;
-    static __device__ __forceinline__ float2 load(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+    static __device__ __forceinline__ v2f load(__amdgpu_buffer_rsrc_t r, int voff, int soff)
     {
         const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
-        return make_float2((float)(short)(u & 0xffffu), (float)(short)(u >> 16));
+        return (v2f){(float)(short)(u & 0xffffu), (float)(short)(u >> 16)};
+    }
+    static __device__ __forceinline__ void load_pair(__amdgpu_buffer_rsrc_t r, int voff, int soff, v2f &s0, v2f &s1)
+    {
+        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        s0 = (v2f){(float)(short)(t.x & 0xffffu), (float)(short)(t.x >> 16)};
+        s1 = (v2f){(float)(short)(t.y & 0xffffu), (float)(short)(t.y >> 16)};
     }
 };
 
 // ---------------------------------------------------------------------------
 // the STFT kernel
 // ---------------------------------------------------------------------------
+// One workgroup per CU walks over its rows (persistent): no workgroup relaunch between
+// rows, the row stores drain while the next row is being loaded, and the next row's
+// samples are requested from inside the epilogue, each into the register whose
+// magnitude has just been stored.
 template <class PL, int FMT>
 __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
 {
     constexpr int N = PL::N, T = PL::T, P = PL::P;
+    constexpr int R0 = PL::R0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    // XCD-aware placement: workgroups b and b+8 share an XCD (round-robin
-    // dispatch), so give each XCD one contiguous run of rows -- consecutive
-    // rows share (N-hop)/N of their input through that XCD's L2.
-    const int64_t per_xcd = (a.rows + 7) / 8;
-    const int64_t row = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (row >= a.rows) return;
-
-    const int tid = threadIdx.x;
-    const int64_t s0 = (a.first_row + row) * (int64_t)a.hop;
     using S = Sample<FMT>;
 
-    const __amdgpu_buffer_rsrc_t rs_iq =
-        make_rsrc(reinterpret_cast<const char *>(a.iq) + s0 * S::BYTES, N * S::BYTES);
-    const __amdgpu_buffer_rsrc_t rs_win = make_rsrc(a.window, N * 4);
+    // XCD-aware placement: workgroups b and b+8 share an XCD (round-robin dispatch), so
+    // each XCD gets one contiguous run of rows and its workgroups take consecutive rows
+    // of it at the same time -- consecutive rows share (N-hop)/N of their input through
+    // that XCD's L2.  Placement affects speed only.
+    const int64_t per_xcd = (a.rows + 7) / 8;
+    const int64_t xcd_first = (int64_t)(blockIdx.x & 7) * per_xcd;
+    const int64_t xcd_end = xcd_first + per_xcd < a.rows ? xcd_first + per_xcd : a.rows;
+    const int64_t stride = gridDim.x >> 3;
+    int64_t row = xcd_first + (blockIdx.x >> 3);
+    if (row >= xcd_end) return;
+
+    // De-phase the workgroups.  They all start together and take the same time per row, so
+    // left alone every CU bursts its loads, then its LDS phase, then its stores at the same
+    // moment and the memory system alternates between idle and a 256-CU queue.  Slot s of an
+    // XCD starts s * stagger cycles late (at most about one row time in total).
+    if (a.stagger > 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long wait = (unsigned long long)(blockIdx.x >> 3) * (unsigned)a.stagger;
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
+
+    const int tid = threadIdx.x;
     const __amdgpu_buffer_rsrc_t rs_tw = make_rsrc(a.twiddles, PL::TW_TOTAL * 8);
+    const char *iq = reinterpret_cast<const char *>(a.iq);
 
-    float2 v[P];
+    v2f v[P];
 
-    // ---- stage 0: samples * window straight from global memory.  All sample loads go
-    // out first (they land in the data registers); the window coefficients follow in
-    // chunks of WIN_CHUNK, two chunks in flight, so the prologue peaks at P*2 + 2*WIN_CHUNK VGPRs.
-    {
-        constexpr int R = PL::R0;
-        constexpr int WIN_CHUNK = P < 8 ? P : 8;
-        constexpr int NCH = P / WIN_CHUNK;
+    // Sample loads of one row into v[].  PAIRED (one butterfly per thread): the two lanes
+    // of a pair (tid even / odd) share their 2*R0 samples -- the even lane fetches both
+    // columns for legs 0..R0/2-1, the odd lane for legs R0/2..R0-1, each with 16-byte loads
+    // (the L1 path moves a 16-byte-per-lane instruction as fast as an 8-byte one, so this
+    // halves the load time).  v[k] / v[R0/2+k] then hold the even / odd column of leg k
+    // (resp. R0/2+k); the window stage multiplies them in place and a DPP swap between the
+    // two lanes puts every sample into its natural slot.
+    constexpr bool PAIRED = (P == R0) && (R0 % 2 == 0) && RO_PAIRED_LOADS;
+    constexpr int H = R0 / 2;
+    const int pair_off = (tid & ~1) + (tid & 1) * H * (N / R0);      // first sample this lane fetches
+    auto load_row = [&](const __amdgpu_buffer_rsrc_t &rs) {
+        if constexpr (PAIRED) {
 #pragma unroll
-        for (int i = 0; i < P; ++i) {
-            const int b = i / R, r = i % R;
-            v[i] = S::load(rs_iq, (tid + T * b) * S::BYTES, r * (N / R) * S::BYTES);
-        }
-        float w[2][WIN_CHUNK];
-        int woff = tid * 4;
-#pragma unroll
-        for (int c = 0; c <= NCH; ++c) {
-            if (c < NCH) {
-                if (c >= 2) woff = after(woff, v[(c - 2) * WIN_CHUNK].x);
-#pragma unroll
-                for (int q = 0; q < WIN_CHUNK; ++q) {
-                    const int i = c * WIN_CHUNK + q, b = i / R, r = i % R;
-                    w[c & 1][q] = buf_load_f(rs_win, woff, (T * b + r * (N / R)) * 4);
-                }
+            for (int k = 0; k < H; ++k) {
+                if constexpr (RO_ABLATE & 32) { v[k] = (v2f){(float)(tid + k), 1.0f}; v[H + k] = v[k]; }
+                else S::load_pair(rs, pair_off * S::BYTES, k * (N / R0) * S::BYTES, v[k], v[H + k]);
             }
-            if (c > 0) {
+        } else {
 #pragma unroll
-                for (int q = 0; q < WIN_CHUNK; ++q) {
-                    const int i = (c - 1) * WIN_CHUNK + q;
-                    const float ww = w[(c - 1) & 1][q];
-                    v[i] = make_float2(v[i].x * ww, (v[i].y + a.gain) * ww);
-                }
+            for (int i = 0; i < P; ++i) {
+                // slot i: butterfly i / R0, leg i % R0 of stage 0
+                if constexpr (RO_ABLATE & 32) v[i] = (v2f){(float)(tid + i), 1.0f};
+                else v[i] = S::load(rs, (tid + T * (i / R0)) * S::BYTES, (i % R0) * (N / R0) * S::BYTES);
             }
         }
-        butterflies<P, R>(v);
-    }
+    };
 
-    // ---- stage 1
-    if constexpr (PL::R1 > 1) {
-        exchange<PL, PL::R0, 1, PL::R1>(smem, v, tid);
-        apply_twiddles<P, T, PL::R1, PL::NS1, PL::TW1>(v, rs_tw, tid);
-        butterflies<P, PL::R1>(v);
-    }
-    // ---- stage 2
-    if constexpr (PL::R2 > 1) {
-        exchange<PL, PL::R1, PL::NS1, PL::R2>(smem, v, tid);
-        apply_twiddles<P, T, PL::R2, PL::NS2, PL::TW2>(v, rs_tw, tid);
-        butterflies<P, PL::R2>(v);
-    }
-    // ---- stage 3
-    if constexpr (PL::R3 > 1) {
-        exchange<PL, PL::R2, PL::NS2, PL::R3>(smem, v, tid);
-        apply_twiddles<P, T, PL::R3, PL::NS3, PL::TW3>(v, rs_tw, tid);
-        butterflies<P, PL::R3>(v);
-    }
+    // ---- prologue: samples of the first row
+    load_row(make_rsrc(iq + (a.first_row + row) * (int64_t)a.hop * S::BYTES, N * S::BYTES));
 
-    // ---- epilogue: |X[k]| to column (k + N/2) mod N   (src/WaterfallBackend.cpp:492-505)
-    // k = j + r*(N/RL) with j < N/RL, so the shifted column is j + a per-register constant.
     constexpr int RL = PL::R3 > 1 ? PL::R3 : (PL::R2 > 1 ? PL::R2 : (PL::R1 > 1 ? PL::R1 : PL::R0));
-    const bool want_rows = a.rows_out != nullptr;
-    const bool want_tile = a.tile_out != nullptr;
-    const __amdgpu_buffer_rsrc_t rs_out =
-        make_rsrc(want_rows ? a.rows_out + row * a.row_stride : nullptr, want_rows ? N * 4 : 0);
-    const __amdgpu_buffer_rsrc_t rs_tile =
-        make_rsrc(want_tile ? a.tile_out + row * (int64_t)a.tile_cols : nullptr,
-                  want_tile ? a.tile_cols * 4 : 0);
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
+    auto stamp = [&](int k) {
+        if constexpr (RO_STAMPS) {
+            unsigned long long t;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (k >= 0) st_acc[k] += t - st_prev;
+            st_prev = t;
+        }
+    };
+    stamp(-1);
+    // window coefficients of the row about to be transformed (fetched in the previous
+    // epilogue / the prologue, all at once: P floats)
+    constexpr int NW = PAIRED ? H : P;
+    using wtype = std::conditional_t<PAIRED, v2f, float>;
+    wtype w[NW];
+    // first..last-1 of the NW coefficient registers
+    auto load_window = [&](const __amdgpu_buffer_rsrc_t &rs_win, auto first_c, auto last_c) {
+        constexpr int first = decltype(first_c)::value, last = decltype(last_c)::value;
+        if constexpr (PAIRED) {
 #pragma unroll
-    for (int b = 0; b < P / RL; ++b) {
-        const int j = tid + T * b;
+            for (int k = first; k < last; ++k) {
+                if constexpr (RO_ABLATE & 2) w[k] = (v2f){0.5f, 0.5f};
+                else w[k] = buf_load_f2(rs_win, pair_off * 4, k * (N / R0) * 4);
+            }
+        } else {
 #pragma unroll
-        for (int r = 0; r < RL; ++r) {
-            const float2 x = v[b * RL + bitrev<RL>(r)];
-            const float m = __builtin_amdgcn_sqrtf(x.x * x.x + x.y * x.y);   // v_sqrt_f32, 1 ulp
-            const int cbase = (r * (N / RL) + N / 2) & (N - 1);
-            buf_store_f(m, rs_out, j * 4, cbase * 4);
-            if (want_tile) {
-                const int tc = j + cbase - a.tile_first;
-                // out-of-tile lanes get an offset the descriptor's range check drops
-                buf_store_f(m, rs_tile, (tc >= 0 && tc < a.tile_cols) ? tc * 4 : 0x40000000, 0);
+            for (int i = first; i < last; ++i) {
+                if constexpr (RO_ABLATE & 2) w[i] = 0.5f;
+                else w[i] = buf_load_f(rs_win, tid * 4, (T * (i / R0) + (i % R0) * (N / R0)) * 4);
             }
         }
+    };
+    // Coefficients [0, NW_EARLY) of the next row are requested right after the window stage
+    // (their registers are free for the whole transform, so these loads cost nothing); the
+    // rest would not fit the 128-VGPR budget next to the butterflies and follows in the epilogue.
+    constexpr int NW_EARLY = (NW * RO_WIN_EARLY_PCT) / 100;
+    using c0 = std::integral_constant<int, 0>;
+    using cE = std::integral_constant<int, NW_EARLY>;
+    using cN = std::integral_constant<int, NW>;
+    load_window(make_rsrc(a.window, N * 4), c0{}, cN{});
+
+    for (;;) {
+        // ---- stage 0: window.  Coefficients arrive in chunks of WIN_CHUNK, two chunks in
+        // flight, so the stage peaks at 2P + 2*WIN_CHUNK VGPRs (+P while a row waits to be stored).
+        // ---- stage 0: window (coefficients and samples were requested a whole epilogue ago)
+        {
+            const v2f gain2 = (v2f){0.0f, a.gain};          // src/FFTBackend.cpp:78-79: Q += gain
+            if constexpr (PAIRED) {
+                const bool odd = tid & 1;
+#pragma unroll
+                for (int k = 0; k < H; ++k) {
+                    const v2f e = (v[k] + gain2) * w[k].xx;        // even column, leg k (H+k on odd lanes)
+                    const v2f o = (v[H + k] + gain2) * w[k].yy;    // odd column
+                    // even lane keeps e in slot k and takes the partner's e (leg H+k) into slot H+k;
+                    // odd lane keeps o in slot H+k and takes the partner's o (leg k) into slot k.
+                    const v2f pe = (v2f){dpp_quad<0xB1>(e.x), dpp_quad<0xB1>(e.y)};
+                    const v2f po = (v2f){dpp_quad<0xB1>(o.x), dpp_quad<0xB1>(o.y)};
+                    v[k] = odd ? po : e;
+                    v[H + k] = odd ? o : pe;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < P; ++i) v[i] = (v[i] + gain2) * (v2f){w[i], w[i]};
+            }
+        }
+        // The coefficients for the NEXT row are requested right away: their registers are free
+        // from here on and the loads overlap the whole transform instead of the epilogue's
+        // memory burst.  (Unconditional: the same table every row.)
+        load_window(make_rsrc(a.window, N * 4), c0{}, cE{});
+        stamp(0);                                   // window multiply (+ wait for samples)
+        stamp(1);
+
+        v2f tw1[PL::R1 > 1 ? P / PL::R1 : 1][TW_SET];
+        butterflies<P, R0>(v);
+        if constexpr (PL::R1 > 1) tw_prefetch<P, T, PL::R1, PL::NS1, PL::TW1>(tw1, rs_tw, tid);
+        stamp(2);                                   // butterflies 0
+
+        // ---- stage 1
+        if constexpr (PL::R1 > 1) {
+            exchange<PL, PL::R0, 1, PL::R1>(smem, v, tid);
+            stamp(3);                               // exchange 1
+            tw_apply<P, PL::R1>(v, tw1);
+            butterflies<P, PL::R1>(v);
+            stamp(4);                               // twiddles + butterflies 1
+        }
+        // ---- stage 2
+        if constexpr (PL::R2 > 1) {
+            v2f tw2[P / PL::R2][TW_SET];
+            tw_prefetch<P, T, PL::R2, PL::NS2, PL::TW2>(tw2, rs_tw, tid);
+            exchange<PL, PL::R1, PL::NS1, PL::R2>(smem, v, tid);
+            stamp(5);                               // exchange 2
+            tw_apply<P, PL::R2>(v, tw2);
+            butterflies<P, PL::R2>(v);
+            stamp(6);                               // twiddles + butterflies 2
+        }
+        // ---- stage 3
+        if constexpr (PL::R3 > 1) {
+            v2f tw3[P / PL::R3][TW_SET];
+            tw_prefetch<P, T, PL::R3, PL::NS3, PL::TW3>(tw3, rs_tw, tid);
+            exchange<PL, PL::R2, PL::NS2, PL::R3>(smem, v, tid);
+            tw_apply<P, PL::R3>(v, tw3);
+            butterflies<P, PL::R3>(v);
+        }
+
+        // ---- epilogue: |X[k]| -> column (k + N/2) mod N  (src/WaterfallBackend.cpp:492-505).
+        // vmcnt retires in issue order and counts stores, so whatever is loaded after a store
+        // cannot be used before that store has been acknowledged (~5k cycles here).  The row
+        // therefore leaves the registers through LDS (free at this point): magnitudes are
+        // written there in row order, the next row's samples and window coefficients are
+        // requested into the freed registers, and only then the row is read back 16 bytes per
+        // lane and stored -- 1 KiB per wave-instruction, the stores being the LAST thing in the
+        // VMEM queue.
+        const int64_t next = row + stride;
+        const bool has_next = next < xcd_end;
+        {
+            float *lds_m = reinterpret_cast<float *>(smem);
+#pragma unroll
+            for (int b = 0; b < P / RL; ++b) {
+#pragma unroll
+                for (int r = 0; r < RL; ++r) {
+                    const v2f x = v[b * RL + bitrev<RL>(r)];
+                    const v2f sq = x * x;
+                    const float mag = __builtin_amdgcn_sqrtf(sq.x + sq.y);   // v_sqrt_f32, 1 ulp
+                    const int cbase = (r * (N / RL) + N / 2) & (N - 1);
+                    lds_m[tid + T * b + cbase] = mag;            // j < N/RL, cbase a multiple of it: no wrap
+                }
+            }
+        }
+        // a zero-sized descriptor turns the loads into no-ops after the last row
+        load_row(make_rsrc(iq + (a.first_row + (has_next ? next : row)) * (int64_t)a.hop * S::BYTES,
+                           has_next ? N * S::BYTES : 0));
+        // unconditional (zero-sized descriptor after the last row): a branch here would keep the
+        // old coefficients alive next to the new ones
+        load_window(make_rsrc(a.window, has_next ? N * 4 : 0), cE{}, cN{});
+        stamp(7);                                   // magnitudes to LDS + next-row loads issued
+        __syncthreads();
+        {
+            const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(a.rows_out + row * a.row_stride, N * 4);
+            const float4 *lds_m4 = reinterpret_cast<const float4 *>(smem);
+#pragma unroll
+            for (int q = 0; q < P / 4; ++q) {
+                const float4 x = lds_m4[tid + T * q];
+                if constexpr (RO_ABLATE & 16) asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
+                else buf_store_f4(x.x, x.y, x.z, x.w, rs_out, tid * 16, q * T * 16);
+                // two reads in flight at most: hoisting all P/4 of them would need P more VGPRs
+                // while the next row's samples and window are already landing in theirs
+                if (q & 1) asm volatile("" ::: "memory");
+            }
+        }
+        __syncthreads();                            // LDS is reused by the next row's exchange
+        stamp(8);                                   // row stores issued
+        st_acc[9] += 1;
+        if (!has_next) break;
+        row = next;
+    }
+    if constexpr (RO_STAMPS) {
+        if (a.stamps && tid == 0)
+            for (int k = 0; k < 10; ++k) a.stamps[blockIdx.x * 10 + k] = st_acc[k];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// band tile: compact copy of columns [first, first+cols) of every row (what the FITS
+// writer keeps, src/WaterfallBackend.cpp:176,204) -- the unit the multi-GPU gather moves.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tile_kernel(TileArgs a)
+{
+    const int64_t total = a.rows * (int64_t)a.cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / a.cols;
+        const int c = (int)(i - r * a.cols);
+        a.tile_out[i] = a.rows_in[r * a.row_stride + a.first + c];
     }
 }
 
@@ -413,18 +657,38 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void scan_kernel(ScanArgs a)
 // ---------------------------------------------------------------------------
 // launch table
 // ---------------------------------------------------------------------------
+// Persistent launch: as many workgroups as the device can hold at once (rounded down to a
+// multiple of 8 so every XCD gets the same share), never more than there are rows.
 template <class PL, int FMT> static hipError_t launch_plan(const StftArgs &a, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&stft_kernel<PL, FMT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, PL::LDS_BYTES);
+    static int resident = 0;            // workgroups resident on the device (all CUs)
+    if (resident == 0) {
+        const void *fn = reinterpret_cast<const void *>(&stft_kernel<PL, FMT>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PL::LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        int dev = 0, cus = 0, per_cu = 0;
+        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, PL::T, PL::LDS_BYTES)) != hipSuccess)
+            return e;
+        if (per_cu < 1) per_cu = 1;
+        resident = cus * per_cu;
     }
     const int64_t per_xcd = (a.rows + 7) / 8;
-    const unsigned grid = (unsigned)(per_xcd * 8);
-    hipLaunchKernelGGL((stft_kernel<PL, FMT>), dim3(grid), dim3(PL::T), PL::LDS_BYTES, s, a);
+    int64_t slots = resident / 8;                       // workgroups per XCD
+    if (slots < 1) slots = 1;
+    if (slots > per_xcd) slots = per_xcd;
+    const unsigned grid = (unsigned)(slots * 8);
+    StftArgs b = a;
+    {
+        static int stagger = -1;                       // experiment knob: RO_STAGGER=<cycles per slot>
+        if (stagger < 0) {
+            const char *e = getenv("RO_STAGGER");
+            stagger = e ? atoi(e) : 0;
+        }
+        b.stagger = stagger;
+    }
+    hipLaunchKernelGGL((stft_kernel<PL, FMT>), dim3(grid), dim3(PL::T), PL::LDS_BYTES, s, b);
     return hipGetLastError();
 }
 
@@ -501,6 +765,16 @@ hipError_t launch_stft(int bins, int fmt, const StftArgs &a, hipStream_t s)
     case 256:   return launch_fmt<Plan256>(a, fmt, s);
     default:    return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_tile(const TileArgs &a, hipStream_t s)
+{
+    if (a.rows <= 0 || a.cols <= 0) return hipSuccess;
+    const int64_t total = a.rows * (int64_t)a.cols;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(tile_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_scan(const ScanArgs &a, hipStream_t s)

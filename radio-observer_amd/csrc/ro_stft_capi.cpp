@@ -117,6 +117,7 @@ struct ro_stft {
     int64_t stat_samples = 0, stat_rows = 0, stat_launches = 0;
     double stat_kernel_ms = 0.0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    unsigned long long *d_stamps = nullptr;    // diagnostic builds (RO_STAMPS) only
 };
 
 namespace {
@@ -144,7 +145,7 @@ int validate_resident(const ro_stft *h, const void *d_iq, int format, int64_t sa
     if (rows < 0 || first_row < 0) return fail(RO_ERR_INVALID, "negative row range");
     if (rows == 0) return RO_OK;
     if (!d_iq) return fail(RO_ERR_INVALID, "null input pointer");
-    if (!d_rows && !d_tile) return fail(RO_ERR_INVALID, "no output requested (rows and tile both null)");
+    if (!d_rows) return fail(RO_ERR_INVALID, "d_rows is required (the band tile is cut from the rows)");
     if (d_rows && row_stride < h->bins)
         return fail(RO_ERR_INVALID, "row_stride %lld < bins %d", (long long)row_stride, h->bins);
     if (d_tile && h->cfg.tile_cols <= 0) return fail(RO_ERR_INVALID, "tile output requested but tile_cols == 0");
@@ -160,22 +161,33 @@ int validate_resident(const ro_stft *h, const void *d_iq, int format, int64_t sa
 }
 
 ro::StftArgs make_stft_args(const ro_stft *h, const void *d_iq, int64_t first_row, int64_t rows,
-                            float *d_rows, int64_t row_stride, float *d_tile)
+                            float *d_rows, int64_t row_stride)
 {
     ro::StftArgs a{};
     a.iq = d_iq;
     a.window = h->d_window;
     a.twiddles = h->d_twiddles;
     a.rows_out = d_rows;
-    a.tile_out = d_tile;
     a.first_row = first_row;
     a.rows = rows;
     a.row_stride = row_stride;
     a.hop = h->hop;
-    a.tile_first = h->cfg.tile_first_col;
-    a.tile_cols = h->cfg.tile_cols;
     a.gain = (float)h->cfg.iq_gain;
+    a.stamps = h->d_stamps;
     return a;
+}
+
+ro::TileArgs make_tile_args(const ro_stft *h, const float *d_rows, int64_t row_stride, int64_t rows,
+                            float *d_tile)
+{
+    ro::TileArgs t{};
+    t.rows_in = d_rows;
+    t.tile_out = d_tile;
+    t.rows = rows;
+    t.row_stride = row_stride;
+    t.first = h->cfg.tile_first_col;
+    t.cols = h->cfg.tile_cols;
+    return t;
 }
 
 ro::ScanArgs make_scan_args(const ro_stft *h, const float *d_rows, int64_t row_stride, int64_t rows,
@@ -203,7 +215,7 @@ int run_stream_batch(ro_stft *h, int64_t rows)
     const int64_t need = (rows - 1) * (int64_t)h->hop + h->bins;       // samples
     HIP_TRY(hipMemcpyAsync(h->d_iq, h->staged.data(), (size_t)need * 2 * sizeof(float),
                            hipMemcpyHostToDevice, h->stream));
-    ro::StftArgs a = make_stft_args(h, h->d_iq, 0, rows, h->d_rows, h->bins, nullptr);
+    ro::StftArgs a = make_stft_args(h, h->d_iq, 0, rows, h->d_rows, h->bins);
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     HIP_TRY(ro::launch_stft(h->bins, RO_IQ_F32, a, h->stream));
     if (h->cfg.enable_scan) {
@@ -418,10 +430,31 @@ extern "C" int ro_stft_destroy(ro_stft_t *h)
     if (h->d_iq) (void)hipFree(h->d_iq);
     if (h->d_rows) (void)hipFree(h->d_rows);
     if (h->d_records) (void)hipFree(h->d_records);
+    if (h->d_stamps) (void)hipFree(h->d_stamps);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
+    return RO_OK;
+}
+
+// Diagnostic hook (not in include/ro_stft.h): allocate / read the per-workgroup phase stamps
+// that a -DRO_STAMPS=1 build of the kernels fills.  A normal build never writes them.
+extern "C" int ro_stft_debug_stamps(ro_stft_t *h, unsigned long long *out, int max_words)
+{
+    if (!h) return fail(RO_ERR_INVALID, "null handle");
+    const int words = 4096 * 10;
+    if (!h->d_stamps) {
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipMalloc(&h->d_stamps, sizeof(unsigned long long) * words));
+        HIP_TRY(hipMemset(h->d_stamps, 0, sizeof(unsigned long long) * words));
+        return RO_OK;
+    }
+    if (out) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out, h->d_stamps, sizeof(unsigned long long) * std::min(words, max_words),
+                          hipMemcpyDeviceToHost));
+    }
     return RO_OK;
 }
 
@@ -464,8 +497,9 @@ extern "C" int ro_stft_run_resident(ro_stft_t *h, const void *d_iq, int format, 
     if (rc != RO_OK || rows == 0) return rc;
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-    ro::StftArgs a = make_stft_args(h, d_iq, first_row, rows, d_rows, row_stride, d_tile);
+    ro::StftArgs a = make_stft_args(h, d_iq, first_row, rows, d_rows, row_stride);
     HIP_TRY(ro::launch_stft(h->bins, format, a, s));
+    if (d_tile) HIP_TRY(ro::launch_tile(make_tile_args(h, d_rows, row_stride, rows, d_tile), s));
     if (d_records) {
         ro::ScanArgs sc = make_scan_args(h, d_rows, row_stride, rows, d_records);
         HIP_TRY(ro::launch_scan(sc, s));
@@ -501,12 +535,13 @@ extern "C" int ro_stft_time_resident(ro_stft_t *h, const void *d_iq, int format,
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     std::vector<hipEvent_t> ev((size_t)iters * 3);
     for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
-    ro::StftArgs a = make_stft_args(h, d_iq, first_row, rows, d_rows, row_stride, d_tile);
+    ro::StftArgs a = make_stft_args(h, d_iq, first_row, rows, d_rows, row_stride);
     ro::ScanArgs sc = make_scan_args(h, d_rows, row_stride, rows, d_records);
     for (int i = 0; i < iters; ++i) {
         HIP_TRY(hipEventRecord(ev[3 * i], s));
         HIP_TRY(ro::launch_stft(h->bins, format, a, s));
         HIP_TRY(hipEventRecord(ev[3 * i + 1], s));
+        if (d_tile) HIP_TRY(ro::launch_tile(make_tile_args(h, d_rows, row_stride, rows, d_tile), s));
         if (d_records) HIP_TRY(ro::launch_scan(sc, s));
         HIP_TRY(hipEventRecord(ev[3 * i + 2], s));
     }

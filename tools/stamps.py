@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""GPU box: run a -DRO_STAMPS=1 build (RO_STFT_LIB) on the C3 shape and print the share of each
+phase of the row loop (s_memtime ticks of wave 0 per workgroup, averaged)."""
+import ctypes as C, importlib, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ro = importlib.import_module("radio-observer_amd")
+lib = ro.library()
+lib.ro_stft_debug_stamps.restype = C.c_int
+lib.ro_stft_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+bins, overlap, R = 32768, 24576, 16384
+hop = bins - overlap
+samples = bins + hop * (R - 1)
+iq = torch.randn((samples, 2), device="cuda", dtype=torch.float32)
+rows = torch.empty((R, bins), device="cuda", dtype=torch.float32)
+st = ro.Stft(bins=bins, overlap=overlap)
+for _ in range(2):
+    st.run_resident(iq, ro.RO_IQ_F32, samples, 0, R, rows, stream=torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+lib.ro_stft_debug_stamps(st._h, None, 0)          # allocate; from now on the kernel records
+st.run_resident(iq, ro.RO_IQ_F32, samples, 0, R, rows, stream=torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+buf = np.zeros(4096 * 10, dtype=np.uint64)
+lib.ro_stft_debug_stamps(st._h, buf.ctypes.data_as(C.c_void_p), buf.size)
+a = buf.reshape(-1, 10)
+a = a[a[:, 9] > 0].astype(np.float64)
+names = ["window(+sample wait)", "deferred stores", "butterflies0+twpf", "exchange1", "tw+bfly1", "exchange2",
+         "tw+bfly2", "mag+next loads", "stores issue"]
+per_row = a[:, :9].sum(0) / a[:, 9].sum()
+tot = per_row.sum()
+print("workgroups %d, rows/wg %.1f, ticks/row %.0f (s_memtime = shader cycles; at 2.1 GHz => %.2f us)" % (len(a), a[:, 9].mean(), tot, tot / 2100.0))
+for n, t in zip(names, per_row):
+    print("  %-22s %8.0f ticks  %5.1f %%" % (n, t, 100 * t / tot))
