@@ -1,0 +1,185 @@
+#include "HipWaterfallBackend.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+namespace ro {
+
+static int wrapIndex(int value, int size)            // src/utils.cpp:12-18
+{
+    while (value < 0) value += size;
+    return value % size;
+}
+
+int Recorder::getSampleRate() const { return backend_->getStreamInfo().sampleRate; }
+int Recorder::getFFTSampleRate() const { return (int)backend_->getFFTSampleRate(); }
+int Recorder::fftMarkToRaw(int mark) const { return (*rawHandles_)[wrapIndex(mark, (int)rawHandles_->size())].mark; }
+WFTime Recorder::fftMarkToTime(int mark) const { return (*rawHandles_)[wrapIndex(mark, (int)rawHandles_->size())].time; }
+
+HipWaterfallBackend::HipWaterfallBackend(const WaterfallConfig &cfg) : cfg_(cfg)
+{
+    bins_ = cfg.bins;
+    overlap_ = ro_clamp_overlap(cfg.bins, cfg.overlap);          // src/FFTBackend.cpp:108-109
+    hop_ = bins_ - overlap_;
+}
+
+HipWaterfallBackend::~HipWaterfallBackend()
+{
+    if (stft_) ro_stft_destroy(stft_);
+}
+
+void HipWaterfallBackend::addRecorder(Recorder *recorder)
+{
+    recorders_.push_back(recorder);
+    recorder->setBuffer(&buffer_, &rawHandles_);
+}
+
+void HipWaterfallBackend::startStream(StreamInfo info)
+{
+    Backend::startStream(info);
+    fftSampleRate_ = ro_fft_sample_rate(info.sampleRate, bins_, overlap_);     // FFTBackend.cpp:150-151
+    samplesIn_ = 0;
+    inMark_ = 0;
+    nextStampRow_ = 0;
+    rowTimes_.clear();
+    rowsDelivered_ = 0;
+    rowLog_.clear();
+
+    // src/WaterfallBackend.cpp:577-588
+    int bufferSize = 1;
+    for (Recorder *r : recorders_) bufferSize = std::max(bufferSize, r->requestBufferSize());
+    buffer_.resize(bins_, cfg_.buffer_chunk_size, bufferSize);
+    rawHandles_.assign(buffer_.getCapacity(), RawDataHandle());
+    {   // resizeRawBuffer(fftSamplesToRaw(bufferSize)): RingBuffer2D<float>(2, 1 MiB, n) (FFTBackend.h:129-132)
+        const int want = fftSamplesToRaw(bufferSize);
+        const int chunkRows = (1024 * 1024) / 8;
+        rawCapacity_ = std::max(1, (want / chunkRows + (want % chunkRows ? 1 : 0)) * chunkRows);
+    }
+    for (Recorder *r : recorders_) r->start();                                   // :591-593
+
+    // the device side: one ro_stft handle per stream; scan bands from whichever recorder wants them
+    if (stft_) { ro_stft_destroy(stft_); stft_ = nullptr; }
+    ro_stft_config_t c;
+    std::memset(&c, 0, sizeof(c));
+    c.struct_size = sizeof(c);
+    c.bins = bins_;
+    c.overlap = overlap_;
+    c.sample_rate = info.sampleRate;
+    c.window_kind = RO_WINDOW_NUTTALL;
+    c.iq_gain = cfg_.iq_gain;
+    c.iq_phase_shift = cfg_.iq_phase_shift;
+    c.device = cfg_.device;
+    c.max_batch_rows = cfg_.max_batch_rows;
+    scanEnabled_ = false;
+    for (Recorder *r : recorders_)
+        if (!scanEnabled_ && r->scanBands(&c.bands)) { c.enable_scan = 1; scanEnabled_ = true; }
+    if (ro_stft_create(&c, &stft_) != RO_OK) {
+        // the reference logs and carries on (LOG_ERROR + return); so does this: no rows will come
+        lastError_ = ro_last_error();
+        std::fprintf(stderr, "HipWaterfallBackend: %s\n", lastError_.c_str());
+        stft_ = nullptr;
+    }
+}
+
+// Times of row starts.  FFTBackend::process stamps every sample with
+// timeOffset.addSamples(i) while it copies a "take" (the samples that complete the next row),
+// then advances timeOffset by the take (src/FFTBackend.cpp:216-223, :255); a row's time is the
+// stamp of its first sample (:225).  Only row starts are needed, so they are computed per take.
+void HipWaterfallBackend::stampRowStarts(int64_t takeBegin, int64_t takeEnd, const WFTime &t)
+{
+    while (nextStampRow_ * (int64_t)hop_ < takeEnd) {
+        const int64_t s = nextStampRow_ * (int64_t)hop_;
+        if (s >= takeBegin) rowTimes_.push_back(t.addSamples((SampleCount)(s - takeBegin), streamInfo_.sampleRate));
+        nextStampRow_++;
+    }
+}
+
+void HipWaterfallBackend::process(const std::vector<Complex> &data, DataInfo info)
+{
+    if (!stft_ || data.empty()) return;
+    // ---- host bookkeeping, same control flow as src/FFTBackend.cpp:209-273 (no per-sample work)
+    {
+        int64_t size = (int64_t)data.size();
+        int64_t pos = samplesIn_;
+        WFTime timeOffset = info.timeOffset;
+        while (size >= bins_ - inMark_) {
+            const int count = bins_ - inMark_;
+            stampRowStarts(pos, pos + count, timeOffset);
+            inMark_ = overlap_;
+            size -= count;
+            pos += count;
+            timeOffset = timeOffset.addSamples((SampleCount)count, streamInfo_.sampleRate);
+        }
+        if (size > 0) {
+            stampRowStarts(pos, pos + size, timeOffset);
+            inMark_ += (int)size;
+        }
+        samplesIn_ += (int64_t)data.size();
+    }
+    // ---- the samples themselves go to the GPU path; struct Complex is two doubles (RO_IQ_F64)
+    int64_t ready = 0;
+    if (ro_stft_push(stft_, data.data(), RO_IQ_F64, (int64_t)data.size(), &ready) != RO_OK) {
+        lastError_ = ro_last_error();
+        std::fprintf(stderr, "HipWaterfallBackend: %s\n", lastError_.c_str());
+        return;
+    }
+    drain(false);
+}
+
+void HipWaterfallBackend::endStream()
+{
+    Backend::endStream();
+    if (stft_) drain(true);
+    for (Recorder *r : recorders_) r->stop();                                    // :604-606
+}
+
+// Hand finished rows to the recorders in stream order.  `flush` runs the kernels on every
+// complete row still staged (end of stream, or a caller that wants minimum latency).
+void HipWaterfallBackend::drain(bool flush)
+{
+    int64_t ready = 0;
+    if (flush && ro_stft_flush(stft_, &ready) != RO_OK) {
+        lastError_ = ro_last_error();
+        return;
+    }
+    const int64_t CH = 64;
+    fetchRows_.resize((size_t)CH * bins_);
+    fetchRecs_.resize((size_t)CH);
+    for (;;) {
+        int64_t first = 0, got = 0;
+        if (ro_stft_fetch(stft_, CH, 0, bins_, fetchRows_.data(), scanEnabled_ ? fetchRecs_.data() : nullptr,
+                          &first, &got) != RO_OK) {
+            lastError_ = ro_last_error();
+            return;
+        }
+        if (got == 0) break;
+        for (int64_t i = 0; i < got; ++i) {
+            const int64_t r = first + i;
+            DataInfo di;
+            di.offset = (SampleCount)r;                                          // info_.offset, :256
+            di.timeOffset = rowTimes_.empty() ? WFTime() : rowTimes_.front();
+            if (!rowTimes_.empty()) rowTimes_.pop_front();
+            // windowRaw_[0].mark after the overlap memmove (src/FFTBackend.cpp:242,251): the mark
+            // (pushes so far, mod capacity) of the next row's first sample, or of this row's when
+            // there is no overlap to move.
+            const int64_t s = (overlap_ > 0 ? (r + 1) : r) * (int64_t)hop_;
+            const int rawMark = (int)((s + 1) % rawCapacity_);
+            processRow(&fetchRows_[(size_t)i * bins_], scanEnabled_ ? &fetchRecs_[(size_t)i] : nullptr, di, rawMark);
+        }
+    }
+}
+
+// WaterfallBackend::processFFT minus the arithmetic (src/WaterfallBackend.cpp:485-541)
+void HipWaterfallBackend::processRow(const float *row, const ro_scan_record_t *scan, DataInfo info, int rawMark)
+{
+    float *dst = buffer_.push();                                                 // :488
+    std::memcpy(dst, row, sizeof(float) * (size_t)bins_);
+    rawHandles_[buffer_.mark()] = RawDataHandle(rawMark, info.timeOffset);       // :507 (one slot ahead)
+    if (scan) currentScan_ = *scan;
+    rowsDelivered_++;
+    if (keepLog_) rowLog_.push_back(RowInfo{info.offset, info.timeOffset, rawMark});
+    for (Recorder *r : recorders_) r->update();                                  // :534-536
+}
+
+}  // namespace ro

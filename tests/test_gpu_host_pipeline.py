@@ -1,0 +1,113 @@
+"""GPU: the host-side mirror of the reference interface (Frontend -> Backend::process ->
+Recorder::update) fed like the reference's frontends feed it, against the oracle's emulation of
+Frontend::process + FFTBackend::process + BolidRecorder::update."""
+import numpy as np
+import pytest
+
+from hostlib import HostPipeline, host_library
+from util import add_chirp, add_tone, noise_iq, rel_to_row_max
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _need_host():
+    assert host_library() is not None, "radio-observer_amd/host/libro_host.so missing: run __graft_entry__.build()"
+
+
+@pytest.mark.parametrize("bins,overlap,chunk,batch", [(1024, 512, 1024, 4), (1024, 512, 4096, 0),
+                                                       (4096, 2048, 1000, 3), (2048, 0, 777, 1),
+                                                       (32768, 24576, 4096, 8)])
+def test_stream_rows_times_and_marks(oracle, bins, overlap, chunk, batch):
+    """WAVStream hands over 1024 samples per call, RawStream up to 4096, JACK arbitrary counts
+    (src/WAVStream.cpp:190, src/RawStream.cpp:32, src/JackFrontend.cpp:35): rows, DataInfo and
+    rawMark must not depend on the chunking except where the reference's timestamps do."""
+    rng = np.random.default_rng(bins + chunk)
+    hop = bins - overlap
+    T = bins + 9 * hop + hop // 3
+    iq = noise_iq(rng, T)
+    z = iq[:, 0].astype(np.float64) + 1j * iq[:, 1].astype(np.float64)
+    start = (1700000000, 250000)
+    p = HostPipeline(bins, overlap, start=start, max_batch_rows=batch, snapshot_length=1)
+    o = oracle.Stream(bins, overlap, start=start, raw_capacity_rows=p.raw_capacity())
+    want_rows, want_info = [], []
+    for i in range(0, T, chunk):
+        p.process(z[i:i + chunk])
+        r, inf = o.process(z[i:i + chunk])
+        want_rows.append(r)
+        want_info += inf
+    p.end()
+    assert p.error == ""
+    want_rows = np.concatenate(want_rows)
+    assert p.rows == want_rows.shape[0] == 10
+    cap = p.ring_capacity()
+    assert p.ring_mark() == 10 % cap
+    got = np.stack([p.ring_row(p.ring_mark() - 10 + i) for i in range(10)])       # at(mark-1) = newest row
+    assert rel_to_row_max(got, want_rows) <= 1e-5
+    for i in range(10):
+        assert p.row_info(i) == want_info[i], (i, p.row_info(i), want_info[i])
+    # rawHandles_ is written one slot AHEAD of its row (src/WaterfallBackend.cpp:507, Appendix B-4)
+    for i in range(10):
+        m, s, u = p.raw_handle((i + 1) % cap)
+        assert (m, s, u) == (want_info[i][3], want_info[i][1], want_info[i][2])
+    p.close()
+
+
+def test_bolid_detection_through_the_pipeline(oracle):
+    """C4: chirps in noise through Frontend -> HipWaterfallBackend -> BolidRecorder; the events
+    must equal the oracle's FSM driven by the oracle's FP64 rows."""
+    bins, overlap, hop = 32768, 24576, 8192
+    rng = np.random.default_rng(0xC4)
+    rows = 120
+    iq = noise_iq(rng, bins + (rows - 1) * hop)
+    add_chirp(iq, 20 * hop, 2.0, 10800.0, -100.0, 3.0)
+    add_chirp(iq, 70 * hop + 1234, 1.0, 10700.0, -100.0, 3.0)
+    z = iq[:, 0].astype(np.float64) + 1j * iq[:, 1].astype(np.float64)
+    p = HostPipeline(bins, overlap, max_batch_rows=16, snapshot_length=60)
+    for i in range(0, len(z), 4096):
+        p.process(z[i:i + 4096])
+    p.end()
+    assert p.error == "" and p.rows == rows
+    ld, dw, ln, nw, adv, jit, avg = p.bands()
+    assert (ld, dw, ln, nw, adv, jit, avg) == (23415, 410, 22528, 409, 11, 29, 27)
+    cap = p.ring_capacity()
+    assert cap == 352 * 8                                     # ceil(60 * 5.859375) * 8, 8 rows per 1 MiB chunk
+    # oracle side
+    want = oracle.stft(iq, bins, overlap)
+    n, pk, a = oracle.scan_rows(want, ln, nw, ld, dw, avg)
+    rate = oracle.lib().ro_oracle_fft_sample_rate(48000, bins, overlap)
+    fsm = oracle.BolidFsm(adv, jit, rate, 48000, 10300.0, 10900.0)
+    expect = []
+    for r in range(rows):
+        ev = fsm.update(n[r], a[r], oracle.lib().ro_oracle_bin_to_frequency(bins, 48000, ld + int(pk[r])),
+                        (r + 1) % cap)
+        if ev.fired:
+            expect.append((r, ev.snap_start, ev.snap_length, ev.raw_length, ev.duration_s, ev.peak_freq,
+                           ev.fmin, ev.fmax))
+    got = [(e.row, e.start, e.length, e.rawLength, e.duration, e.peakFreq, e.fmin, e.fmax) for e in p.events()]
+    assert len(expect) == 2, expect
+    assert got == expect                                      # event rows, lengths, peak bins: bit-exact
+    assert p.state() == fsm.f.state
+    # noise / magnitude of the events agree to fp32-FFT accuracy
+    margin = a.astype(np.float64) / (2 * n.astype(np.float64))
+    assert np.abs(margin - 1).min() > 1e-3                    # no marginal row in this signal
+    p.close()
+
+
+def test_backend_without_scan_recorder_still_delivers_rows(oracle):
+    """averageBinRange_ is 0 at N=1024 (src/BolidRecorder.cpp:102-104: the reference asserts);
+    here the recorder simply asks for no scan and the rows still flow."""
+    bins, overlap = 1024, 512
+    rng = np.random.default_rng(5)
+    iq = noise_iq(rng, 1024 * 6)
+    i16 = np.clip(np.rint(add_tone(iq * 300, 10400.0, 8000.0)), -32768, 32767)
+    z = i16[:, 0] + 1j * i16[:, 1]
+    p = HostPipeline(bins, overlap, max_batch_rows=2, snapshot_length=1)
+    for i in range(0, len(z), 1024):
+        p.process(z[i:i + 1024])
+    p.end()
+    assert p.rows == 11 and p.events() == []
+    want = oracle.stft(z, bins, overlap)
+    got = np.stack([p.ring_row(p.ring_mark() - 11 + i) for i in range(11)])
+    assert rel_to_row_max(got, want) <= 1e-5
+    p.close()

@@ -1,0 +1,96 @@
+"""GPU: the streaming half of the C ABI (ro_stft_push / flush / fetch) -- the Backend::process
+boundary -- against the oracle, for every sample format a reference frontend produces."""
+import numpy as np
+import pytest
+
+from util import add_tone, noise_iq, rel_to_row_max
+
+pytestmark = pytest.mark.gpu
+
+
+def stream(ro, iq_chunks, bins, overlap, **kw):
+    rows, recs, firsts = [], [], []
+    with ro.Stft(bins=bins, overlap=overlap, **kw) as st:
+        for c in iq_chunks:
+            st.push(c)
+            while True:
+                first, r, rec = st.fetch(5)
+                if len(r) == 0:
+                    break
+                rows.append(r); firsts.append(first)
+                if rec is not None:
+                    recs.append(rec)
+        st.flush()
+        while True:
+            first, r, rec = st.fetch(1000)
+            if len(r) == 0:
+                break
+            rows.append(r); firsts.append(first)
+            if rec is not None:
+                recs.append(rec)
+        stats = st.stats()
+    return (np.concatenate(rows) if rows else np.zeros((0, bins), np.float32)), recs, firsts, stats
+
+
+@pytest.mark.parametrize("bins,overlap,chunk,batch", [(1024, 512, 1024, 3), (4096, 2048, 4096, 0),
+                                                       (4096, 3072, 333, 7), (32768, 24576, 4096, 5)])
+def test_push_fetch_float32(ro, oracle, bins, overlap, chunk, batch):
+    rng = np.random.default_rng(chunk)
+    hop = bins - overlap
+    T = bins + 12 * hop + 17
+    iq = noise_iq(rng, T)
+    chunks = [iq[i:i + chunk] for i in range(0, T, chunk)]
+    got, _, firsts, stats = stream(ro, chunks, bins, overlap, max_batch_rows=batch)
+    want = oracle.stft(iq, bins, overlap)
+    assert got.shape == want.shape == (13, bins)
+    assert rel_to_row_max(got, want) <= 1e-5
+    assert firsts[0] == 0 and stats["samples_in"] == T and stats["rows_out"] == 13
+
+
+def test_push_formats_agree(ro, oracle):
+    """struct Complex (double), float32 and int16 inputs of the same values give identical rows."""
+    bins, overlap = 2048, 1024
+    rng = np.random.default_rng(1)
+    f = add_tone(noise_iq(rng, bins * 5, 200.0), 5000.0, 9000.0)
+    i16 = np.clip(np.rint(f), -32768, 32767).astype(np.int16)
+    a, *_ = stream(ro, [i16], bins, overlap)
+    b, *_ = stream(ro, [i16.astype(np.float32)], bins, overlap)
+    c, *_ = stream(ro, [i16[:, 0].astype(np.float64) + 1j * i16[:, 1]], bins, overlap)
+    d, *_ = stream(ro, [(i16[:, 0] + 1j * i16[:, 1]).astype(np.complex64)], bins, overlap)
+    assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d)
+    assert rel_to_row_max(a, oracle.stft(i16.astype(np.float64), bins, overlap)) <= 1e-5
+
+
+def test_fetch_columns_and_records(ro, oracle):
+    bins, overlap = 32768, 24576
+    b = oracle.bolid_bands(bins, 48000, overlap, 10300, 10900, 9000, 9600, 2, 5, 40)
+    bands = ro.Bands(low_noise=b.low_noise, noise_width=b.noise_width, low_detect=b.low_detect,
+                     detect_width=b.detect_width, avg_bins=b.avg_bins)
+    rng = np.random.default_rng(2)
+    iq = noise_iq(rng, bins + 9 * 8192)
+    with ro.Stft(bins=bins, overlap=overlap, bands=bands, max_batch_rows=4) as st:
+        assert st.push(iq) == 8                       # two full batches are ready, two rows still staged
+        first, band, rec = st.fetch(3, first_col=22528, cols=2048)
+        assert first == 0 and band.shape == (3, 2048) and rec.shape == (3,)
+        assert st.flush() == 7
+        first2, rest, rec2 = st.fetch(100)
+        assert first2 == 3 and rest.shape == (7, bins)
+        assert st.fetch(10)[1].shape[0] == 0
+    want = oracle.stft(iq, bins, overlap)
+    assert rel_to_row_max(band, want[:3, 22528:24576]) <= 1e-5 * want[:3].max() / want[:3, 22528:24576].max() + 1e-5
+    assert rel_to_row_max(rest, want[3:]) <= 1e-5
+    n, p, a = oracle.scan_rows(rest, b.low_noise, b.noise_width, b.low_detect, b.detect_width, b.avg_bins)
+    assert np.array_equal(rec2["noise"], n) and np.array_equal(rec2["peak"], p) and np.array_equal(rec2["average"], a)
+
+
+def test_short_and_empty_streams(ro):
+    with ro.Stft(bins=1024, overlap=512) as st:
+        assert st.push(np.zeros((0, 2), np.float32)) == 0
+        assert st.push(np.zeros((1023, 2), np.float32)) == 0
+        assert st.flush() == 0                        # less than one window: nothing comes out
+        assert st.push(np.zeros((1, 2), np.float32)) == 0
+        assert st.flush() == 1
+        first, rows, _ = st.fetch(10)
+        assert first == 0 and rows.shape == (1, 1024) and not rows.any()
+        st.reset()
+        assert st.flush() == 0
