@@ -19,4 +19,10 @@ from .capi import (  # noqa: F401
     RO_WINDOW_NUTTALL, RO_WINDOW_HANN, RO_WINDOW_CUSTOM, RO_IQ_F32, RO_IQ_I16, RO_IQ_F64,
 )
 
+def sharding():
+    """time-chunk sharding helpers (radio-observer_amd/timeshard.py; imports torch lazily)"""
+    import importlib
+    return importlib.import_module(__name__ + ".timeshard")
+
+
 __all__ = ["capi", "Stft", "StftError", "Bands", "ScanRecord", "library"]
