@@ -16,4 +16,9 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAI
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$N -- $SHORT > /dev/null 2> $OUT/pmc_$N.log || echo "pmc $C failed"
   echo "pmc $C done"
 done
-find $OUT -name "*.csv" | head -50
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --output-format csv -d $OUT/calib_$C -- python3 $ROOT/tools/calib_run.py > $OUT/calib_$C.log 2>&1 || echo "calib $C failed"
+  echo "calib $C done"
+done
+python3 $ROOT/tools/profile_report.py $OUT > $OUT/SUMMARY.txt 2>&1
+cat $OUT/SUMMARY.txt
