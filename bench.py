@@ -53,7 +53,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-parity", action="store_true")
     p.add_argument("--pmc-traffic", type=float, default=None,
-                   help="HBM bytes per launch from a separate rocprofv3 --pmc run (see profiles/)")
+                   help="HBM bytes per launch from a separate rocprofv3 --pmc run (default: profiles/*_traffic.json)")
     return p.parse_args()
 
 
@@ -97,6 +97,22 @@ def cpu_baseline(iq_host, w, bands, budget_s):
         done += n
     dt = time.perf_counter() - t0
     return done, dt
+
+
+def pmc_traffic(rows):
+    """HBM bytes per launch measured with rocprofv3 PMC counters in their own passes (the counters
+    cannot be read from inside this process); the newest profiles/rNN_traffic.json, scaled to `rows`."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
+        try:
+            best = json.load(open(f))
+        except Exception:
+            pass
+    if not best:
+        return None
+    per_row = best["traffic_bytes_per_launch"] / (best["algorithmic_bytes_per_launch"] / ALG_BYTES_PER_ROW)
+    return per_row * rows
 
 
 def main():
@@ -205,7 +221,8 @@ def main():
                        "parallelism": "time-chunk per GPU" + ("; all-gather of band tile [%d,+%d) + scan "
                                                               "records per step, overlapped" % tile if tile else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": a.pmc_traffic,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": a.pmc_traffic if a.pmc_traffic is not None else pmc_traffic(R),
                          "kernel": "stft_kernel<32768>", "kernel_ms": k_stft,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ROW * R,
                          "scan_kernel_ms": k_scan},
