@@ -49,6 +49,8 @@ def parse():
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--rows", type=int, default=16384, help="rows per step per GPU")
+    p.add_argument("--bins", type=int, default=32768, help="FFT size (default = the headline C3/C4 workload)")
+    p.add_argument("--overlap", type=int, default=None, help="overlap in samples (default 75 %% of bins)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-parity", action="store_true")
@@ -61,7 +63,7 @@ def make_bands(ro):
     f2b = lambda f: ro.frequency_to_bin(BINS, FS, f)
     lo_d, hi_d = sorted((f2b(JSON_BOLID["min_detect"]), f2b(JSON_BOLID["max_detect"])))
     lo_n, hi_n = sorted((f2b(JSON_BOLID["min_noise"]), f2b(JSON_BOLID["max_noise"])))
-    avg = f2b(JSON_BOLID["avg_freq_range"]) - f2b(0.0)
+    avg = max(f2b(JSON_BOLID["avg_freq_range"]) - f2b(0.0), 1)
     return ro.Bands(low_noise=lo_n, noise_width=hi_n - lo_n, low_detect=lo_d, detect_width=hi_d - lo_d,
                     avg_bins=avg)
 
@@ -111,12 +113,20 @@ def pmc_traffic(rows):
             pass
     if not best:
         return None
+    if (BINS, OVERLAP) != (32768, 24576):
+        return None                                          # the PMC passes were taken on the headline shape
     per_row = best["traffic_bytes_per_launch"] / (best["algorithmic_bytes_per_launch"] / ALG_BYTES_PER_ROW)
     return per_row * rows
 
 
 def main():
     a = parse()
+    global BINS, OVERLAP, HOP, ALG_BYTES_PER_ROW
+    if a.bins != BINS or a.overlap is not None:             # non-headline shapes (e.g. C2: --bins 4096 --overlap 2048)
+        BINS = a.bins
+        OVERLAP = a.overlap if a.overlap is not None else (3 * BINS) // 4
+        HOP = BINS - OVERLAP
+        ALG_BYTES_PER_ROW = HOP * 8 + BINS * 4
     import torch
     import torch.distributed as dist
 
@@ -214,8 +224,10 @@ def main():
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C3/C4: synthetic IQ 48 kHz, FFT bins=32768, overlap=24576 (75%), "
-                                   "Nuttall window, waterfall magnitude rows + BolidRecorder scan",
+            "config": {"workload": "%s: synthetic IQ 48 kHz, FFT bins=%d, overlap=%d (%d%%), "
+                                   "Nuttall window, waterfall magnitude rows + BolidRecorder scan"
+                                   % ("C3/C4" if (BINS, OVERLAP) == (32768, 24576) else "custom", BINS, OVERLAP,
+                                      round(100.0 * OVERLAP / BINS)),
                        "rows_per_step_per_gpu": R, "samples_per_step_per_gpu": samples,
                        "input": "float32 I/Q resident in HBM", "output": "float32 rows in HBM",
                        "parallelism": "time-chunk per GPU" + ("; all-gather of band tile [%d,+%d) + scan "
@@ -223,7 +235,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": a.pmc_traffic if a.pmc_traffic is not None else pmc_traffic(R),
-                         "kernel": "stft_kernel<32768>", "kernel_ms": k_stft,
+                         "kernel": "stft_kernel<%d>" % BINS, "kernel_ms": k_stft,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ROW * R,
                          "scan_kernel_ms": k_scan},
             "device": st.device_name,
@@ -264,7 +276,7 @@ def main():
 
         # ---- CPU baseline (rank 0, N=1 only): the oracle port on the host cores of this box
         if world == 1 and not a.no_cpu_baseline:
-            n_cpu = min(R, 8192)
+            n_cpu = min(R, 8192 if BINS >= 16384 else 65536)
             host = iq[:BINS + HOP * (n_cpu - 1)].cpu().numpy()
             done, cdt = cpu_baseline(host, st.window, bands, a.cpu_seconds)
             out["cpu_baseline"] = {"value": done / cdt, "unit": "rows/s", "cores": 1, "kind": "port",

@@ -42,6 +42,10 @@
 #ifndef RO_PAIRED_LOADS
 #define RO_PAIRED_LOADS 1
 #endif
+// threads per workgroup of the N = 32768 plan (1024: 32 points per thread; 512: 64)
+#ifndef RO_T32768
+#define RO_T32768 1024
+#endif
 // share (percent) of the next row's window coefficients that is prefetched across the transform
 #ifndef RO_WIN_EARLY_PCT
 #define RO_WIN_EARLY_PCT 25
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
     load_row(make_rsrc(iq + (a.first_row + row) * (int64_t)a.hop * S::BYTES, N * S::BYTES));
 
     constexpr int RL = PL::R3 > 1 ? PL::R3 : (PL::R2 > 1 ? PL::R2 : (PL::R1 > 1 ? PL::R1 : PL::R0));
-    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
     auto stamp = [&](int k) {
         if constexpr (RO_STAMPS) {
             unsigned long long t;
@@ -511,14 +515,16 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
                 }
             }
         }
+        stamp(10);                                  // magnitudes -> LDS writes issued
         // a zero-sized descriptor turns the loads into no-ops after the last row
         load_row(make_rsrc(iq + (a.first_row + (has_next ? next : row)) * (int64_t)a.hop * S::BYTES,
                            has_next ? N * S::BYTES : 0));
         // unconditional (zero-sized descriptor after the last row): a branch here would keep the
         // old coefficients alive next to the new ones
         load_window(make_rsrc(a.window, has_next ? N * 4 : 0), cE{}, cN{});
-        stamp(7);                                   // magnitudes to LDS + next-row loads issued
+        stamp(7);                                   // next-row loads issued
         __syncthreads();
+        stamp(11);                                  // barrier 1
         {
             const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(a.rows_out + row * a.row_stride, N * 4);
             const float4 *lds_m4 = reinterpret_cast<const float4 *>(smem);
@@ -532,15 +538,16 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
                 if (q & 1) asm volatile("" ::: "memory");
             }
         }
+        stamp(12);                                  // LDS read-back + row stores issued
         __syncthreads();                            // LDS is reused by the next row's exchange
-        stamp(8);                                   // row stores issued
+        stamp(8);                                   // barrier 2
         st_acc[9] += 1;
         if (!has_next) break;
         row = next;
     }
     if constexpr (RO_STAMPS) {
         if (a.stamps && tid == 0)
-            for (int k = 0; k < 10; ++k) a.stamps[blockIdx.x * 10 + k] = st_acc[k];
+            for (int k = 0; k < 16; ++k) a.stamps[blockIdx.x * 16 + k] = st_acc[k];
     }
 }
 
@@ -693,7 +700,7 @@ template <class PL, int FMT> static hipError_t launch_plan(const StftArgs &a, hi
 }
 
 //                      N      T   R0  R1  R2  R3  split
-using Plan32768 = Plan<32768, 1024, 32, 32, 32, 1, true>;
+using Plan32768 = Plan<32768, RO_T32768, 32, 32, 32, 1, true>;
 using Plan16384 = Plan<16384,  512, 32, 32, 16, 1, true>;
 using Plan8192  = Plan< 8192,  256, 32, 32,  8, 1, false>;
 using Plan4096  = Plan< 4096,  256, 16, 16, 16, 1, false>;

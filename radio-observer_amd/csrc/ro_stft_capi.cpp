@@ -443,7 +443,7 @@ extern "C" int ro_stft_destroy(ro_stft_t *h)
 extern "C" int ro_stft_debug_stamps(ro_stft_t *h, unsigned long long *out, int max_words)
 {
     if (!h) return fail(RO_ERR_INVALID, "null handle");
-    const int words = 4096 * 10;
+    const int words = 4096 * 16;
     if (!h->d_stamps) {
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipMalloc(&h->d_stamps, sizeof(unsigned long long) * words));

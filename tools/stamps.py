@@ -20,14 +20,16 @@ torch.cuda.synchronize()
 lib.ro_stft_debug_stamps(st._h, None, 0)          # allocate; from now on the kernel records
 st.run_resident(iq, ro.RO_IQ_F32, samples, 0, R, rows, stream=torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
-buf = np.zeros(4096 * 10, dtype=np.uint64)
+buf = np.zeros(4096 * 16, dtype=np.uint64)
 lib.ro_stft_debug_stamps(st._h, buf.ctypes.data_as(C.c_void_p), buf.size)
-a = buf.reshape(-1, 10)
+a = buf.reshape(-1, 16)
 a = a[a[:, 9] > 0].astype(np.float64)
-names = ["window(+sample wait)", "deferred stores", "butterflies0+twpf", "exchange1", "tw+bfly1", "exchange2",
-         "tw+bfly2", "mag+next loads", "stores issue"]
-per_row = a[:, :9].sum(0) / a[:, 9].sum()
+idx = [0, 1, 2, 3, 4, 5, 6, 10, 7, 11, 12, 8]
+names = ["window mult (+sample wait)", "-", "butterflies0 + tw prefetch", "exchange 1", "tw + butterflies 1",
+         "exchange 2", "tw + butterflies 2", "magnitudes -> LDS", "next-row loads issue", "barrier 1",
+         "LDS read-back + stores issue", "barrier 2"]
+per_row = a[:, idx].sum(0) / a[:, 9].sum()
 tot = per_row.sum()
 print("workgroups %d, rows/wg %.1f, ticks/row %.0f (s_memtime = shader cycles; at 2.1 GHz => %.2f us)" % (len(a), a[:, 9].mean(), tot, tot / 2100.0))
 for n, t in zip(names, per_row):
-    print("  %-22s %8.0f ticks  %5.1f %%" % (n, t, 100 * t / tot))
+    print("  %-30s %8.0f ticks  %5.1f %%" % (n, t, 100 * t / tot))
