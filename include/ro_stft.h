@@ -105,7 +105,8 @@ int     ro_time_to_fft_samples(double seconds, float fft_sample_rate);
 int64_t ro_row_count(int64_t samples, int bins, int overlap);
 /* window table as FFTBackend::startStream builds it, :156-186 */
 int     ro_window_table(int kind, int bins, float *out);
-/* 1 if `bins` has a kernel in this build */
+/* 1 if `bins` has a kernel in this build: powers of two 256 .. 1048576 (single pass up to
+ * 32768, multi-pass through HBM scratch above) */
 int     ro_bins_supported(int bins);
 
 /* ---- handle --------------------------------------------------------------- */

@@ -45,6 +45,26 @@ struct ScanArgs {
     int               avg_bins;
 };
 
+// ---- large transforms (bins > 32768): multi-pass Stockham through HBM scratch
+struct BigArgs {
+    const void   *iq;          // FIRST pass: sample 0 of the stream
+    const float  *window;      // FIRST pass
+    const float2 *tw;          // exp(-2 pi i m / N), m in [0, N)
+    const float2 *in;          // middle / last passes: [rows][N]
+    float2       *out;         // first / middle passes: [rows][N]
+    float        *rows_out;    // LAST pass: [rows][row_stride]
+    int64_t       first_row;   // stream row index of scratch row 0
+    int64_t       rows;
+    int64_t       row_stride;
+    int           hop;
+    int           n;           // N
+    int           ns;          // product of the radices of earlier passes
+    float         gain;
+};
+bool       big_supported(int bins);               // power of two in (32768, 2^20]
+int        big_radices(int bins, int radices[8]); // number of passes
+hipError_t launch_big_pass(int radix, bool first, bool last, int fmt, const BigArgs &a, hipStream_t s);
+
 bool       stft_supported(int bins);
 int        stft_twiddle_count(int bins);          // float2 entries, <0 if unsupported
 bool       stft_radices(int bins, int radices[4]);

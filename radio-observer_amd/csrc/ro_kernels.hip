@@ -552,6 +552,70 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// Large transforms (N = 65536 ... 1048576, the sizes of Bolidozor.json:45 and Ionozor.json:27).
+// A row no longer fits a CU, so the same Stockham autosort recurrence runs as separate passes
+// of radix 16 (last pass 2..16) over complex scratch rows in HBM: one thread per butterfly,
+//   in :  x[j + k*(N/R)] * w(k*(j mod Ns)/(Ns*R)),   out:  y[(j/Ns)*Ns*R + (j mod Ns) + k*Ns].
+// The first pass reads the samples in place and applies the window, the last one writes
+// |X| fft-shifted.  Twiddles come from one exp(-2 pi i m/N) table (exact entries, no products).
+// Bound: HBM, 16 B per point and pass; not the benchmarked shape (5.9 rows/s is real time there).
+// ---------------------------------------------------------------------------
+template <int R, bool FIRST, bool LAST, int FMT>
+__global__ __launch_bounds__(256) void big_pass_kernel(BigArgs a)
+{
+    const int per_row = a.n / R;                                  // butterflies per row (multiple of 256)
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = g / per_row;
+    if (row >= a.rows) return;
+    const int j = (int)(g - row * per_row);
+    v2f v[R];
+    if constexpr (FIRST) {
+        using S = Sample<FMT>;
+        const int64_t s0 = (a.first_row + row) * (int64_t)a.hop;
+        const __amdgpu_buffer_rsrc_t rs =
+            make_rsrc(reinterpret_cast<const char *>(a.iq) + s0 * S::BYTES, (unsigned)a.n * S::BYTES);
+        const v2f gain2 = (v2f){0.0f, a.gain};
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int n = j + k * per_row;
+            const float w = a.window[n];
+            v[k] = (S::load(rs, n * S::BYTES, 0) + gain2) * (v2f){w, w};
+        }
+    } else {
+        const float2 *in = a.in + row * (int64_t)a.n;
+        const int kk = j & (a.ns - 1);
+        const int step = a.n / (a.ns * R);                        // table stride of this pass
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const float2 x = in[j + k * per_row];
+            v[k] = (v2f){x.x, x.y};
+            if (k > 0) {
+                const float2 t = a.tw[(int64_t)k * kk * step];    // k*kk*step < N
+                v[k] = cmul(v[k], (v2f){t.x, t.y});
+            }
+        }
+    }
+    dif<R>(v);
+    const int j0 = (j / a.ns) * (a.ns * R) + (j & (a.ns - 1));
+    if constexpr (LAST) {
+        float *out = a.rows_out + row * a.row_stride;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const v2f x = v[bitrev<R>(k)];
+            const v2f sq = x * x;
+            out[(j0 + k * a.ns + a.n / 2) & (a.n - 1)] = __builtin_amdgcn_sqrtf(sq.x + sq.y);
+        }
+    } else {
+        float2 *out = a.out + row * (int64_t)a.n;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const v2f x = v[bitrev<R>(k)];
+            out[j0 + k * a.ns] = make_float2(x.x, x.y);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // band tile: compact copy of columns [first, first+cols) of every row (what the FITS
 // writer keeps, src/WaterfallBackend.cpp:176,204) -- the unit the multi-GPU gather moves.
 // ---------------------------------------------------------------------------
@@ -772,6 +836,53 @@ hipError_t launch_stft(int bins, int fmt, const StftArgs &a, hipStream_t s)
     case 256:   return launch_fmt<Plan256>(a, fmt, s);
     default:    return hipErrorInvalidValue;
     }
+}
+
+bool big_supported(int bins)
+{
+    return bins > 32768 && bins <= (1 << 20) && (bins & (bins - 1)) == 0;
+}
+
+int big_radices(int bins, int radices[8])
+{
+    if (!big_supported(bins)) return 0;
+    int l = 0;
+    while ((1 << l) < bins) ++l;
+    int n = 0;
+    while (l >= 4 + 1 || l == 4) {          // radix 16 while at least one more bit (or exactly 4) remains
+        radices[n++] = 16;
+        l -= 4;
+        if (l < 4) break;
+    }
+    if (l > 0) radices[n++] = 1 << l;       // last pass: 2, 4 or 8
+    return n;
+}
+
+template <int R, bool FIRST, bool LAST, int FMT> static hipError_t launch_big(const BigArgs &a, hipStream_t s)
+{
+    const int64_t total = a.rows * (int64_t)(a.n / R);
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffff) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((big_pass_kernel<R, FIRST, LAST, FMT>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_big_pass(int radix, bool first, bool last, int fmt, const BigArgs &a, hipStream_t s)
+{
+    if (a.rows <= 0) return hipSuccess;
+    if (first && !last && radix == 16)
+        return fmt == RO_FMT_I16 ? launch_big<16, true, false, RO_FMT_I16>(a, s)
+                                 : launch_big<16, true, false, RO_FMT_F32>(a, s);
+    if (!first && !last && radix == 16) return launch_big<16, false, false, RO_FMT_F32>(a, s);
+    if (!first && last) {
+        switch (radix) {
+        case 2:  return launch_big<2, false, true, RO_FMT_F32>(a, s);
+        case 4:  return launch_big<4, false, true, RO_FMT_F32>(a, s);
+        case 8:  return launch_big<8, false, true, RO_FMT_F32>(a, s);
+        case 16: return launch_big<16, false, true, RO_FMT_F32>(a, s);
+        }
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_tile(const TileArgs &a, hipStream_t s)

@@ -84,6 +84,18 @@ std::vector<float2> build_twiddles(int bins)
     return tw;
 }
 
+// exp(-2 pi i m / N) for the multi-pass path, rounded once from long double
+std::vector<float2> build_full_twiddles(int bins)
+{
+    std::vector<float2> tw((size_t)bins);
+    const long double two_pi = 8.0L * atanl(1.0L);
+    for (int m = 0; m < bins; ++m) {
+        const long double ang = -two_pi * (long double)m / (long double)bins;
+        tw[(size_t)m] = make_float2((float)cosl(ang), (float)sinl(ang));
+    }
+    return tw;
+}
+
 struct Batch {
     int64_t first_row = 0;
     int64_t rows = 0;
@@ -118,6 +130,12 @@ struct ro_stft {
     double stat_kernel_ms = 0.0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     unsigned long long *d_stamps = nullptr;    // diagnostic builds (RO_STAMPS) only
+
+    // large transforms (bins > 32768): full twiddle table + two complex scratch blocks in HBM
+    bool    big = false;
+    float2 *d_tw_big = nullptr;
+    float2 *d_scratch[2] = {nullptr, nullptr};
+    int64_t scratch_rows = 0;
 };
 
 namespace {
@@ -207,6 +225,48 @@ ro::ScanArgs make_scan_args(const ro_stft *h, const float *d_rows, int64_t row_s
     return s;
 }
 
+// window -> FFT -> |X| for rows [first_row, +rows): the single-pass kernel, or for bins > 32768
+// the multi-pass path in chunks that fit the scratch blocks
+int launch_transform(ro_stft *h, const void *d_iq, int format, int64_t first_row, int64_t rows, float *d_rows,
+                     int64_t row_stride, hipStream_t s)
+{
+    if (!h->big) {
+        ro::StftArgs a = make_stft_args(h, d_iq, first_row, rows, d_rows, row_stride);
+        HIP_TRY(ro::launch_stft(h->bins, format, a, s));
+        return RO_OK;
+    }
+    if (!h->d_scratch[0]) {
+        h->scratch_rows = std::max<int64_t>(1, ((int64_t)512 << 20) / ((int64_t)h->bins * 8));
+        for (int i = 0; i < 2; ++i)
+            HIP_TRY(hipMalloc(&h->d_scratch[i], (size_t)h->scratch_rows * h->bins * sizeof(float2)));
+    }
+    int radix[8];
+    const int passes = ro::big_radices(h->bins, radix);
+    for (int64_t done = 0; done < rows; done += h->scratch_rows) {
+        const int64_t n = std::min(h->scratch_rows, rows - done);
+        ro::BigArgs b{};
+        b.iq = d_iq;
+        b.window = h->d_window;
+        b.tw = h->d_tw_big;
+        b.first_row = first_row + done;
+        b.rows = n;
+        b.row_stride = row_stride;
+        b.hop = h->hop;
+        b.n = h->bins;
+        b.gain = (float)h->cfg.iq_gain;
+        int ns = 1;
+        for (int p = 0; p < passes; ++p) {
+            b.ns = ns;
+            b.in = h->d_scratch[(p + 1) & 1];
+            b.out = h->d_scratch[p & 1];
+            b.rows_out = d_rows + done * row_stride;
+            HIP_TRY(ro::launch_big_pass(radix[p], p == 0, p == passes - 1, format, b, s));
+            ns *= radix[p];
+        }
+    }
+    return RO_OK;
+}
+
 // run one batch of the streaming path: rows [rows_emitted, +rows) from the staged samples
 int run_stream_batch(ro_stft *h, int64_t rows)
 {
@@ -215,9 +275,11 @@ int run_stream_batch(ro_stft *h, int64_t rows)
     const int64_t need = (rows - 1) * (int64_t)h->hop + h->bins;       // samples
     HIP_TRY(hipMemcpyAsync(h->d_iq, h->staged.data(), (size_t)need * 2 * sizeof(float),
                            hipMemcpyHostToDevice, h->stream));
-    ro::StftArgs a = make_stft_args(h, h->d_iq, 0, rows, h->d_rows, h->bins);
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    HIP_TRY(ro::launch_stft(h->bins, RO_IQ_F32, a, h->stream));
+    {
+        int rc = launch_transform(h, h->d_iq, RO_IQ_F32, 0, rows, h->d_rows, h->bins, h->stream);
+        if (rc != RO_OK) return rc;
+    }
     if (h->cfg.enable_scan) {
         ro::ScanArgs s = make_scan_args(h, h->d_rows, h->bins, rows, h->d_records);
         HIP_TRY(ro::launch_scan(s, h->stream));
@@ -328,7 +390,7 @@ extern "C" int ro_window_table(int kind, int bins, float *out)
     return RO_OK;
 }
 
-extern "C" int ro_bins_supported(int bins) { return ro::stft_supported(bins) ? 1 : 0; }
+extern "C" int ro_bins_supported(int bins) { return (ro::stft_supported(bins) || ro::big_supported(bins)) ? 1 : 0; }
 
 // ---------------------------------------------------------------------------
 // handle
@@ -340,8 +402,8 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg, ro_stft_t **out)
     if (cfg->struct_size != sizeof(ro_stft_config_t))
         return fail(RO_ERR_INVALID, "ro_stft_create: struct_size %u != %zu", cfg->struct_size,
                     sizeof(ro_stft_config_t));
-    if (!ro::stft_supported(cfg->bins))
-        return fail(RO_ERR_UNSUPPORTED, "bins = %d has no kernel (powers of two 256..32768)", cfg->bins);
+    if (!ro::stft_supported(cfg->bins) && !ro::big_supported(cfg->bins))
+        return fail(RO_ERR_UNSUPPORTED, "bins = %d has no kernel (powers of two 256..1048576)", cfg->bins);
     if (cfg->iq_phase_shift != 0)
         return fail(RO_ERR_UNSUPPORTED, "iq_phase_shift != 0 is undefined behaviour in the reference "
                                         "(src/FFTBackend.cpp:67-71) and is not supported");
@@ -388,8 +450,9 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg, ro_stft_t **out)
         std::memcpy(h->window.data(), cfg->window_table, sizeof(float) * h->bins);
     else
         build_window(cfg->window_kind, h->bins, h->window.data());
-    std::vector<float2> tw = build_twiddles(h->bins);
-    if ((int)tw.size() != ro::stft_twiddle_count(h->bins)) {
+    h->big = ro::big_supported(h->bins);
+    std::vector<float2> tw = h->big ? std::vector<float2>() : build_twiddles(h->bins);
+    if (!h->big && (int)tw.size() != ro::stft_twiddle_count(h->bins)) {
         delete h;
         return fail(RO_ERR_STATE, "internal: twiddle table size mismatch");
     }
@@ -411,6 +474,11 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg, ro_stft_t **out)
     CREATE_TRY(hipMemcpy(h->d_window, h->window.data(), sizeof(float) * h->bins, hipMemcpyHostToDevice));
     if (!tw.empty())
         CREATE_TRY(hipMemcpy(h->d_twiddles, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice));
+    if (h->big) {
+        std::vector<float2> full = build_full_twiddles(h->bins);
+        CREATE_TRY(hipMalloc(&h->d_tw_big, sizeof(float2) * full.size()));
+        CREATE_TRY(hipMemcpy(h->d_tw_big, full.data(), sizeof(float2) * full.size(), hipMemcpyHostToDevice));
+    }
 #undef CREATE_TRY
 
     // streaming buffers are allocated lazily by the first push
@@ -431,6 +499,9 @@ extern "C" int ro_stft_destroy(ro_stft_t *h)
     if (h->d_rows) (void)hipFree(h->d_rows);
     if (h->d_records) (void)hipFree(h->d_records);
     if (h->d_stamps) (void)hipFree(h->d_stamps);
+    if (h->d_tw_big) (void)hipFree(h->d_tw_big);
+    for (int i = 0; i < 2; ++i)
+        if (h->d_scratch[i]) (void)hipFree(h->d_scratch[i]);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -497,8 +568,8 @@ extern "C" int ro_stft_run_resident(ro_stft_t *h, const void *d_iq, int format, 
     if (rc != RO_OK || rows == 0) return rc;
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-    ro::StftArgs a = make_stft_args(h, d_iq, first_row, rows, d_rows, row_stride);
-    HIP_TRY(ro::launch_stft(h->bins, format, a, s));
+    rc = launch_transform(h, d_iq, format, first_row, rows, d_rows, row_stride, s);
+    if (rc != RO_OK) return rc;
     if (d_tile) HIP_TRY(ro::launch_tile(make_tile_args(h, d_rows, row_stride, rows, d_tile), s));
     if (d_records) {
         ro::ScanArgs sc = make_scan_args(h, d_rows, row_stride, rows, d_records);
@@ -535,11 +606,11 @@ extern "C" int ro_stft_time_resident(ro_stft_t *h, const void *d_iq, int format,
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     std::vector<hipEvent_t> ev((size_t)iters * 3);
     for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
-    ro::StftArgs a = make_stft_args(h, d_iq, first_row, rows, d_rows, row_stride);
     ro::ScanArgs sc = make_scan_args(h, d_rows, row_stride, rows, d_records);
     for (int i = 0; i < iters; ++i) {
         HIP_TRY(hipEventRecord(ev[3 * i], s));
-        HIP_TRY(ro::launch_stft(h->bins, format, a, s));
+        rc = launch_transform(h, d_iq, format, first_row, rows, d_rows, row_stride, s);
+        if (rc != RO_OK) return rc;
         HIP_TRY(hipEventRecord(ev[3 * i + 1], s));
         if (d_tile) HIP_TRY(ro::launch_tile(make_tile_args(h, d_rows, row_stride, rows, d_tile), s));
         if (d_records) HIP_TRY(ro::launch_scan(sc, s));

@@ -63,9 +63,9 @@ def test_window_tables_bit_identical_to_oracle(ro, oracle, bins):
 
 
 def test_supported_sizes(ro):
-    for b in (256, 512, 1024, 2048, 4096, 8192, 16384, 32768):
-        assert ro.bins_supported(b)
-    for b in (0, 100, 255, 1000, 65536, 524288):
+    for b in (256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144, 524288, 1048576):
+        assert ro.bins_supported(b)      # 65536 / 524288: Bolidozor.json:45, Ionozor.json:27
+    for b in (0, 100, 128, 255, 1000, 32728, 2097152):
         assert not ro.bins_supported(b)
 
 

@@ -46,6 +46,35 @@ def test_noise_rows_match_oracle(ro, oracle, torch_cuda, bins):
     assert err <= TOL
 
 
+@pytest.mark.parametrize("bins,overlap,nrows", [(65536, 49152, 5), (131072, 0, 2), (262144, 131072, 3),
+                                                 (524288, 262144, 3), (1048576, 786432, 2)])
+def test_large_transforms(ro, oracle, torch_cuda, bins, overlap, nrows):
+    """Bolidozor.json:45-46 (65536 / 49152) and Ionozor.json:27-28 (524288 / 262144): the
+    multi-pass path through HBM scratch."""
+    rng = np.random.default_rng(bins % 1000)
+    hop = bins - overlap
+    iq = add_tone(noise_iq(rng, bins + (nrows - 1) * hop + 3), 10600.0, 20.0, fs=96000)
+    got = gpu_rows(ro, torch_cuda, iq, bins, overlap, sample_rate=96000)
+    want = oracle.stft(iq, bins, overlap)
+    assert got.shape == want.shape == (nrows, bins)
+    err = rel_to_row_max(got, want)
+    print("bins=%d rel-to-row-max err %.3g" % (bins, err))
+    assert err <= TOL
+    assert abs(int(got[0].argmax()) - ro.frequency_to_bin(bins, 96000, 10600.0)) <= 1
+
+
+def test_large_transform_many_rows_cross_scratch_chunks(ro, oracle, torch_cuda):
+    """more rows than one scratch block holds (1024 rows at N=65536)."""
+    torch = torch_cuda
+    bins, overlap, nrows = 65536, 65536 - 256, 1100
+    rng = np.random.default_rng(8)
+    iq = noise_iq(rng, bins + (nrows - 1) * 256)
+    got = gpu_rows(ro, torch, iq, bins, overlap)
+    for r in (0, 1023, 1024, 1099):
+        want = oracle.stft(iq[r * 256:r * 256 + bins], bins, overlap)[0]
+        assert rel_to_row_max(got[r][None], want[None]) <= TOL
+
+
 @pytest.mark.parametrize("bins,overlap", [(1024, 512), (4096, 2048), (32768, 24576), (32768, 0),
                                            (4096, 4095), (2048, 100), (32768, 32767)])
 def test_overlap_variants(ro, oracle, torch_cuda, bins, overlap):
