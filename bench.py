@@ -54,6 +54,9 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-parity", action="store_true")
+    p.add_argument("--comm", choices=["nccl", "gloo-host"], default="nccl",
+                   help="gloo-host: rehearsal mode for 1-GPU boxes -- every rank uses cuda:0 and the gather is "
+                        "staged through host memory over gloo (exercises the N>1 control flow, not xGMI)")
     p.add_argument("--pmc-traffic", type=float, default=None,
                    help="HBM bytes per launch from a separate rocprofv3 --pmc run (default: profiles/*_traffic.json)")
     return p.parse_args()
@@ -139,12 +142,27 @@ def main():
                      % (a.gpus, a.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    if a.comm == "gloo-host":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.comm == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def all_gather(out, inp):
+        """RCCL all-gather over xGMI; in rehearsal mode the same exchange through host memory."""
+        if a.comm == "nccl":
+            dist.all_gather_into_tensor(out, inp)
+        else:
+            h_in = inp.cpu()
+            h_out = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(h_out, h_in)
+            out.copy_(h_out)
 
     ro = importlib.import_module("radio-observer_amd")
     R = a.rows
@@ -182,8 +200,8 @@ def main():
             ready.record(stream)
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ready)
-                dist.all_gather_into_tensor(g_tiles[b], tiles[b])
-                dist.all_gather_into_tensor(g_recs[b], recs[b])
+                all_gather(g_tiles[b], tiles[b])
+                all_gather(g_recs[b], recs[b])
                 ev = torch.cuda.Event()
                 ev.record(comm_stream)
                 comm_done[b] = ev
@@ -205,7 +223,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if a.comm == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
