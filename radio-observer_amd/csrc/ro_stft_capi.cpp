@@ -96,12 +96,19 @@ std::vector<float2> build_full_twiddles(int bins)
     return tw;
 }
 
+// One launch worth of finished rows on their way to the caller.  The buffers are pinned host
+// memory (hipHostMalloc) recycled through a free list; `done` fires when the device-to-host
+// copies have landed, so ro_stft_push never waits for the GPU -- only ro_stft_fetch does.
 struct Batch {
     int64_t first_row = 0;
     int64_t rows = 0;
-    std::vector<float> data;                   // rows x bins
-    std::vector<ro_scan_record_t> records;     // rows (empty when scan disabled)
+    float *data = nullptr;                     // capacity_rows x bins, pinned
+    ro_scan_record_t *records = nullptr;       // capacity_rows, pinned
+    int64_t capacity_rows = 0;
     int64_t consumed = 0;                      // rows already fetched
+    hipEvent_t done = nullptr;
+    hipEvent_t k0 = nullptr, k1 = nullptr;     // around the kernels of this batch (timing counters)
+    bool pending = false;                      // `done` not yet waited for
 };
 
 }  // namespace
@@ -118,13 +125,18 @@ struct ro_stft {
 
     // streaming state
     int batch_rows = 0;
-    std::vector<float> staged;                 // interleaved f32 I,Q not yet consumed
-    int64_t stream_sample0 = 0;                // stream index of staged[0]
+    std::vector<float> staged;                 // interleaved f32 I,Q; samples before staged_begin are spent
+    size_t  staged_begin = 0;                  // first live sample in `staged`
+    int64_t stream_sample0 = 0;                // stream index of the sample at staged_begin
+    float  *h_in[2] = {nullptr, nullptr};      // pinned H2D staging, alternating
+    hipEvent_t h_in_free[2] = {nullptr, nullptr};
+    int64_t batch_seq = 0;
+    std::vector<Batch *> batch_pool;           // recycled pinned batches
     int64_t rows_emitted = 0;                  // stream index of the next row to compute
     float *d_iq = nullptr;                     // batch input  ((batch_rows-1)*hop + bins samples)
     float *d_rows = nullptr;                   // batch output (batch_rows x bins)
     ro_scan_record_t *d_records = nullptr;
-    std::deque<Batch> ready;
+    std::deque<Batch *> ready;
     int64_t rows_ready = 0;
     int64_t stat_samples = 0, stat_rows = 0, stat_launches = 0;
     double stat_kernel_ms = 0.0;
@@ -267,56 +279,104 @@ int launch_transform(ro_stft *h, const void *d_iq, int format, int64_t first_row
     return RO_OK;
 }
 
-// run one batch of the streaming path: rows [rows_emitted, +rows) from the staged samples
+Batch *acquire_batch(ro_stft *h)
+{
+    if (!h->batch_pool.empty()) {
+        Batch *b = h->batch_pool.back();
+        h->batch_pool.pop_back();
+        return b;
+    }
+    Batch *b = new (std::nothrow) Batch();
+    if (!b) return nullptr;
+    b->capacity_rows = h->batch_rows;
+    if (hipHostMalloc(reinterpret_cast<void **>(&b->data), (size_t)b->capacity_rows * h->bins * sizeof(float),
+                      hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&b->records), (size_t)b->capacity_rows * sizeof(ro_scan_record_t),
+                      hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&b->done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreate(&b->k0) != hipSuccess || hipEventCreate(&b->k1) != hipSuccess) {
+        if (b->data) (void)hipHostFree(b->data);
+        if (b->records) (void)hipHostFree(b->records);
+        delete b;
+        return nullptr;
+    }
+    return b;
+}
+
+void release_batch(ro_stft *h, Batch *b)
+{
+    b->consumed = 0;
+    b->rows = 0;
+    b->pending = false;
+    h->batch_pool.push_back(b);
+}
+
+void destroy_batch(Batch *b)
+{
+    if (b->data) (void)hipHostFree(b->data);
+    if (b->records) (void)hipHostFree(b->records);
+    if (b->done) (void)hipEventDestroy(b->done);
+    if (b->k0) (void)hipEventDestroy(b->k0);
+    if (b->k1) (void)hipEventDestroy(b->k1);
+    delete b;
+}
+
+// run one batch of the streaming path: rows [rows_emitted, +rows) from the staged samples.
+// Everything is enqueued on the handle's stream and the call returns; the host only waits when
+// it is about to overwrite a pinned staging buffer whose upload has not finished.
 int run_stream_batch(ro_stft *h, int64_t rows)
 {
     if (rows <= 0) return RO_OK;
     HIP_TRY(hipSetDevice(h->device));
     const int64_t need = (rows - 1) * (int64_t)h->hop + h->bins;       // samples
-    HIP_TRY(hipMemcpyAsync(h->d_iq, h->staged.data(), (size_t)need * 2 * sizeof(float),
-                           hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    const int slot = (int)(h->batch_seq & 1);
+    HIP_TRY(hipEventSynchronize(h->h_in_free[slot]));                   // upload two batches ago is done
+    std::memcpy(h->h_in[slot], h->staged.data() + h->staged_begin * 2, (size_t)need * 2 * sizeof(float));
+    HIP_TRY(hipMemcpyAsync(h->d_iq, h->h_in[slot], (size_t)need * 2 * sizeof(float), hipMemcpyHostToDevice,
+                           h->stream));
+    HIP_TRY(hipEventRecord(h->h_in_free[slot], h->stream));
+    Batch *b = acquire_batch(h);
+    if (!b) return fail(RO_ERR_NOMEM, "out of pinned host memory for a row batch");
+    HIP_TRY(hipEventRecord(b->k0, h->stream));
     {
         int rc = launch_transform(h, h->d_iq, RO_IQ_F32, 0, rows, h->d_rows, h->bins, h->stream);
-        if (rc != RO_OK) return rc;
+        if (rc != RO_OK) { release_batch(h, b); return rc; }
     }
     if (h->cfg.enable_scan) {
         ro::ScanArgs s = make_scan_args(h, h->d_rows, h->bins, rows, h->d_records);
         HIP_TRY(ro::launch_scan(s, h->stream));
     }
-    HIP_TRY(hipEventRecord(h->ev1, h->stream));
-
-    Batch b;
-    b.first_row = h->rows_emitted;
-    b.rows = rows;
-    b.data.resize((size_t)rows * h->bins);
-    HIP_TRY(hipMemcpyAsync(b.data.data(), h->d_rows, b.data.size() * sizeof(float),
-                           hipMemcpyDeviceToHost, h->stream));
-    if (h->cfg.enable_scan) {
-        b.records.resize((size_t)rows);
-        HIP_TRY(hipMemcpyAsync(b.records.data(), h->d_records, (size_t)rows * sizeof(ro_scan_record_t),
+    HIP_TRY(hipEventRecord(b->k1, h->stream));
+    b->first_row = h->rows_emitted;
+    b->rows = rows;
+    HIP_TRY(hipMemcpyAsync(b->data, h->d_rows, (size_t)rows * h->bins * sizeof(float), hipMemcpyDeviceToHost,
+                           h->stream));
+    if (h->cfg.enable_scan)
+        HIP_TRY(hipMemcpyAsync(b->records, h->d_records, (size_t)rows * sizeof(ro_scan_record_t),
                                hipMemcpyDeviceToHost, h->stream));
-    }
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    h->stat_kernel_ms += ms;
+    HIP_TRY(hipEventRecord(b->done, h->stream));
+    b->pending = true;
+    h->batch_seq += 1;
     h->stat_launches += 1;
     h->stat_rows += rows;
 
-    // drop the samples no later row needs: the next row starts rows*hop further on
+    // the samples no later row needs are spent: the next row starts rows*hop further on
     const int64_t consumed = rows * (int64_t)h->hop;
-    h->staged.erase(h->staged.begin(), h->staged.begin() + (size_t)consumed * 2);
+    h->staged_begin += (size_t)consumed;
+    if (h->staged_begin * 2 > h->staged.size() / 2 && h->staged_begin > (size_t)h->bins) {   // compact now and then
+        h->staged.erase(h->staged.begin(), h->staged.begin() + h->staged_begin * 2);
+        h->staged_begin = 0;
+    }
     h->stream_sample0 += consumed;
     h->rows_emitted += rows;
     h->rows_ready += rows;
-    h->ready.push_back(std::move(b));
+    h->ready.push_back(b);
     return RO_OK;
 }
 
 int64_t staged_complete_rows(const ro_stft *h)
 {
-    const int64_t have = (int64_t)(h->staged.size() / 2);
+    const int64_t have = (int64_t)(h->staged.size() / 2 - h->staged_begin);
     if (have < h->bins) return 0;
     return (have - h->bins) / h->hop + 1;
 }
@@ -499,6 +559,15 @@ extern "C" int ro_stft_destroy(ro_stft_t *h)
     if (h->d_rows) (void)hipFree(h->d_rows);
     if (h->d_records) (void)hipFree(h->d_records);
     if (h->d_stamps) (void)hipFree(h->d_stamps);
+    while (!h->ready.empty()) {
+        destroy_batch(h->ready.front());
+        h->ready.pop_front();
+    }
+    for (Batch *b : h->batch_pool) destroy_batch(b);
+    for (int i = 0; i < 2; ++i) {
+        if (h->h_in[i]) (void)hipHostFree(h->h_in[i]);
+        if (h->h_in_free[i]) (void)hipEventDestroy(h->h_in_free[i]);
+    }
     if (h->d_tw_big) (void)hipFree(h->d_tw_big);
     for (int i = 0; i < 2; ++i)
         if (h->d_scratch[i]) (void)hipFree(h->d_scratch[i]);
@@ -653,6 +722,11 @@ extern "C" int ro_stft_push(ro_stft_t *h, const void *iq, int format, int64_t sa
         HIP_TRY(hipMalloc(&h->d_iq, in_samples * 2 * sizeof(float)));
         HIP_TRY(hipMalloc(&h->d_rows, (size_t)h->batch_rows * h->bins * sizeof(float)));
         HIP_TRY(hipMalloc(&h->d_records, (size_t)h->batch_rows * sizeof(ro_scan_record_t)));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->h_in[i]), in_samples * 2 * sizeof(float),
+                                  hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&h->h_in_free[i], hipEventDisableTiming));
+        }
     }
 
     // the caller's buffer is only valid during the call (src/WAVStream.cpp:113,123): copy now.
@@ -700,19 +774,29 @@ extern "C" int ro_stft_fetch(ro_stft_t *h, int64_t max_rows, int first_col, int 
         return fail(RO_ERR_INVALID, "columns [%d,+%d) outside [0,%d)", first_col, cols, h->bins);
     if (records_out && !h->cfg.enable_scan) return fail(RO_ERR_STATE, "scan records requested but scan is off");
     int64_t got = 0;
-    if (first_row_index) *first_row_index = h->ready.empty() ? h->rows_emitted
-                                                             : h->ready.front().first_row + h->ready.front().consumed;
+    if (first_row_index) *first_row_index = h->rows_emitted;
+    if (first_row_index && !h->ready.empty())
+        *first_row_index = h->ready.front()->first_row + h->ready.front()->consumed;
     while (got < max_rows && !h->ready.empty()) {
-        Batch &b = h->ready.front();
-        const int64_t take = std::min(max_rows - got, b.rows - b.consumed);
-        for (int64_t r = 0; r < take; ++r) {
-            const float *src = b.data.data() + (size_t)(b.consumed + r) * h->bins + first_col;
-            if (rows_out) std::memcpy(rows_out + (size_t)(got + r) * cols, src, sizeof(float) * cols);
-            if (records_out) records_out[got + r] = b.records[(size_t)(b.consumed + r)];
+        Batch *b = h->ready.front();
+        if (b->pending) {                                   // the only place the host waits for the GPU
+            HIP_TRY(hipEventSynchronize(b->done));
+            b->pending = false;
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, b->k0, b->k1) == hipSuccess) h->stat_kernel_ms += ms;
         }
-        b.consumed += take;
+        const int64_t take = std::min(max_rows - got, b->rows - b->consumed);
+        for (int64_t r = 0; r < take; ++r) {
+            const float *src = b->data + (size_t)(b->consumed + r) * h->bins + first_col;
+            if (rows_out) std::memcpy(rows_out + (size_t)(got + r) * cols, src, sizeof(float) * cols);
+            if (records_out) records_out[got + r] = b->records[(size_t)(b->consumed + r)];
+        }
+        b->consumed += take;
         got += take;
-        if (b.consumed == b.rows) h->ready.pop_front();
+        if (b->consumed == b->rows) {
+            h->ready.pop_front();
+            release_batch(h, b);
+        }
     }
     h->rows_ready -= got;
     *rows_got = got;
@@ -722,8 +806,13 @@ extern "C" int ro_stft_fetch(ro_stft_t *h, int64_t max_rows, int first_col, int 
 extern "C" int ro_stft_reset(ro_stft_t *h)
 {
     if (!h) return fail(RO_ERR_INVALID, "null handle");
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->staged.clear();
-    h->ready.clear();
+    h->staged_begin = 0;
+    while (!h->ready.empty()) {
+        release_batch(h, h->ready.front());
+        h->ready.pop_front();
+    }
     h->stream_sample0 = 0;
     h->rows_emitted = 0;
     h->rows_ready = 0;
