@@ -7,7 +7,7 @@
 
 namespace ro {
 
-BolidRecorder::BolidRecorder(HipWaterfallBackend *backend, const BolidConfig &cfg) : Recorder(backend), cfg_(cfg)
+BolidRecorder::BolidRecorder(WaterfallBase *backend, const BolidConfig &cfg) : Recorder(backend), cfg_(cfg)
 {
     minDetectFq_ = std::min(cfg.low_detect_freq, cfg.hi_detect_freq);        // ORDER_PAIR, BolidRecorder.h:161
     maxDetectFq_ = std::max(cfg.low_detect_freq, cfg.hi_detect_freq);

@@ -39,7 +39,7 @@ class BolidRecorder : public Recorder {
 public:
     enum State { STATE_INIT, STATE_BOLID, STATE_BOLID_ENDED };
 
-    BolidRecorder(HipWaterfallBackend *backend, const BolidConfig &cfg);
+    BolidRecorder(WaterfallBase *backend, const BolidConfig &cfg);
 
     int  requestBufferSize() override;       // SnapshotRecorder::requestBufferSize, WaterfallBackend.cpp:339-347
     void start() override;

@@ -12,40 +12,30 @@ static int wrapIndex(int value, int size)            // src/utils.cpp:12-18
     return value % size;
 }
 
-int Recorder::getSampleRate() const { return backend_->getStreamInfo().sampleRate; }
+int Recorder::getSampleRate() const { return backend_->streamInfo().sampleRate; }
 int Recorder::getFFTSampleRate() const { return (int)backend_->getFFTSampleRate(); }
 int Recorder::fftMarkToRaw(int mark) const { return (*rawHandles_)[wrapIndex(mark, (int)rawHandles_->size())].mark; }
 WFTime Recorder::fftMarkToTime(int mark) const { return (*rawHandles_)[wrapIndex(mark, (int)rawHandles_->size())].time; }
 
-HipWaterfallBackend::HipWaterfallBackend(const WaterfallConfig &cfg) : cfg_(cfg)
+WaterfallBase::WaterfallBase(const WaterfallConfig &cfg) : cfg_(cfg)
 {
     bins_ = cfg.bins;
     overlap_ = ro_clamp_overlap(cfg.bins, cfg.overlap);          // src/FFTBackend.cpp:108-109
     hop_ = bins_ - overlap_;
 }
 
-HipWaterfallBackend::~HipWaterfallBackend()
-{
-    if (stft_) ro_stft_destroy(stft_);
-}
-
-void HipWaterfallBackend::addRecorder(Recorder *recorder)
+void WaterfallBase::addRecorder(Recorder *recorder)
 {
     recorders_.push_back(recorder);
     recorder->setBuffer(&buffer_, &rawHandles_);
 }
 
-void HipWaterfallBackend::startStream(StreamInfo info)
+bool WaterfallBase::beginStream(const StreamInfo &info, ro_bands_t *bands)
 {
-    Backend::startStream(info);
+    info_ = info;
     fftSampleRate_ = ro_fft_sample_rate(info.sampleRate, bins_, overlap_);     // FFTBackend.cpp:150-151
-    samplesIn_ = 0;
-    inMark_ = 0;
-    nextStampRow_ = 0;
-    rowTimes_.clear();
     rowsDelivered_ = 0;
     rowLog_.clear();
-
     // src/WaterfallBackend.cpp:577-588
     int bufferSize = 1;
     for (Recorder *r : recorders_) bufferSize = std::max(bufferSize, r->requestBufferSize());
@@ -57,11 +47,49 @@ void HipWaterfallBackend::startStream(StreamInfo info)
         rawCapacity_ = std::max(1, (want / chunkRows + (want % chunkRows ? 1 : 0)) * chunkRows);
     }
     for (Recorder *r : recorders_) r->start();                                   // :591-593
+    bool any = false;
+    for (Recorder *r : recorders_)
+        if (!any && r->scanBands(bands)) any = true;
+    return any;
+}
+
+void WaterfallBase::finishStream()
+{
+    for (Recorder *r : recorders_) r->stop();                                    // :604-606
+}
+
+// WaterfallBackend::processFFT minus the arithmetic (src/WaterfallBackend.cpp:485-541)
+void WaterfallBase::processRow(const float *row, const ro_scan_record_t *scan, DataInfo info, int rawMark)
+{
+    float *dst = buffer_.push();                                                 // :488
+    std::memcpy(dst, row, sizeof(float) * (size_t)bins_);
+    rawHandles_[buffer_.mark()] = RawDataHandle(rawMark, info.timeOffset);       // :507 (one slot ahead)
+    if (scan) currentScan_ = *scan;
+    rowsDelivered_++;
+    if (keepLog_) rowLog_.push_back(RowInfo{info.offset, info.timeOffset, rawMark});
+    for (Recorder *r : recorders_) r->update();                                  // :534-536
+}
+
+HipWaterfallBackend::HipWaterfallBackend(const WaterfallConfig &cfg) : WaterfallBase(cfg) {}
+
+HipWaterfallBackend::~HipWaterfallBackend()
+{
+    if (stft_) ro_stft_destroy(stft_);
+}
+
+void HipWaterfallBackend::startStream(StreamInfo info)
+{
+    Backend::startStream(info);
+    samplesIn_ = 0;
+    inMark_ = 0;
+    nextStampRow_ = 0;
+    rowTimes_.clear();
 
     // the device side: one ro_stft handle per stream; scan bands from whichever recorder wants them
     if (stft_) { ro_stft_destroy(stft_); stft_ = nullptr; }
     ro_stft_config_t c;
     std::memset(&c, 0, sizeof(c));
+    scanEnabled_ = beginStream(info, &c.bands);
     c.struct_size = sizeof(c);
     c.bins = bins_;
     c.overlap = overlap_;
@@ -71,9 +99,7 @@ void HipWaterfallBackend::startStream(StreamInfo info)
     c.iq_phase_shift = cfg_.iq_phase_shift;
     c.device = cfg_.device;
     c.max_batch_rows = cfg_.max_batch_rows;
-    scanEnabled_ = false;
-    for (Recorder *r : recorders_)
-        if (!scanEnabled_ && r->scanBands(&c.bands)) { c.enable_scan = 1; scanEnabled_ = true; }
+    c.enable_scan = scanEnabled_ ? 1 : 0;
     if (ro_stft_create(&c, &stft_) != RO_OK) {
         // the reference logs and carries on (LOG_ERROR + return); so does this: no rows will come
         lastError_ = ro_last_error();
@@ -90,7 +116,7 @@ void HipWaterfallBackend::stampRowStarts(int64_t takeBegin, int64_t takeEnd, con
 {
     while (nextStampRow_ * (int64_t)hop_ < takeEnd) {
         const int64_t s = nextStampRow_ * (int64_t)hop_;
-        if (s >= takeBegin) rowTimes_.push_back(t.addSamples((SampleCount)(s - takeBegin), streamInfo_.sampleRate));
+        if (s >= takeBegin) rowTimes_.push_back(t.addSamples((SampleCount)(s - takeBegin), info_.sampleRate));
         nextStampRow_++;
     }
 }
@@ -109,7 +135,7 @@ void HipWaterfallBackend::process(const std::vector<Complex> &data, DataInfo inf
             inMark_ = overlap_;
             size -= count;
             pos += count;
-            timeOffset = timeOffset.addSamples((SampleCount)count, streamInfo_.sampleRate);
+            timeOffset = timeOffset.addSamples((SampleCount)count, info_.sampleRate);
         }
         if (size > 0) {
             stampRowStarts(pos, pos + size, timeOffset);
@@ -131,7 +157,7 @@ void HipWaterfallBackend::endStream()
 {
     Backend::endStream();
     if (stft_) drain(true);
-    for (Recorder *r : recorders_) r->stop();                                    // :604-606
+    finishStream();
 }
 
 // Hand finished rows to the recorders in stream order.  `flush` runs the kernels on every
@@ -168,18 +194,6 @@ void HipWaterfallBackend::drain(bool flush)
             processRow(&fetchRows_[(size_t)i * bins_], scanEnabled_ ? &fetchRecs_[(size_t)i] : nullptr, di, rawMark);
         }
     }
-}
-
-// WaterfallBackend::processFFT minus the arithmetic (src/WaterfallBackend.cpp:485-541)
-void HipWaterfallBackend::processRow(const float *row, const ro_scan_record_t *scan, DataInfo info, int rawMark)
-{
-    float *dst = buffer_.push();                                                 // :488
-    std::memcpy(dst, row, sizeof(float) * (size_t)bins_);
-    rawHandles_[buffer_.mark()] = RawDataHandle(rawMark, info.timeOffset);       // :507 (one slot ahead)
-    if (scan) currentScan_ = *scan;
-    rowsDelivered_++;
-    if (keepLog_) rowLog_.push_back(RowInfo{info.offset, info.timeOffset, rawMark});
-    for (Recorder *r : recorders_) r->update();                                  // :534-536
 }
 
 }  // namespace ro

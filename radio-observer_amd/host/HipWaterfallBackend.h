@@ -26,12 +26,12 @@ struct RawDataHandle {                       // src/FFTBackend.h:43-49
     RawDataHandle(int m, WFTime t) : mark(m), time(t) {}
 };
 
-class HipWaterfallBackend;
+class WaterfallBase;
 
 // src/WaterfallBackend.h:42-103
 class Recorder {
 public:
-    explicit Recorder(HipWaterfallBackend *backend) : backend_(backend) {}
+    explicit Recorder(WaterfallBase *backend) : backend_(backend) {}
     virtual ~Recorder() {}
     void setBuffer(RingBuffer2D<float> *buffer, std::vector<RawDataHandle> *rawHandles)
     {
@@ -54,7 +54,7 @@ public:
     virtual bool scanBands(ro_bands_t *) const { return false; }
 
 protected:
-    HipWaterfallBackend        *backend_;
+    WaterfallBase              *backend_;
     RingBuffer2D<float>        *buffer_ = nullptr;
     std::vector<RawDataHandle> *rawHandles_ = nullptr;
 };
@@ -73,31 +73,33 @@ struct WaterfallConfig {
     int         max_batch_rows = 0;          // rows per kernel launch; small = low latency
 };
 
-class HipWaterfallBackend : public Backend {
+// Everything WaterfallBackend is to its recorders (src/WaterfallBackend.h:239-290 and the FFTBackend
+// accessors they call, src/FFTBackend.h:110-200): the row ring, the raw handles, the bin/Hz/time
+// helpers, and the per-row delivery of src/WaterfallBackend.cpp:485-541 minus the arithmetic.  The HIP
+// backend feeds it from the GPU; ManualWaterfall lets host-only tests feed rows by hand.
+class WaterfallBase {
 public:
-    explicit HipWaterfallBackend(const WaterfallConfig &cfg);
-    ~HipWaterfallBackend() override;
+    explicit WaterfallBase(const WaterfallConfig &cfg);
+    virtual ~WaterfallBase() {}
 
     // ---- FFTBackend's public surface (src/FFTBackend.h:110-200)
     int   getBins() const { return bins_; }
     float getFFTSampleRate() const { return fftSampleRate_; }
     SampleType getGain() const { return cfg_.iq_gain; }
-    float binToFrequency(int bin) const { return ro_bin_to_frequency(bins_, streamInfo_.sampleRate, bin); }
+    StreamInfo streamInfo() const { return info_; }
+    float binToFrequency(int bin) const { return ro_bin_to_frequency(bins_, info_.sampleRate, bin); }
     float binToFrequency() const { return binToFrequency(1) - binToFrequency(0); }
-    int   frequencyToBin(float f) const { return ro_frequency_to_bin(bins_, streamInfo_.sampleRate, f); }
+    int   frequencyToBin(float f) const { return ro_frequency_to_bin(bins_, info_.sampleRate, f); }
     double fftSamplesToTime(int samples) const { return (double)samples / (double)fftSampleRate_; }
     int   timeToFFTSamples(double t) const { return ro_time_to_fft_samples(t, fftSampleRate_); }
     int   fftSamplesToRaw(int sampleCount) const                     // src/WaterfallBackend.h:283-287
     {
-        return (int)(((double)sampleCount / (double)fftSampleRate_) * (double)streamInfo_.sampleRate);
+        return (int)(((double)sampleCount / (double)fftSampleRate_) * (double)info_.sampleRate);
     }
     std::string getOrigin() const { return cfg_.origin; }
+    const WaterfallConfig &config() const { return cfg_; }
 
     void addRecorder(Recorder *recorder);                            // src/WaterfallBackend.cpp:563-567
-
-    void startStream(StreamInfo info) override;                      // :573-594 + FFTBackend.cpp:144-189
-    void process(const std::vector<Complex> &data, DataInfo info) override;
-    void endStream() override;                                       // :600-607
 
     // ---- what the row being delivered looks like (valid inside Recorder::update())
     const ro_scan_record_t &currentScan() const { return currentScan_; }
@@ -109,43 +111,75 @@ public:
     const std::vector<RawDataHandle> &rawHandles() const { return rawHandles_; }
     int64_t rowsDelivered() const { return rowsDelivered_; }
     int rawCapacity() const { return rawCapacity_; }
-    const std::string &lastError() const { return lastError_; }
     struct RowInfo { uint64_t offset; WFTime time; int rawMark; };
     const std::vector<RowInfo> &rowLog() const { return rowLog_; }
     void keepRowLog(bool on) { keepLog_ = on; }
 
 protected:
-    // the reference's hook (src/FFTBackend.h:104) sees complex spectra; this backend hands
-    // over the finished magnitude row instead (the spectrum never leaves the GPU).
+    // src/WaterfallBackend.cpp:573-594 (ring sizing, recorders' start()); returns the scan bands a
+    // recorder asked for through *bands (true if any)
+    bool beginStream(const StreamInfo &info, ro_bands_t *bands);
+    void finishStream();                                             // :600-607
+    // the reference's hook (src/FFTBackend.h:104) sees complex spectra; here the finished magnitude row
+    // is handed over instead (the spectrum never leaves the GPU)
     virtual void processRow(const float *row, const ro_scan_record_t *scan, DataInfo info, int rawMark);
+
+    WaterfallConfig cfg_;
+    StreamInfo info_;
+    int   bins_, overlap_, hop_;
+    float fftSampleRate_ = 0.f;
+    bool  scanEnabled_ = false;
+
+    RingBuffer2D<float>        buffer_;
+    std::vector<RawDataHandle> rawHandles_;
+    std::vector<Recorder *>    recorders_;
+    int     rawCapacity_ = 1;
+    int64_t rowsDelivered_ = 0;
+    ro_scan_record_t currentScan_{};
+    std::vector<RowInfo> rowLog_;
+    bool keepLog_ = false;
+};
+
+// host-only source: rows (and scan records) are pushed by the caller.  Used by the CPU tests of the
+// recorders; never part of a data path.
+class ManualWaterfall : public WaterfallBase {
+public:
+    explicit ManualWaterfall(const WaterfallConfig &cfg) : WaterfallBase(cfg) {}
+    void startStream(const StreamInfo &info) { ro_bands_t b; scanEnabled_ = beginStream(info, &b); }
+    void pushRow(const float *row, const ro_scan_record_t *scan, WFTime time, int rawMark)
+    {
+        DataInfo di;
+        di.offset = (SampleCount)rowsDelivered_;
+        di.timeOffset = time;
+        processRow(row, scan, di, rawMark);
+    }
+    void endStream() { finishStream(); }
+};
+
+class HipWaterfallBackend : public Backend, public WaterfallBase {
+public:
+    explicit HipWaterfallBackend(const WaterfallConfig &cfg);
+    ~HipWaterfallBackend() override;
+
+    void startStream(StreamInfo info) override;                      // :573-594 + FFTBackend.cpp:144-189
+    void process(const std::vector<Complex> &data, DataInfo info) override;
+    void endStream() override;                                       // :600-607
+    const std::string &lastError() const { return lastError_; }
 
 private:
     void drain(bool flush);
     void stampRowStarts(int64_t takeBegin, int64_t takeEnd, const WFTime &t);
 
-    WaterfallConfig cfg_;
-    int   bins_, overlap_, hop_;
-    float fftSampleRate_ = 0.f;
     ro_stft_t *stft_ = nullptr;
-    bool  scanEnabled_ = false;
     std::string lastError_;
-
-    RingBuffer2D<float>        buffer_;
-    std::vector<RawDataHandle> rawHandles_;
-    std::vector<Recorder *>    recorders_;
 
     // framing bookkeeping that stays on the host (timestamps, raw marks: O(1) per row)
     int64_t samplesIn_ = 0;          // samples received so far
     int     inMark_ = 0;             // samples held towards the next row (inMark_ - window_)
     int64_t nextStampRow_ = 0;       // next row whose first-sample time is still unknown
     std::deque<WFTime> rowTimes_;    // time of the first sample of rows not yet delivered
-    int     rawCapacity_ = 1;
-    int64_t rowsDelivered_ = 0;
-    ro_scan_record_t currentScan_{};
     std::vector<float> fetchRows_;
     std::vector<ro_scan_record_t> fetchRecs_;
-    std::vector<RowInfo> rowLog_;
-    bool keepLog_ = false;
 };
 
 }  // namespace ro

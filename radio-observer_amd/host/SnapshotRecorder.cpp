@@ -1,0 +1,137 @@
+#include "SnapshotRecorder.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <ctime>
+
+#include "FITSWriter.h"
+
+namespace ro {
+
+static std::string formatTime(const WFTime &t, const char *fmt)       // src/WFTime.cpp:19-34 (UTC)
+{
+    std::time_t s = (std::time_t)t.sec;
+    char buf[256];
+    const size_t n = std::strftime(buf, sizeof(buf), fmt, std::gmtime(&s));
+    return std::string(buf, n);
+}
+
+static std::string joinPath(const std::string &a, const std::string &b)
+{
+    if (a.empty()) return b;
+    if (a.back() == '/') return a + b;
+    return a + "/" + b;
+}
+
+SnapshotRecorder::SnapshotRecorder(WaterfallBase *backend, const SnapshotConfig &cfg) : Recorder(backend), cfg_(cfg)
+{
+    leftFrequency_ = std::min(cfg.low_freq, cfg.hi_freq);            // ORDER_PAIR, WaterfallBackend.h:205
+    rightFrequency_ = std::max(cfg.low_freq, cfg.hi_freq);
+}
+
+int SnapshotRecorder::requestBufferSize()
+{
+    const float rate = backend_->getFFTSampleRate();
+    snapshotRows_ = (int)std::ceil(cfg_.snapshot_length * rate);
+    if (snapshotRows_ < 1) snapshotRows_ = 1;
+    return snapshotRows_ * 8;
+}
+
+void SnapshotRecorder::start()
+{
+    if (leftFrequency_ == rightFrequency_) {                          // :368-374
+        const StreamInfo info = backend_->streamInfo();
+        leftFrequency_ = -(float)info.sampleRate / 2.0f;
+        rightFrequency_ = (float)info.sampleRate / 2.0f;
+        leftBin_ = 0;
+        rightBin_ = backend_->getBins();
+    } else {
+        leftBin_ = backend_->frequencyToBin(leftFrequency_);
+        rightBin_ = backend_->frequencyToBin(rightFrequency_);
+    }
+    nextSnapshot_ = Snapshot();
+    nextSnapshot_.fileName = getFileName(fftMarkToTime(nextSnapshot_.start));   // :394-395 (epoch-zero name on
+    pending_.clear();                                                            //  the first file: App. B-4)
+    queued_.clear();
+    written_.clear();
+}
+
+std::string SnapshotRecorder::getFileName(WFTime time) const
+{
+    char name[1024];
+    std::snprintf(name, sizeof(name), "%s%03d_%s_%s.%s", formatTime(time, "%Y%m%d%H%M%S").c_str(),
+                  (int)(time.usec / 1000), backend_->getOrigin().c_str(), cfg_.output_type.c_str(), "fits");
+    return joinPath(cfg_.output_dir, name);                           // :332-335 (the directory is joined twice
+}                                                                     //  in the reference's write(); once here)
+
+void SnapshotRecorder::startWriting()
+{
+    if (nextSnapshot_.length == 0) nextSnapshot_.length = buffer_->size(nextSnapshot_.start);      // :111-112
+    if (snapshotRows_ < nextSnapshot_.length) nextSnapshot_.length = snapshotRows_;                // :113-114
+    const int end = nextSnapshot_.start + nextSnapshot_.length;
+    nextSnapshot_.reservation = buffer_->reserve(nextSnapshot_.start, end);                         // :117
+    pending_.push_back(nextSnapshot_);                                                              // :120
+    queued_.push_back(nextSnapshot_);
+    nextSnapshot_ = Snapshot();
+    nextSnapshot_.start = end;                                                                      // :122
+    nextSnapshot_.fileName = getFileName(fftMarkToTime(nextSnapshot_.start));                       // :125
+    drainPending(false);
+}
+
+// the worker's loop body (:60-104): write what is complete, keep the rest for later
+void SnapshotRecorder::drainPending(bool final)
+{
+    std::vector<Snapshot> keep;
+    for (const Snapshot &s : pending_) {
+        if (buffer_->size(s.start) >= s.length) {
+            write(s);
+            buffer_->freeReservation(s.reservation);
+        } else if (!final) {
+            keep.push_back(s);
+        }
+    }
+    pending_.swap(keep);
+}
+
+void SnapshotRecorder::update()
+{
+    if (buffer_->size(nextSnapshot_.start) >= snapshotRows_ + 2) startWriting();                   // :417-426
+    else if (!pending_.empty()) drainPending(false);
+}
+
+void SnapshotRecorder::stop()
+{
+    if (buffer_->size(nextSnapshot_.start) >= 0 && writeUnfinished_) startWriting();               // :402-403
+    drainPending(true);
+}
+
+bool SnapshotRecorder::write(const Snapshot &s)
+{
+    const WFTime time = fftMarkToTime(s.start);                       // :143
+    const float fftSampleRate = backend_->getFFTSampleRate();
+    FITSWriter w;
+    if (!w.open("!" + s.fileName)) return false;
+    const int width = rightBin_ - leftBin_;
+    w.createImage(width, s.length);
+    w.comment("File created by radio-observer_amd (MI355X STFT path).");       // :130-135 writeHeader()
+    w.comment("See https://github.com/MLAB-project/radio-observer.");
+    w.writeHeader("ORIGIN", backend_->getOrigin().c_str(), "");
+    w.date();
+    w.writeHeader("DATE-OBS", formatTime(time, "%Y-%m-%dT%H:%M:%S").c_str(), "observation date (UTC)");
+    w.writeHeader("CTYPE2", "TIME", "in seconds");
+    w.writeHeader("CRPIX2", 1, "");
+    w.writeHeader("CRVAL2", (long long)time.toMilliseconds(), "unix time of the first FFT row in this file in ms");
+    w.writeHeader("CDELT2", 1000.0 / (double)fftSampleRate, "time difference between two FFT samples in ms");
+    w.writeHeader("CTYPE1", "FREQ", "in Hz");
+    w.writeHeader("CRPIX1", 1.f, "");
+    w.writeHeader("CRVAL1", (float)leftFrequency_, "frequency, in Hz, of the leftmost pixel in the image");
+    w.writeHeader("CDELT1", (float)backend_->binToFrequency(), "frequency difference between two neighbouring pixels in Hz");
+    int rowIndex = s.start;
+    for (int y = 0; y < s.length; ++y, ++rowIndex) w.write(y, 1, buffer_->at(rowIndex) + leftBin_);   // :203-205
+    const bool ok = w.close();
+    if (ok) written_.push_back(s.fileName);
+    return ok;
+}
+
+}  // namespace ro

@@ -3,9 +3,13 @@
 #include <cstring>
 #include <vector>
 
+#include <sstream>
+
 #include "BolidRecorder.h"
+#include "Frontends.h"
 #include "HipWaterfallBackend.h"
 #include "RingBuffer.h"
+#include "SnapshotRecorder.h"
 
 using namespace ro;
 
@@ -31,13 +35,16 @@ int ro_host_ring_reserve(void *r, int s, int e) { return RING(r)->reserve(s, e);
 int ro_host_ring_free_reservation(void *r, int h) { return RING(r)->freeReservation(h) ? 1 : 0; }
 int ro_host_ring_is_dirty(void *r, int h) { return RING(r)->isDirty(h) ? 1 : 0; }
 
-// ---- Frontend -> HipWaterfallBackend -> BolidRecorder
+// ---- Frontend -> HipWaterfallBackend -> {SnapshotRecorder, BolidRecorder}
 struct Pipeline {
     HipWaterfallBackend backend;
+    SnapshotRecorder snap;
     BolidRecorder bolid;
     FrontendDriver frontend;
-    Pipeline(const WaterfallConfig &w, const BolidConfig &b) : backend(w), bolid(&backend, b), frontend(&backend)
+    Pipeline(const WaterfallConfig &w, const BolidConfig &b, const SnapshotConfig &sc, bool with_snapshot)
+        : backend(w), snap(&backend, sc), bolid(&backend, b), frontend(&backend)
     {
+        if (with_snapshot) backend.addRecorder(&snap);       // same order as radio-observer.json:52-88
         backend.addRecorder(&bolid);
         backend.keepRowLog(true);
     }
@@ -60,12 +67,45 @@ void *ro_host_pipeline_create(int bins, int overlap, int sample_rate, int64_t st
     b.advance_time = advance_time;
     b.jitter_time = jitter_time;
     b.avg_freq_range = avg_range;
-    Pipeline *p = new Pipeline(w, b);
+    Pipeline *p = new Pipeline(w, b, SnapshotConfig(), false);
     StreamInfo si;
     si.sampleRate = sample_rate;
     si.timeOffset = WFTime(start_sec, start_usec);
     p->frontend.startStream(si);
     return p;
+}
+// same, plus a SnapshotRecorder writing FITS files of [lo_snap, hi_snap) Hz every snapshot_length seconds
+void *ro_host_pipeline_create_snap(int bins, int overlap, int sample_rate, int64_t start_sec, int64_t start_usec,
+                                   int max_batch_rows, int snapshot_length, float lo_snap, float hi_snap,
+                                   const char *out_dir, const char *origin)
+{
+    WaterfallConfig w;
+    w.bins = bins;
+    w.overlap = overlap;
+    w.max_batch_rows = max_batch_rows;
+    w.origin = origin;
+    SnapshotConfig sc;
+    sc.output_dir = out_dir;
+    sc.snapshot_length = snapshot_length;
+    sc.low_freq = lo_snap;
+    sc.hi_freq = hi_snap;
+    BolidConfig b;
+    b.snapshot_length = snapshot_length;
+    b.low_detect_freq = 10300; b.hi_detect_freq = 10900; b.low_noise_freq = 9000; b.hi_noise_freq = 9600;
+    b.advance_time = 2; b.jitter_time = 5;
+    Pipeline *p = new Pipeline(w, b, sc, true);
+    StreamInfo si;
+    si.sampleRate = sample_rate;
+    si.timeOffset = WFTime(start_sec, start_usec);
+    p->frontend.startStream(si);
+    return p;
+}
+int ro_host_pipeline_files(void *p, char *buf, int len)
+{
+    std::string all;
+    for (const auto &f : static_cast<Pipeline *>(p)->snap.filesWritten()) all += f + "\n";
+    std::snprintf(buf, (size_t)len, "%s", all.c_str());
+    return (int)static_cast<Pipeline *>(p)->snap.filesWritten().size();
 }
 void ro_host_pipeline_destroy(void *p) { delete static_cast<Pipeline *>(p); }
 #define PIPE(p) static_cast<Pipeline *>(p)
@@ -119,5 +159,180 @@ int ro_host_pipeline_events(void *p, BolidEvent *out, int max)
     return (int)ev.size();
 }
 int ro_host_pipeline_state(void *p) { return (int)PIPE(p)->bolid.state(); }
+
+
+// ---- frontends against a recording backend (no GPU): what exactly does Backend::process() receive?
+struct RecordingBackend : public Backend {
+    std::vector<int> callSizes;
+    std::vector<DataInfo> infos;
+    std::vector<Complex> samples;
+    int started = 0, ended = 0;
+    void startStream(StreamInfo info) override { Backend::startStream(info); started++; }
+    void process(const std::vector<Complex> &data, DataInfo info) override
+    {
+        callSizes.push_back((int)data.size());
+        infos.push_back(info);
+        samples.insert(samples.end(), data.begin(), data.end());
+    }
+    void endStream() override { ended++; }
+};
+
+struct FrontendRun {
+    RecordingBackend backend;
+    WAVFormat format;
+    std::string error, inf1;
+    bool ok = false;
+};
+
+// kind 0: WAVStream over `bytes`; kind 1: RawStream (float32 I,Q) at `sample_rate`
+void *ro_host_frontend_run(int kind, const char *bytes, int64_t n, int sample_rate, int64_t start_sec,
+                           int64_t start_usec)
+{
+    FrontendRun *r = new FrontendRun();
+    std::istringstream in(std::string(bytes, (size_t)n));
+    if (kind == 0) {
+        WAVStream w(in, &r->backend);
+        r->ok = w.run();
+        r->format = w.format();
+        r->error = w.lastError();
+        r->inf1 = w.inf1();
+    } else {
+        RawStream w(in, &r->backend, sample_rate, WFTime(start_sec, start_usec));
+        w.run();
+        r->ok = true;
+    }
+    return r;
+}
+void ro_host_frontend_free(void *r) { delete static_cast<FrontendRun *>(r); }
+#define FR(r) static_cast<FrontendRun *>(r)
+int ro_host_frontend_ok(void *r) { return FR(r)->ok ? 1 : 0; }
+const char *ro_host_frontend_error(void *r) { return FR(r)->error.c_str(); }
+const char *ro_host_frontend_inf1(void *r) { return FR(r)->inf1.c_str(); }
+int ro_host_frontend_calls(void *r) { return (int)FR(r)->backend.callSizes.size(); }
+int ro_host_frontend_started(void *r) { return FR(r)->backend.started * 10 + FR(r)->backend.ended; }
+int ro_host_frontend_sample_rate(void *r) { return FR(r)->backend.getStreamInfo().sampleRate; }
+void ro_host_frontend_format(void *r, int *out6)
+{
+    const WAVFormat &f = FR(r)->format;
+    out6[0] = f.audioFormat; out6[1] = f.channelCount; out6[2] = f.sampleRate; out6[3] = f.byteRate;
+    out6[4] = f.blockAlign; out6[5] = f.bitsPerSample;
+}
+int ro_host_frontend_call(void *r, int i, uint64_t *offset, int64_t *sec, int64_t *usec)
+{
+    *offset = FR(r)->backend.infos[(size_t)i].offset;
+    *sec = FR(r)->backend.infos[(size_t)i].timeOffset.sec;
+    *usec = FR(r)->backend.infos[(size_t)i].timeOffset.usec;
+    return FR(r)->backend.callSizes[(size_t)i];
+}
+int64_t ro_host_frontend_samples(void *r, double *out, int64_t max)
+{
+    const auto &s = FR(r)->backend.samples;
+    const int64_t n = std::min<int64_t>((int64_t)s.size(), max);
+    if (out) std::memcpy(out, s.data(), sizeof(Complex) * (size_t)n);
+    return (int64_t)s.size();
+}
+
+// ---- C1 end to end: WAV bytes -> WAVStream -> HipWaterfallBackend (GPU) -> SnapshotRecorder -> FITS files
+int64_t ro_host_wav_to_fits(const char *bytes, int64_t n, int bins, int overlap, int max_batch_rows,
+                            int snapshot_length, float lo, float hi, const char *out_dir, const char *origin,
+                            char *files, int files_len, char *err, int err_len)
+{
+    WaterfallConfig w;
+    w.bins = bins;
+    w.overlap = overlap;
+    w.max_batch_rows = max_batch_rows;
+    w.origin = origin;
+    SnapshotConfig sc;
+    sc.output_dir = out_dir;
+    sc.snapshot_length = snapshot_length;
+    sc.low_freq = lo;
+    sc.hi_freq = hi;
+    HipWaterfallBackend backend(w);
+    SnapshotRecorder snap(&backend, sc);
+    backend.addRecorder(&snap);
+    std::istringstream in(std::string(bytes, (size_t)n));
+    WAVStream wav(in, &backend);
+    const bool ok = wav.run();
+    std::string all;
+    for (const auto &f : snap.filesWritten()) all += f + "\n";
+    std::snprintf(files, (size_t)files_len, "%s", all.c_str());
+    std::snprintf(err, (size_t)err_len, "%s%s", ok ? "" : wav.lastError().c_str(), backend.lastError().c_str());
+    return backend.rowsDelivered();
+}
+
+// ---- recorders on hand-fed rows (no GPU): cadence, FITS files, detector
+struct ManualRig {
+    ManualWaterfall source;
+    SnapshotRecorder snap;
+    BolidRecorder bolid;
+    ManualRig(const WaterfallConfig &w, const SnapshotConfig &s, const BolidConfig &b)
+        : source(w), snap(&source, s), bolid(&source, b)
+    {
+        source.addRecorder(&snap);
+        source.addRecorder(&bolid);
+    }
+};
+void *ro_host_manual_create(int bins, int overlap, int sample_rate, int snapshot_length, float lo_snap, float hi_snap,
+                            const char *out_dir, const char *origin, double advance_time, double jitter_time)
+{
+    WaterfallConfig w;
+    w.bins = bins;
+    w.overlap = overlap;
+    w.origin = origin;
+    SnapshotConfig sc;
+    sc.output_dir = out_dir;
+    sc.snapshot_length = snapshot_length;
+    sc.low_freq = lo_snap;
+    sc.hi_freq = hi_snap;
+    BolidConfig b;
+    b.snapshot_length = snapshot_length;
+    b.low_detect_freq = 10300; b.hi_detect_freq = 10900; b.low_noise_freq = 9000; b.hi_noise_freq = 9600;
+    b.advance_time = advance_time; b.jitter_time = jitter_time;
+    ManualRig *m = new ManualRig(w, sc, b);
+    StreamInfo si;
+    si.sampleRate = sample_rate;
+    m->source.startStream(si);
+    return m;
+}
+#define RIG(m) static_cast<ManualRig *>(m)
+void ro_host_manual_destroy(void *m) { delete RIG(m); }
+void ro_host_manual_push(void *m, const float *row, float n, int p, float a, int64_t sec, int64_t usec, int raw_mark)
+{
+    ro_scan_record_t s{n, p, a};
+    RIG(m)->source.pushRow(row, &s, WFTime(sec, usec), raw_mark);
+}
+void ro_host_manual_end(void *m) { RIG(m)->source.endStream(); }
+int ro_host_manual_info(void *m, int *out6)
+{
+    out6[0] = RIG(m)->source.buffer().getCapacity();
+    out6[1] = RIG(m)->snap.snapshotRows();
+    out6[2] = RIG(m)->snap.leftBin();
+    out6[3] = RIG(m)->snap.rightBin();
+    out6[4] = (int)RIG(m)->snap.snapshotsQueued().size();
+    out6[5] = (int)RIG(m)->bolid.state();
+    return 0;
+}
+int ro_host_manual_files(void *m, char *buf, int len)
+{
+    std::string all;
+    for (const auto &f : RIG(m)->snap.filesWritten()) all += f + "\n";
+    std::snprintf(buf, (size_t)len, "%s", all.c_str());
+    return (int)RIG(m)->snap.filesWritten().size();
+}
+int ro_host_manual_snapshot(void *m, int i, int *start, int *length)
+{
+    const auto &q = RIG(m)->snap.snapshotsQueued();
+    if (i < 0 || i >= (int)q.size()) return -1;
+    *start = q[(size_t)i].start;
+    *length = q[(size_t)i].length;
+    return 0;
+}
+int ro_host_manual_events(void *m, BolidEvent *out, int max)
+{
+    const auto &ev = RIG(m)->bolid.events();
+    const int n = (int)std::min<size_t>(ev.size(), (size_t)max);
+    for (int i = 0; i < n; ++i) out[i] = ev[(size_t)i];
+    return (int)ev.size();
+}
 
 }  // extern "C"

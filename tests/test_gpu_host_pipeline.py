@@ -111,3 +111,39 @@ def test_backend_without_scan_recorder_still_delivers_rows(oracle):
     got = np.stack([p.ring_row(p.ring_mark() - 11 + i) for i in range(11)])
     assert rel_to_row_max(got, want) <= 1e-5
     p.close()
+
+
+def test_c1_wav_to_fits_end_to_end(oracle, tmp_path):
+    """BASELINE config 1 (with the 2-channel stand-in for the reference's unreadable mono case, SURVEY.md
+    §0-9): 16-bit I/Q WAV at 48 kHz -> WAVStream -> FFT bins 1024 / overlap 512 on the GPU ->
+    SnapshotRecorder -> FITS; the image must equal the oracle's rows over [low_freq, hi_freq)."""
+    import ctypes as C
+    from test_host_cpu import read_fits, wav_bytes
+    L = host_library()
+    L.ro_host_wav_to_fits.restype = C.c_int64
+    L.ro_host_wav_to_fits.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                      C.c_float, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+    rng = np.random.default_rng(0xC1)
+    frames = 1024 * 200                                           # a multiple of 1024 frames (SURVEY.md §0-9)
+    f = add_tone(noise_iq(rng, frames, 300.0), 10400.0, 8000.0)
+    i16 = np.clip(np.rint(f), -32768, 32767).astype(np.int16)
+    payload = wav_bytes(i16, rate=48000)
+    files, err = C.create_string_buffer(16384), C.create_string_buffer(1024)
+    rows = L.ro_host_wav_to_fits(payload, len(payload), 1024, 512, 16, 1, 9000.0, 12000.0, str(tmp_path).encode(),
+                                 b"c1test", files, 16384, err, 1024)
+    assert err.value == b"", err.value
+    want = oracle.stft(i16.astype(np.float64), 1024, 512)
+    assert rows == want.shape[0] == (frames - 1024) // 512 + 1
+    names = files.value.decode().split()
+    lo = oracle.lib().ro_oracle_frequency_to_bin(1024, 48000, 9000.0)
+    hi = oracle.lib().ro_oracle_frequency_to_bin(1024, 48000, 12000.0)
+    snap_rows = int(np.ceil(1 * 93.75))                           # 94 rows per one-second snapshot
+    assert len(names) == int(np.ceil(rows / snap_rows))
+    got = np.concatenate([read_fits(n)[1] for n in names])
+    assert got.shape == (rows, hi - lo)
+    ref = want[:, lo:hi]
+    assert np.abs(got - ref).max() <= 1e-5 * want.max()
+    hdr = read_fits(names[1])[0]
+    assert float(hdr["CRVAL1"]) == 9000.0 and abs(float(hdr["CDELT2"]) - 1000.0 / 93.75) < 1e-9
+    # the tone sits where frequencyToBin puts it
+    assert abs(int(want[5].argmax()) - oracle.lib().ro_oracle_frequency_to_bin(1024, 48000, 10400.0)) <= 1

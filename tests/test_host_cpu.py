@@ -1,0 +1,274 @@
+"""CPU tests of the host-side mirror (radio-observer_amd/host): frontends, FITS writer, snapshot cadence and
+the detector's state machine on hand-fed rows.  No GPU: rows and scan records are supplied by the test."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from hostlib import BolidEvent, host_library
+
+
+@pytest.fixture(scope="module")
+def H():
+    L = host_library()
+    assert L is not None, "radio-observer_amd/host/libro_host.so missing: run __graft_entry__.build()"
+    L.ro_host_frontend_run.restype = C.c_void_p
+    L.ro_host_frontend_run.argtypes = [C.c_int, C.c_char_p, C.c_int64, C.c_int, C.c_int64, C.c_int64]
+    for n, rt in (("free", None), ("ok", C.c_int), ("calls", C.c_int), ("started", C.c_int),
+                  ("sample_rate", C.c_int), ("error", C.c_char_p), ("inf1", C.c_char_p)):
+        f = getattr(L, "ro_host_frontend_" + n)
+        f.argtypes = [C.c_void_p]
+        f.restype = rt
+    L.ro_host_frontend_format.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.ro_host_frontend_call.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_int64),
+                                        C.POINTER(C.c_int64)]
+    L.ro_host_frontend_call.restype = C.c_int
+    L.ro_host_frontend_samples.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int64]
+    L.ro_host_frontend_samples.restype = C.c_int64
+    L.ro_host_manual_create.restype = C.c_void_p
+    L.ro_host_manual_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_char_p,
+                                        C.c_char_p, C.c_double, C.c_double]
+    L.ro_host_manual_destroy.argtypes = [C.c_void_p]
+    L.ro_host_manual_push.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_float, C.c_int, C.c_float, C.c_int64,
+                                      C.c_int64, C.c_int]
+    L.ro_host_manual_end.argtypes = [C.c_void_p]
+    L.ro_host_manual_info.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.ro_host_manual_files.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.ro_host_manual_files.restype = C.c_int
+    L.ro_host_manual_snapshot.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ro_host_manual_snapshot.restype = C.c_int
+    L.ro_host_manual_events.argtypes = [C.c_void_p, C.POINTER(BolidEvent), C.c_int]
+    L.ro_host_manual_events.restype = C.c_int
+    return L
+
+
+def wav_bytes(frames_i16, rate=48000, channels=2, bits=16, extra_chunks=True, fmt_extra=0):
+    data = frames_i16.astype("<i2").tobytes()
+    fmt = struct.pack("<hhiihh", 1, channels, rate, rate * channels * bits // 8, channels * bits // 8, bits)
+    fmt += b"\x00" * fmt_extra
+    chunks = b"fmt " + struct.pack("<I", len(fmt)) + fmt
+    if extra_chunks:
+        chunks += b"inf1" + struct.pack("<I", 8) + b"station\x00"
+        chunks += b"LIST" + struct.pack("<I", 4) + b"abcd"
+    chunks += b"data" + struct.pack("<I", len(data)) + data
+    return b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks
+
+
+def run_frontend(H, kind, payload, rate=48000, start=(0, 0)):
+    r = H.ro_host_frontend_run(kind, payload, len(payload), rate, start[0], start[1])
+    n = H.ro_host_frontend_calls(r)
+    calls = []
+    for i in range(n):
+        o, s, u = C.c_uint64(), C.c_int64(), C.c_int64()
+        size = H.ro_host_frontend_call(r, i, C.byref(o), C.byref(s), C.byref(u))
+        calls.append((size, o.value, s.value, u.value))
+    total = H.ro_host_frontend_samples(r, None, 0)
+    buf = np.empty((total, 2), np.float64)
+    H.ro_host_frontend_samples(r, buf.ctypes.data_as(C.POINTER(C.c_double)), total)
+    fmt = (C.c_int * 6)()
+    H.ro_host_frontend_format(r, fmt)
+    out = dict(ok=bool(H.ro_host_frontend_ok(r)), calls=calls, samples=buf, format=list(fmt),
+               error=(H.ro_host_frontend_error(r) or b"").decode(), started=H.ro_host_frontend_started(r),
+               rate=H.ro_host_frontend_sample_rate(r), inf1=(H.ro_host_frontend_inf1(r) or b"").decode())
+    H.ro_host_frontend_free(r)
+    return out
+
+
+def test_wavstream_blocks_values_and_times(H, oracle):
+    """src/WAVStream.cpp:112-123: 1024 frames per Backend::process call, int16 -> double without
+    scaling; Frontend::process recomputes the DataInfo after every call (src/Frontend.cpp:47-51)."""
+    rng = np.random.default_rng(0)
+    frames = rng.integers(-32768, 32768, size=(1024 * 5 + 300, 2)).astype(np.int16)
+    for fmt_extra in (0, 2):
+        r = run_frontend(H, 0, wav_bytes(frames, rate=96000, fmt_extra=fmt_extra))
+        assert r["ok"] and r["started"] == 11 and r["rate"] == 96000 and r["inf1"] == "station"
+        assert r["format"] == [1, 2, 96000, 96000 * 4, 4, 16]
+        assert [c[0] for c in r["calls"]] == [1024] * 5 + [300]        # the tail is delivered once, true length
+        assert np.array_equal(r["samples"], frames.astype(np.float64))
+        off = 0
+        for size, o, s, u in r["calls"]:
+            assert o == off
+            es, eu = C.c_int64(), C.c_int64()
+            oracle.lib().ro_oracle_wftime_add_samples(0, 0, off, 96000, C.byref(es), C.byref(eu))
+            assert (s, u) == (es.value, eu.value)
+            off += size
+
+
+def test_wavstream_rejects_what_the_reference_cannot_read(H):
+    frames = np.zeros((100, 2), np.int16)
+    r = run_frontend(H, 0, wav_bytes(frames, bits=8))
+    assert not r["ok"] and "16 bits" in r["error"] and r["calls"] == []    # src/WAVStream.cpp:103-106
+    mono = np.zeros((100, 1), np.int16)
+    r = run_frontend(H, 0, wav_bytes(mono, channels=1))
+    assert not r["ok"] and "2-channel" in r["error"]                        # reference: out-of-bounds reads (UB)
+    r = run_frontend(H, 0, b"RIFX" + b"\x00" * 40)
+    assert not r["ok"] and "chunk ID" in r["error"] and r["started"] == 0   # :209-213
+    r = run_frontend(H, 0, b"RIFF" + struct.pack("<I", 4) + b"AVI ")
+    assert not r["ok"] and "chunk format" in r["error"]                     # :223-227
+
+
+def test_rawstream_blocks(H):
+    """src/RawStream.cpp:30-69: float32 I,Q, 4096 frames per call, a short last read is delivered as is."""
+    rng = np.random.default_rng(1)
+    iq = rng.standard_normal((4096 * 2 + 77, 2)).astype(np.float32)
+    r = run_frontend(H, 1, iq.tobytes(), rate=48000, start=(1700000000, 5))
+    assert r["started"] == 11 and [c[0] for c in r["calls"]] == [4096, 4096, 77]
+    assert np.array_equal(r["samples"], iq.astype(np.float64))
+    assert r["calls"][0][2:] == (1700000000, 5) and r["calls"][1][1] == 4096
+    assert r["calls"][1][2:] == (1700000000, 5 + 85333)                      # 4096/48000 s, truncated to us
+
+
+# ---------------------------------------------------------------------------------------------------
+def read_fits(path):
+    raw = open(path, "rb").read()
+    assert len(raw) % 2880 == 0
+    cards, pos, done = [], 0, False
+    while not done:
+        block = raw[pos:pos + 2880]
+        pos += 2880
+        for i in range(0, 2880, 80):
+            c = block[i:i + 80].decode("ascii")
+            if c.startswith("END"):
+                done = True
+                break
+            cards.append(c)
+    hdr = {}
+    for c in cards:
+        if c[8:10] == "= ":
+            key = c[:8].strip()
+            val = c[10:].split(" / ")[0].strip()
+            hdr[key] = val.strip("'").strip() if val.startswith("'") else val
+    w, h = int(hdr["NAXIS1"]), int(hdr["NAXIS2"])
+    data = np.frombuffer(raw[pos:pos + w * h * 4], dtype=">f4").reshape(h, w)
+    assert len(raw) == pos + ((w * h * 4 + 2879) // 2880) * 2880
+    return hdr, data, cards
+
+
+def manual(H, tmp_path, bins=4096, overlap=2048, rate=48000, snap_len=1, lo=10100.0, hi=11000.0, adv=0.1, jit=0.3):
+    m = H.ro_host_manual_create(bins, overlap, rate, snap_len, lo, hi, str(tmp_path).encode(), b"teststn", adv, jit)
+    info = (C.c_int * 6)()
+    H.ro_host_manual_info(m, info)
+    return m, list(info)
+
+
+def test_snapshot_cadence_and_fits_files(H, oracle, tmp_path):
+    """SnapshotRecorder: snapshotRows = ceil(len * fftRate) (:339-347), fires when rows+2 are present
+    (:415-427), stop() writes the unfinished tail (:400-403); FITS keys of :141-211."""
+    bins, overlap, rate = 4096, 2048, 48000
+    m, info = manual(H, tmp_path)
+    fft_rate = oracle.lib().ro_oracle_fft_sample_rate(rate, bins, overlap)           # 23.4375 rows/s
+    snap_rows = int(np.ceil(1 * fft_rate))                                            # 24
+    cap, got_rows, lbin, rbin = info[0], info[1], info[2], info[3]
+    assert got_rows == snap_rows == 24 and cap >= snap_rows * 8
+    assert (lbin, rbin) == (oracle.lib().ro_oracle_frequency_to_bin(bins, rate, 10100.0),
+                            oracle.lib().ro_oracle_frequency_to_bin(bins, rate, 11000.0))
+    rng = np.random.default_rng(2)
+    total = 60
+    rows = rng.random((total, bins)).astype(np.float32)
+    t0 = 1700000000
+    hop = bins - overlap
+    for r in range(total):
+        es, eu = C.c_int64(), C.c_int64()
+        oracle.lib().ro_oracle_wftime_add_samples(t0, 0, r * hop, rate, C.byref(es), C.byref(eu))
+        H.ro_host_manual_push(m, rows[r].ctypes.data_as(C.POINTER(C.c_float)), 1.0, 0, 0.5, es.value, eu.value, r)
+    H.ro_host_manual_end(m)
+    H.ro_host_manual_info(m, (C.c_int * 6)())
+    buf = C.create_string_buffer(8192)
+    nfiles = H.ro_host_manual_files(m, buf, 8192)
+    files = buf.value.decode().split()
+    # snapshots fire at rows 26 and 50 (size >= 24 + 2), stop() flushes the 12-row tail
+    snaps = []
+    for i in range(3):
+        s, l = C.c_int(), C.c_int()
+        assert H.ro_host_manual_snapshot(m, i, C.byref(s), C.byref(l)) == 0
+        snaps.append((s.value, l.value))
+    assert snaps == [(0, 24), (24, 24), (48, 12)] and nfiles == 3
+    # file names: time of the row BEFORE the snapshot start (rawHandles_ one slot ahead, Appendix B-4);
+    # the first name is computed before any row exists -> epoch zero
+    assert os.path.basename(files[0]) == "19700101000000000_teststn_snap.fits"
+    hdr, data, cards = read_fits(files[1])
+    assert hdr["BITPIX"] == "-32" and int(hdr["NAXIS1"]) == rbin - lbin and int(hdr["NAXIS2"]) == 24
+    assert np.array_equal(data, rows[24:48, lbin:rbin])                               # rows x [leftBin, rightBin)
+    assert hdr["ORIGIN"] == "teststn" and hdr["CTYPE1"] == "FREQ" and hdr["CTYPE2"] == "TIME"
+    assert float(hdr["CRVAL1"]) == 10100.0 and int(hdr["CRPIX2"]) == 1
+    assert abs(float(hdr["CDELT2"]) - 1000.0 / fft_rate) < 1e-9
+    assert abs(float(hdr["CDELT1"]) - rate / bins) < 1e-3
+    # CRVAL2 = unix ms of fftMarkToTime(start): the handle at slot `start` describes row start-1
+    es, eu = C.c_int64(), C.c_int64()
+    oracle.lib().ro_oracle_wftime_add_samples(t0, 0, 23 * hop, rate, C.byref(es), C.byref(eu))
+    assert int(hdr["CRVAL2"]) == int(es.value * 1000 + eu.value / 1000.0)
+    assert all(len(c) == 80 for c in cards)
+    hdr, data, _ = read_fits(files[2])
+    assert int(hdr["NAXIS2"]) == 12 and np.array_equal(data, rows[48:60, lbin:rbin])
+    H.ro_host_manual_destroy(m)
+
+
+def test_fits_readable_by_cfitsio_if_present(H, tmp_path):
+    lib = None
+    for p in ("/opt/conda/lib/libcfitsio.so", "libcfitsio.so", "libcfitsio.so.9", "libcfitsio.so.10"):
+        try:
+            lib = C.CDLL(p)
+            break
+        except OSError:
+            pass
+    if lib is None:
+        pytest.skip("no cfitsio on this box")
+    m, info = manual(H, tmp_path, snap_len=1)
+    rows = np.random.default_rng(3).random((30, 4096)).astype(np.float32)
+    for r in range(30):
+        H.ro_host_manual_push(m, rows[r].ctypes.data_as(C.POINTER(C.c_float)), 1.0, 0, 0.5, 1700000000 + r, 0, r)
+    H.ro_host_manual_end(m)
+    buf = C.create_string_buffer(8192)
+    H.ro_host_manual_files(m, buf, 8192)
+    path = buf.value.decode().split()[0]
+    fptr, status = C.c_void_p(), C.c_int(0)
+    lib.ffopen(C.byref(fptr), path.encode(), 0, C.byref(status))
+    assert status.value == 0
+    naxes = (C.c_long * 2)()
+    bitpix, naxis = C.c_int(), C.c_int()
+    lib.ffgipr(fptr, 2, C.byref(bitpix), C.byref(naxis), naxes, C.byref(status))
+    assert (status.value, bitpix.value, naxis.value, naxes[1]) == (0, -32, 2, 24)
+    out = np.empty((24, naxes[0]), np.float32)
+    fpixel = (C.c_long * 2)(1, 1)
+    anynul = C.c_int()
+    lib.ffgpxv(fptr, 42, fpixel, C.c_longlong(out.size), None, out.ctypes.data_as(C.c_void_p), C.byref(anynul),
+               C.byref(status))                                                       # 42 = TFLOAT
+    assert status.value == 0 and np.array_equal(out, rows[:24, info[2]:info[3]])
+    lib.ffclos(fptr, C.byref(status))
+    H.ro_host_manual_destroy(m)
+
+
+def test_bolid_recorder_fsm_matches_oracle(H, oracle, tmp_path):
+    """BolidRecorder::update on hand-fed scan records == the oracle's FSM (src/BolidRecorder.cpp:171-273)."""
+    bins, overlap, rate = 32768, 24576, 48000
+    m, info = manual(H, tmp_path, bins=bins, overlap=overlap, snap_len=60, adv=2.0, jit=5.0)
+    cap = info[0]
+    b = oracle.bolid_bands(bins, rate, overlap, 10300, 10900, 9000, 9600, 2, 5, 40)
+    fft_rate = oracle.lib().ro_oracle_fft_sample_rate(rate, bins, overlap)
+    fsm = oracle.BolidFsm(b.advance, b.jitter, fft_rate, rate, 10300.0, 10900.0)
+    rng = np.random.default_rng(4)
+    script = np.zeros(400, bool)
+    for s, l in ((30, 9), (45, 2), (120, 1), (200, 40), (245, 3), (330, 5)):
+        script[s:s + l] = True
+    row = np.zeros(bins, np.float32)
+    expect = []
+    for i, d in enumerate(script):
+        n = np.float32(1.0 + 0.1 * rng.random())
+        a = np.float32(n * (3.0 if d else 1.5))                                      # detect <=> a > 2n
+        p = int(rng.integers(0, b.detect_width))
+        H.ro_host_manual_push(m, row.ctypes.data_as(C.POINTER(C.c_float)), float(n), p, float(a), i, 0, i)
+        ev = fsm.update(n, a, oracle.lib().ro_oracle_bin_to_frequency(bins, rate, b.low_detect + p), (i + 1) % cap)
+        if ev.fired:
+            expect.append((i, ev.snap_start, ev.snap_length, ev.raw_length, ev.duration_s, ev.noise, ev.peak_freq,
+                           ev.magnitude, ev.fmin, ev.fmax))
+    buf = (BolidEvent * 32)()
+    n_ev = H.ro_host_manual_events(m, buf, 32)
+    got = [(e.row, e.start, e.length, e.rawLength, e.duration, e.noise, e.peakFreq, e.magnitude, e.fmin, e.fmax)
+           for e in buf[:n_ev]]
+    assert len(expect) >= 3 and got == expect
+    info2 = (C.c_int * 6)()
+    H.ro_host_manual_info(m, info2)
+    assert info2[5] == fsm.f.state
+    H.ro_host_manual_destroy(m)
