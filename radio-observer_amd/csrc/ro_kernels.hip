@@ -42,6 +42,10 @@
 #ifndef RO_PAIRED_LOADS
 #define RO_PAIRED_LOADS 1
 #endif
+// LDS exchange of the N = 32768 plan through ds_write_addtid_b32 (1) or plain ds_write_b32 (0)
+#ifndef RO_USE_ADDTID
+#define RO_USE_ADDTID 1
+#endif
 // threads per workgroup of the N = 32768 plan (1024: 32 points per thread; 512: 64)
 #ifndef RO_T32768
 #define RO_T32768 1024
@@ -255,21 +259,29 @@ __device__ __forceinline__ void lds_gather(const E *lds, v2f (&v)[P], int tid, F
 // full exchange between a finished stage (RA, NS) and the next stage of radix RB.
 // SPLIT (row too large for LDS as float2): the real plane goes first; gathering it
 // into v[].x leaves v[].y in the old register order for the second scatter.
-template <class PL, int RA, int NS, int RB>
-__device__ __forceinline__ void exchange(void *smem, v2f (&v)[PL::P], int tid)
+template <class PL, int RA, int NS, int RB, typename ST>
+__device__ __forceinline__ void exchange(void *smem, v2f (&v)[PL::P], int tid, ST sub)
 {
     constexpr int N = PL::N, P = PL::P, T = PL::T;
     if constexpr (RO_ABLATE & 4) return;
     if constexpr (PL::SPLIT) {
         float *lds = reinterpret_cast<float *>(smem);
         lds_scatter<P, T, RA, NS>(lds, v, tid, [](v2f e) { return e.x; });
+        sub(0);
         __syncthreads();
+        sub(1);
         lds_gather<N, P, T, RB>(lds, v, tid, [](v2f &d, float s) { d.x = s; });
+        sub(2);
         __syncthreads();
+        sub(3);
         lds_scatter<P, T, RA, NS>(lds, v, tid, [](v2f e) { return e.y; });
+        sub(0);
         __syncthreads();
+        sub(1);
         lds_gather<N, P, T, RB>(lds, v, tid, [](v2f &d, float s) { d.y = s; });
+        sub(2);
         __syncthreads();
+        sub(3);
     } else {
         v2f *lds = reinterpret_cast<v2f *>(smem);
         lds_scatter<P, T, RA, NS>(lds, v, tid, [](v2f e) { return e; });
@@ -277,6 +289,92 @@ __device__ __forceinline__ void exchange(void *smem, v2f (&v)[PL::P], int tid)
         lds_gather<N, P, T, RB>(lds, v, tid, [](v2f &d, v2f s) { d = s; });
         __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------------------
+// N = 32768 exchange with ds_write_addtid_b32.  In-kernel stamps showed that four fifths of an
+// exchange is spent waiting for the LDS WRITES (ds_write_b32 moves address + data VGPRs to the
+// LDS at 4 cycles per wave-instruction; 128 KiB per plane took ~3.7k cycles), the gathers being
+// cheap.  ds_write_addtid_b32 has no address VGPR (address = M0 + offset + 4*lane, 2 cycles per
+// wave-instruction), but needs a lane-linear image.  Both exchanges have one:
+//   after stage 0 (element i = 32 j + r):           image[r*1025 + j]       gather (j'&31)*1025 + (j'>>5) + 32 r'
+//   after stage 1 (i = (j>>5)*1024 + (j&31) + 32r): image[r*1024 + j]       gather (j'>>5)*1024 + (j'&31) + 32 r'
+// (j = writing thread, r = its register slot; j', r' = reading thread / slot).  Writes are
+// lane-linear, reads hit 32 consecutive banks per half-wave: no conflicts either way.
+// M0 holds 16 bits and the offset field 16 bits, so slots 0..15 and 16..31 use two M0 values.
+// ---------------------------------------------------------------------------
+template <int O0, int O1, int O2, int O3, int O4, int O5, int O6, int O7>
+__device__ __forceinline__ void addtid_write8(unsigned m0, float a0, float a1, float a2, float a3, float a4,
+                                              float a5, float a6, float a7)
+{
+    // "SALU writes M0 -> LDS add-TID instruction" needs one wait state; hipcc pads nothing inside asm
+    asm volatile("s_mov_b32 m0, %8\n\t"
+                 "s_nop 0\n\t"
+                 "ds_write_addtid_b32 %0 offset:%9\n\t"
+                 "ds_write_addtid_b32 %1 offset:%10\n\t"
+                 "ds_write_addtid_b32 %2 offset:%11\n\t"
+                 "ds_write_addtid_b32 %3 offset:%12\n\t"
+                 "ds_write_addtid_b32 %4 offset:%13\n\t"
+                 "ds_write_addtid_b32 %5 offset:%14\n\t"
+                 "ds_write_addtid_b32 %6 offset:%15\n\t"
+                 "ds_write_addtid_b32 %7 offset:%16"
+                 :
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7), "s"(m0), "n"(O0), "n"(O1),
+                   "n"(O2), "n"(O3), "n"(O4), "n"(O5), "n"(O6), "n"(O7)
+                 : "memory");
+}
+
+// scatter one plane of the 32 register slots: slot r (value v[bitrev32(r)]) to byte r*ROWB + 4*tid
+template <int ROWB, bool YPLANE> __device__ __forceinline__ void addtid_scatter32(const v2f (&v)[32], unsigned wave_bytes)
+{
+    constexpr int X = 15 * ROWB + ((65532 - 3840 - 15 * ROWB) / 4) * 4 < 65532 - 3840 ? 15 * ROWB : 15 * ROWB;
+    // second half: M0 = wave_bytes + HB, offsets r*ROWB - HB in [0, 65535]; HB chosen so both fit 16 bits
+    constexpr int HB = (31 * ROWB - 65532 + 3) / 4 * 4 > 0 ? ((31 * ROWB - 65532 + 3) / 4) * 4 : 0;
+    static_assert(HB + 3840 <= 65532 && 31 * ROWB - HB <= 65535 && 16 * ROWB - HB >= 0, "M0 / offset split");
+    (void)X;
+#define RO_PL(r) (YPLANE ? v[bitrev<32>(r)].y : v[bitrev<32>(r)].x)
+    addtid_write8<0 * ROWB, 1 * ROWB, 2 * ROWB, 3 * ROWB, 4 * ROWB, 5 * ROWB, 6 * ROWB, 7 * ROWB>(
+        wave_bytes, RO_PL(0), RO_PL(1), RO_PL(2), RO_PL(3), RO_PL(4), RO_PL(5), RO_PL(6), RO_PL(7));
+    addtid_write8<8 * ROWB, 9 * ROWB, 10 * ROWB, 11 * ROWB, 12 * ROWB, 13 * ROWB, 14 * ROWB, 15 * ROWB>(
+        wave_bytes, RO_PL(8), RO_PL(9), RO_PL(10), RO_PL(11), RO_PL(12), RO_PL(13), RO_PL(14), RO_PL(15));
+    addtid_write8<16 * ROWB - HB, 17 * ROWB - HB, 18 * ROWB - HB, 19 * ROWB - HB, 20 * ROWB - HB, 21 * ROWB - HB,
+                  22 * ROWB - HB, 23 * ROWB - HB>(wave_bytes + HB, RO_PL(16), RO_PL(17), RO_PL(18), RO_PL(19),
+                                                  RO_PL(20), RO_PL(21), RO_PL(22), RO_PL(23));
+    addtid_write8<24 * ROWB - HB, 25 * ROWB - HB, 26 * ROWB - HB, 27 * ROWB - HB, 28 * ROWB - HB, 29 * ROWB - HB,
+                  30 * ROWB - HB, 31 * ROWB - HB>(wave_bytes + HB, RO_PL(24), RO_PL(25), RO_PL(26), RO_PL(27),
+                                                  RO_PL(28), RO_PL(29), RO_PL(30), RO_PL(31));
+#undef RO_PL
+}
+
+// XCH = 1: between stage 0 and 1, XCH = 2: between stage 1 and 2   (N = 32768, T = 1024, radix 32 everywhere)
+template <int XCH, typename ST>
+__device__ __forceinline__ void exchange_addtid(void *smem, v2f (&v)[32], int tid, ST sub)
+{
+    if constexpr (RO_ABLATE & 4) return;
+    constexpr int ROW = XCH == 1 ? 1025 : 1024;                   // floats per register-slot row of the image
+    const float *lds = reinterpret_cast<const float *>(smem);
+    const unsigned wave_bytes = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6) * 256u;
+    const float *g = lds + (XCH == 1 ? (tid & 31) * 1025 + (tid >> 5) : (tid >> 5) * 1024 + (tid & 31));
+    addtid_scatter32<ROW * 4, false>(v, wave_bytes);
+    sub(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    sub(1);
+#pragma unroll
+    for (int r = 0; r < 32; ++r) v[r].x = g[32 * r];
+    sub(2);
+    __syncthreads();
+    sub(3);
+    addtid_scatter32<ROW * 4, true>(v, wave_bytes);
+    sub(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    sub(1);
+#pragma unroll
+    for (int r = 0; r < 32; ++r) v[r].y = g[32 * r];
+    sub(2);
+    __syncthreads();
+    sub(3);
 }
 
 // ---------------------------------------------------------------------------
@@ -324,6 +422,9 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
 {
     constexpr int N = PL::N, T = PL::T, P = PL::P;
     constexpr int R0 = PL::R0;
+    // the N = 32768 plan exchanges through ds_write_addtid_b32 (see exchange_addtid)
+    constexpr bool ADDTID = RO_USE_ADDTID && N == 32768 && T == 1024 && P == 32 && PL::R0 == 32 && PL::R1 == 32 &&
+                            PL::R2 == 32 && PL::R3 == 1 && PL::SPLIT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using S = Sample<FMT>;
 
@@ -466,7 +567,8 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
 
         // ---- stage 1
         if constexpr (PL::R1 > 1) {
-            exchange<PL, PL::R0, 1, PL::R1>(smem, v, tid);
+            if constexpr (ADDTID) exchange_addtid<1>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
+            else exchange<PL, PL::R0, 1, PL::R1>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             stamp(3);                               // exchange 1
             tw_apply<P, PL::R1>(v, tw1);
             butterflies<P, PL::R1>(v);
@@ -476,7 +578,8 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         if constexpr (PL::R2 > 1) {
             v2f tw2[P / PL::R2][TW_SET];
             tw_prefetch<P, T, PL::R2, PL::NS2, PL::TW2>(tw2, rs_tw, tid);
-            exchange<PL, PL::R1, PL::NS1, PL::R2>(smem, v, tid);
+            if constexpr (ADDTID) exchange_addtid<2>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
+            else exchange<PL, PL::R1, PL::NS1, PL::R2>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             stamp(5);                               // exchange 2
             tw_apply<P, PL::R2>(v, tw2);
             butterflies<P, PL::R2>(v);
@@ -486,7 +589,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         if constexpr (PL::R3 > 1) {
             v2f tw3[P / PL::R3][TW_SET];
             tw_prefetch<P, T, PL::R3, PL::NS3, PL::TW3>(tw3, rs_tw, tid);
-            exchange<PL, PL::R2, PL::NS2, PL::R3>(smem, v, tid);
+            exchange<PL, PL::R2, PL::NS2, PL::R3>(smem, v, tid, [](int) {});
             tw_apply<P, PL::R3>(v, tw3);
             butterflies<P, PL::R3>(v);
         }
