@@ -217,11 +217,15 @@ def main():
     for i in range(a.warmup):
         step(i)
     fence()
+    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev_a.record(stream)
     for i in range(a.steps):
         step(i)
+    ev_b.record(stream)
     fence()
     dt = time.perf_counter() - t0
+    gpu_ms_per_step = ev_a.elapsed_time(ev_b) / a.steps
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if a.comm == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -257,6 +261,7 @@ def main():
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ROW * R,
                          "scan_kernel_ms": k_scan},
             "device": st.device_name,
+            "gpu_ms_per_step_events": gpu_ms_per_step, "step_ms_back_to_back": float(np.mean(ms_all)),
         }
 
         # ---- device copy bandwidth for context (float32 copy of the row buffer)

@@ -131,7 +131,7 @@ int ro_stft_set_bands(ro_stft_t *h, const ro_bands_t *bands);
  *   d_tile      device, rows x tile_cols floats (compact copy of columns
  *               [tile_first_col, +tile_cols) of d_rows), or NULL
  *   d_records   device, rows records, or NULL (needs enable_scan)
- *   stream      hipStream_t as void* (NULL = the handle's own stream)
+ *   stream      hipStream_t as void* (NULL = the default stream, with its usual ordering rules)
  * The call is asynchronous on `stream`. */
 int ro_stft_run_resident(ro_stft_t *h, const void *d_iq, int format, int64_t samples,
                          int64_t first_row, int64_t rows,

@@ -45,11 +45,19 @@ template <> struct W32<15> { static constexpr float c = -RO_C1, s = RO_C7; };
 // .yx / .xx swizzles fold into op_sel, and constant pairs live in SGPRs.
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// a * w for a twiddle held in registers: (ax wx - ay wy, ay wx + ax wy)
+// a * w for a twiddle held in registers: (ax wx - ay wy, ay wx + ax wy) in two packed ops.
+// hipcc builds the (-wy, wy) operand with an extra v_xor; the VOP3P modifiers do it for free:
+// op_sel / op_sel_hi pick the half of each source that feeds the low / high result lane and
+// neg_lo negates a source for the low lane only.  (Pure asm, no side effects: the scheduler is
+// free to move it; packed VALU ops need no software wait states between each other.)
 __device__ __forceinline__ v2f cmul(v2f a, v2f w)
 {
-    const v2f t = a * w.xx;
-    return __builtin_elementwise_fma(a.yx, (v2f){-w.y, w.y}, t);
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));                 // a * (wx, wx)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"           // (ay,ax)*(-wy,wy) + t
+        : "=v"(r)
+        : "v"(a), "v"(w), "v"(t));
+    return r;
 }
 
 // d * exp(-2*pi*i*M/32) = (x c + y s, y c - x s)

@@ -535,12 +535,16 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         // ---- stage 0: window (coefficients and samples were requested a whole epilogue ago)
         {
             const v2f gain2 = (v2f){0.0f, a.gain};          // src/FFTBackend.cpp:78-79: Q += gain
+            if (a.gain != 0.0f) {                           // every shipped config has iq_gain = 0: skip the adds
+#pragma unroll
+                for (int i = 0; i < P; ++i) v[i] = v[i] + gain2;
+            }
             if constexpr (PAIRED) {
                 const bool odd = tid & 1;
 #pragma unroll
                 for (int k = 0; k < H; ++k) {
-                    const v2f e = (v[k] + gain2) * w[k].xx;        // even column, leg k (H+k on odd lanes)
-                    const v2f o = (v[H + k] + gain2) * w[k].yy;    // odd column
+                    const v2f e = v[k] * w[k].xx;                  // even column, leg k (H+k on odd lanes)
+                    const v2f o = v[H + k] * w[k].yy;              // odd column
                     // even lane keeps e in slot k and takes the partner's e (leg H+k) into slot H+k;
                     // odd lane keeps o in slot H+k and takes the partner's o (leg k) into slot k.
                     const v2f pe = (v2f){dpp_quad<0xB1>(e.x), dpp_quad<0xB1>(e.y)};
@@ -550,7 +554,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < P; ++i) v[i] = (v[i] + gain2) * (v2f){w[i], w[i]};
+                for (int i = 0; i < P; ++i) v[i] = v[i] * (v2f){w[i], w[i]};
             }
         }
         // The coefficients for the NEXT row are requested right away: their registers are free

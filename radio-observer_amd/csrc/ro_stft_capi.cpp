@@ -636,7 +636,7 @@ extern "C" int ro_stft_run_resident(ro_stft_t *h, const void *d_iq, int format, 
                                d_records);
     if (rc != RO_OK || rows == 0) return rc;
     HIP_TRY(hipSetDevice(h->device));
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t s = (hipStream_t)stream;      // NULL = the default (null) stream, like any HIP launch
     rc = launch_transform(h, d_iq, format, first_row, rows, d_rows, row_stride, s);
     if (rc != RO_OK) return rc;
     if (d_tile) HIP_TRY(ro::launch_tile(make_tile_args(h, d_rows, row_stride, rows, d_tile), s));
@@ -656,7 +656,7 @@ extern "C" int ro_stft_scan_resident(ro_stft_t *h, const float *d_rows, int64_t 
     if (!h->cfg.enable_scan) return fail(RO_ERR_STATE, "scan bands not configured");
     if (rows < 0 || row_stride < h->bins) return fail(RO_ERR_INVALID, "bad rows / row_stride");
     HIP_TRY(hipSetDevice(h->device));
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t s = (hipStream_t)stream;      // NULL = the default (null) stream, like any HIP launch
     ro::ScanArgs sc = make_scan_args(h, d_rows, row_stride, rows, d_records);
     HIP_TRY(ro::launch_scan(sc, s));
     return RO_OK;
@@ -672,7 +672,7 @@ extern "C" int ro_stft_time_resident(ro_stft_t *h, const void *d_iq, int format,
     if (rc != RO_OK) return rc;
     if (iters <= 0 || !ms_out) return fail(RO_ERR_INVALID, "iters must be positive and ms_out non-null");
     HIP_TRY(hipSetDevice(h->device));
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t s = (hipStream_t)stream;      // NULL = the default (null) stream, like any HIP launch
     std::vector<hipEvent_t> ev((size_t)iters * 3);
     for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
     ro::ScanArgs sc = make_scan_args(h, d_rows, row_stride, rows, d_records);
