@@ -34,10 +34,6 @@
 #ifndef RO_STAMPS
 #define RO_STAMPS 0
 #endif
-// 1: the row stores are issued at the top of the next iteration, after the window loads
-#ifndef RO_DEFER_STORES
-#define RO_DEFER_STORES 0
-#endif
 // 16-byte sample loads shared by lane pairs (see load_row); 0 = one 8-byte load per sample
 #ifndef RO_PAIRED_LOADS
 #define RO_PAIRED_LOADS 1
@@ -121,25 +117,10 @@ __device__ __forceinline__ void buf_store_f4(float x0, float x1, float x2, float
     __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, RO_STORE_AUX);
 }
 
-// 4x4 transpose across the four lanes of a quad (DPP quad_perm, no LDS): afterwards
-// register k of lane a holds what register a of lane k held.
+// value of lane (quad_perm) of the same register, DPP: no LDS, full-rate VALU
 template <int CTRL> __device__ __forceinline__ float dpp_quad(float x)
 {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xF, 0xF, false));
-}
-__device__ __forceinline__ void quad_transpose(float &x0, float &x1, float &x2, float &x3, int lane)
-{
-    const bool hi2 = lane & 2, hi1 = lane & 1;
-    {   // swap the off-diagonal 2x2 blocks with lane ^ 2   (quad_perm [2,3,0,1])
-        const float r0 = dpp_quad<0x4E>(hi2 ? x0 : x2);
-        const float r1 = dpp_quad<0x4E>(hi2 ? x1 : x3);
-        if (hi2) { x0 = r0; x1 = r1; } else { x2 = r0; x3 = r1; }
-    }
-    {   // transpose inside each 2x2 block with lane ^ 1     (quad_perm [1,0,3,2])
-        const float r0 = dpp_quad<0xB1>(hi1 ? x0 : x1);
-        const float r1 = dpp_quad<0xB1>(hi1 ? x2 : x3);
-        if (hi1) { x0 = r0; x2 = r1; } else { x1 = r0; x3 = r1; }
-    }
 }
 
 // Ordering by fake data dependence: returns `off` unchanged, but the compiler must
@@ -324,26 +305,22 @@ __device__ __forceinline__ void addtid_write8(unsigned m0, float a0, float a1, f
                  : "memory");
 }
 
-// scatter one plane of the 32 register slots: slot r (value v[bitrev32(r)]) to byte r*ROWB + 4*tid
-template <int ROWB, bool YPLANE> __device__ __forceinline__ void addtid_scatter32(const v2f (&v)[32], unsigned wave_bytes)
+// scatter 32 floats per lane, slot q (value f(q), q a literal after inlining) to byte q*ROWB + 4*tid
+template <int ROWB, typename F> __device__ __forceinline__ void addtid_scatter32(unsigned wave_bytes, F f)
 {
-    constexpr int X = 15 * ROWB + ((65532 - 3840 - 15 * ROWB) / 4) * 4 < 65532 - 3840 ? 15 * ROWB : 15 * ROWB;
-    // second half: M0 = wave_bytes + HB, offsets r*ROWB - HB in [0, 65535]; HB chosen so both fit 16 bits
+    // second half: M0 = wave_bytes + HB, offsets q*ROWB - HB in [0, 65535]; HB chosen so both fit 16 bits
     constexpr int HB = (31 * ROWB - 65532 + 3) / 4 * 4 > 0 ? ((31 * ROWB - 65532 + 3) / 4) * 4 : 0;
     static_assert(HB + 3840 <= 65532 && 31 * ROWB - HB <= 65535 && 16 * ROWB - HB >= 0, "M0 / offset split");
-    (void)X;
-#define RO_PL(r) (YPLANE ? v[bitrev<32>(r)].y : v[bitrev<32>(r)].x)
     addtid_write8<0 * ROWB, 1 * ROWB, 2 * ROWB, 3 * ROWB, 4 * ROWB, 5 * ROWB, 6 * ROWB, 7 * ROWB>(
-        wave_bytes, RO_PL(0), RO_PL(1), RO_PL(2), RO_PL(3), RO_PL(4), RO_PL(5), RO_PL(6), RO_PL(7));
+        wave_bytes, f(0), f(1), f(2), f(3), f(4), f(5), f(6), f(7));
     addtid_write8<8 * ROWB, 9 * ROWB, 10 * ROWB, 11 * ROWB, 12 * ROWB, 13 * ROWB, 14 * ROWB, 15 * ROWB>(
-        wave_bytes, RO_PL(8), RO_PL(9), RO_PL(10), RO_PL(11), RO_PL(12), RO_PL(13), RO_PL(14), RO_PL(15));
+        wave_bytes, f(8), f(9), f(10), f(11), f(12), f(13), f(14), f(15));
     addtid_write8<16 * ROWB - HB, 17 * ROWB - HB, 18 * ROWB - HB, 19 * ROWB - HB, 20 * ROWB - HB, 21 * ROWB - HB,
-                  22 * ROWB - HB, 23 * ROWB - HB>(wave_bytes + HB, RO_PL(16), RO_PL(17), RO_PL(18), RO_PL(19),
-                                                  RO_PL(20), RO_PL(21), RO_PL(22), RO_PL(23));
+                  22 * ROWB - HB, 23 * ROWB - HB>(wave_bytes + HB, f(16), f(17), f(18), f(19), f(20), f(21), f(22),
+                                                  f(23));
     addtid_write8<24 * ROWB - HB, 25 * ROWB - HB, 26 * ROWB - HB, 27 * ROWB - HB, 28 * ROWB - HB, 29 * ROWB - HB,
-                  30 * ROWB - HB, 31 * ROWB - HB>(wave_bytes + HB, RO_PL(24), RO_PL(25), RO_PL(26), RO_PL(27),
-                                                  RO_PL(28), RO_PL(29), RO_PL(30), RO_PL(31));
-#undef RO_PL
+                  30 * ROWB - HB, 31 * ROWB - HB>(wave_bytes + HB, f(24), f(25), f(26), f(27), f(28), f(29), f(30),
+                                                  f(31));
 }
 
 // XCH = 1: between stage 0 and 1, XCH = 2: between stage 1 and 2   (N = 32768, T = 1024, radix 32 everywhere)
@@ -355,7 +332,7 @@ __device__ __forceinline__ void exchange_addtid(void *smem, v2f (&v)[32], int ti
     const float *lds = reinterpret_cast<const float *>(smem);
     const unsigned wave_bytes = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6) * 256u;
     const float *g = lds + (XCH == 1 ? (tid & 31) * 1025 + (tid >> 5) : (tid >> 5) * 1024 + (tid & 31));
-    addtid_scatter32<ROW * 4, false>(v, wave_bytes);
+    addtid_scatter32<ROW * 4>(wave_bytes, [&](int q) { return v[bitrev<32>(q)].x; });
     sub(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -365,7 +342,7 @@ __device__ __forceinline__ void exchange_addtid(void *smem, v2f (&v)[32], int ti
     sub(2);
     __syncthreads();
     sub(3);
-    addtid_scatter32<ROW * 4, true>(v, wave_bytes);
+    addtid_scatter32<ROW * 4>(wave_bytes, [&](int q) { return v[bitrev<32>(q)].y; });
     sub(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -562,7 +539,6 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         // memory burst.  (Unconditional: the same table every row.)
         load_window(make_rsrc(a.window, N * 4), c0{}, cE{});
         stamp(0);                                   // window multiply (+ wait for samples)
-        stamp(1);
 
         v2f tw1[PL::R1 > 1 ? P / PL::R1 : 1][TW_SET];
         butterflies<P, R0>(v);
