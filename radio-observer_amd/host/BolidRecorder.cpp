@@ -7,18 +7,25 @@
 
 namespace ro {
 
-BolidRecorder::BolidRecorder(WaterfallBase *backend, const BolidConfig &cfg) : Recorder(backend), cfg_(cfg)
+static SnapshotConfig snapshotPart(const BolidConfig &c)
 {
-    minDetectFq_ = std::min(cfg.low_detect_freq, cfg.hi_detect_freq);        // ORDER_PAIR, BolidRecorder.h:161
-    maxDetectFq_ = std::max(cfg.low_detect_freq, cfg.hi_detect_freq);
+    SnapshotConfig s;
+    s.output_dir = c.output_dir;
+    s.output_type = c.output_type;
+    s.compress_output = c.compress_output;
+    s.write_files = c.write_files;
+    s.snapshot_length = c.snapshot_length;
+    s.low_freq = c.low_freq;
+    s.hi_freq = c.hi_freq;
+    return s;
 }
 
-int BolidRecorder::requestBufferSize()
+BolidRecorder::BolidRecorder(WaterfallBase *backend, const BolidConfig &cfg)
+    : SnapshotRecorder(backend, snapshotPart(cfg)), cfg_(cfg)
 {
-    const float rate = backend_->getFFTSampleRate();
-    snapshotRows_ = (int)std::ceil(cfg_.snapshot_length * rate);
-    if (snapshotRows_ < 1) snapshotRows_ = 1;
-    return snapshotRows_ * 8;
+    writeUnfinished_ = false;                                                // src/BolidRecorder.h:160
+    minDetectFq_ = std::min(cfg.low_detect_freq, cfg.hi_detect_freq);        // ORDER_PAIR, BolidRecorder.h:161
+    maxDetectFq_ = std::max(cfg.low_detect_freq, cfg.hi_detect_freq);
 }
 
 void BolidRecorder::start()
@@ -37,6 +44,7 @@ void BolidRecorder::start()
     noiseMetadataRows_ = backend_->timeToFFTSamples(cfg_.noise_metadata_time);
     state_ = STATE_INIT;                                                                            // :106-108
     events_.clear();
+    SnapshotRecorder::start();                                                                      // :115
 }
 
 bool BolidRecorder::scanBands(ro_bands_t *b) const
@@ -68,8 +76,9 @@ void BolidRecorder::update()
             noise_ = n;
             magnitude_ = a;
             duration_ = 1;
-            snapStart_ = buffer_->mark() - advance_;
-            snapLength_ = 2 * advance_;
+            nextSnapshot_.start = buffer_->mark() - advance_;                    // :178-180
+            nextSnapshot_.length = 2 * advance_;
+            nextSnapshot_.fileName = getFileName(fftMarkToTime(nextSnapshot_.start));
             state_ = STATE_BOLID;
         }
         break;
@@ -77,7 +86,7 @@ void BolidRecorder::update()
         if (detect) {
             duration_ += 1;
         } else {
-            snapLength_ += duration_;
+            nextSnapshot_.length += duration_;
             duration_ = 1;
             state_ = STATE_BOLID_ENDED;
         }
@@ -89,24 +98,27 @@ void BolidRecorder::update()
         } else if (duration_ >= jitter_) {
             BolidEvent ev;
             ev.row = backend_->currentRowIndex();
-            ev.start = snapStart_;
-            ev.length = snapLength_;
-            ev.duration = (float)(snapLength_ - 2 * advance_) / (float)backend_->getFFTSampleRate();   // :209
+            ev.start = nextSnapshot_.start;
+            ev.length = nextSnapshot_.length;
+            ev.duration = (float)(nextSnapshot_.length - 2 * advance_) / (float)backend_->getFFTSampleRate();   // :209
             ev.noise = noise_;
             ev.peakFreq = peakFreq_;
             ev.magnitude = magnitude_;
             ev.fmin = peakFreq_ - (maxDetectFq_ - minDetectFq_) / 4;                                    // :241
             ev.fmax = peakFreq_ + (maxDetectFq_ - minDetectFq_) / 4;
-            ev.rawLength = fftSamplesToRaw(snapLength_);                                                // :246
+            ev.rawLength = fftSamplesToRaw(nextSnapshot_.length);                                       // :246
             events_.push_back(ev);
             if (out_) {                                                                                 // :250-257
                 (*out_) << "met;" << ev.row << ";" << ev.noise << ";" << ev.peakFreq << ";" << ev.magnitude << ";"
                         << ev.fmin << ";" << ev.fmax << ";" << ev.duration << ";" << ev.rawLength << "#" << std::endl;
             }
+            nextSnapshot_.includeRawData = true;                                                        // :262-263
+            startWriting();
             state_ = STATE_INIT;
         }
         break;
     }
+    if (!pending_.empty()) drainPending(false);              // the worker's retry loop (WaterfallBackend.cpp:60-104)
 }
 
 }  // namespace ro

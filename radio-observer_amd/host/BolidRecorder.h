@@ -8,12 +8,16 @@
 #include <string>
 #include <vector>
 
-#include "HipWaterfallBackend.h"
+#include "SnapshotRecorder.h"
 
 namespace ro {
 
 // BolidRecorder::make's config keys and defaults (src/BolidRecorder.cpp:360-381)
 struct BolidConfig {
+    std::string output_dir = ".";
+    std::string output_type = "blid";
+    bool   compress_output = true;
+    bool   write_files = true;              // see SnapshotConfig
     int    snapshot_length = 60;
     float  low_freq = 9000, hi_freq = 12000;
     float  low_detect_freq = 10000, hi_detect_freq = 10900;
@@ -35,13 +39,12 @@ struct BolidEvent {                          // what :223-263 writes to CSV / Bo
 
 struct NoiseSample { float noise, peakFreq, magnitude; };   // NoiseMessage payload, :137-138
 
-class BolidRecorder : public Recorder {
+class BolidRecorder : public SnapshotRecorder {
 public:
     enum State { STATE_INIT, STATE_BOLID, STATE_BOLID_ENDED };
 
     BolidRecorder(WaterfallBase *backend, const BolidConfig &cfg);
 
-    int  requestBufferSize() override;       // SnapshotRecorder::requestBufferSize, WaterfallBackend.cpp:339-347
     void start() override;
     void update() override;
     bool scanBands(ro_bands_t *b) const override;
@@ -63,11 +66,10 @@ private:
     BolidConfig cfg_;
     float minDetectFq_, maxDetectFq_;
     int   lowDetectBin_ = 0, detectWidth_ = 0, lowNoiseBin_ = 0, noiseWidth_ = 0;
-    int   advance_ = 0, jitter_ = 0, averageBinRange_ = 0, noiseMetadataRows_ = 0, snapshotRows_ = 1;
+    int   advance_ = 0, jitter_ = 0, averageBinRange_ = 0, noiseMetadataRows_ = 0;
     State state_ = STATE_INIT;
     float peakFreq_ = 0, noise_ = 0, magnitude_ = 0;
     int   duration_ = 0;
-    int   snapStart_ = 0, snapLength_ = 0;
     std::vector<BolidEvent> events_;
     NoiseSample lastNoise_{};
     std::ostream *out_ = nullptr;

@@ -27,7 +27,7 @@ WaterfallBase::WaterfallBase(const WaterfallConfig &cfg) : cfg_(cfg)
 void WaterfallBase::addRecorder(Recorder *recorder)
 {
     recorders_.push_back(recorder);
-    recorder->setBuffer(&buffer_, &rawHandles_);
+    recorder->setBuffer(&buffer_, &rawBuffer_, &rawHandles_);
 }
 
 bool WaterfallBase::beginStream(const StreamInfo &info, ro_bands_t *bands)
@@ -45,12 +45,23 @@ bool WaterfallBase::beginStream(const StreamInfo &info, ro_bands_t *bands)
         const int want = fftSamplesToRaw(bufferSize);
         const int chunkRows = (1024 * 1024) / 8;
         rawCapacity_ = std::max(1, (want / chunkRows + (want % chunkRows ? 1 : 0)) * chunkRows);
+        if (cfg_.keep_raw) rawBuffer_.resize(2, 1024 * 1024, want);
     }
     for (Recorder *r : recorders_) r->start();                                   // :591-593
     bool any = false;
     for (Recorder *r : recorders_)
         if (!any && r->scanBands(bands)) any = true;
     return any;
+}
+
+void WaterfallBase::pushRaw(const Complex *data, size_t n)
+{
+    if (!cfg_.keep_raw || rawBuffer_.getCapacity() == 0) return;
+    for (size_t i = 0; i < n; ++i) {
+        float *row = rawBuffer_.push();                      // FFTBackend::floatToInt(Complex, float*), FFTBackend.h:258-262
+        row[0] = (float)data[i].real;
+        row[1] = (float)data[i].imag;
+    }
 }
 
 void WaterfallBase::finishStream()
@@ -143,6 +154,7 @@ void HipWaterfallBackend::process(const std::vector<Complex> &data, DataInfo inf
         }
         samplesIn_ += (int64_t)data.size();
     }
+    pushRaw(data.data(), data.size());
     // ---- the samples themselves go to the GPU path; struct Complex is two doubles (RO_IQ_F64)
     int64_t ready = 0;
     if (ro_stft_push(stft_, data.data(), RO_IQ_F64, (int64_t)data.size(), &ready) != RO_OK) {

@@ -33,9 +33,11 @@ class Recorder {
 public:
     explicit Recorder(WaterfallBase *backend) : backend_(backend) {}
     virtual ~Recorder() {}
-    void setBuffer(RingBuffer2D<float> *buffer, std::vector<RawDataHandle> *rawHandles)
+    void setBuffer(RingBuffer2D<float> *buffer, RingBuffer2D<float> *rawBuffer,
+                   std::vector<RawDataHandle> *rawHandles)
     {
         buffer_ = buffer;
+        rawBuffer_ = rawBuffer;
         rawHandles_ = rawHandles;
     }
     int getSampleRate() const;
@@ -56,6 +58,7 @@ public:
 protected:
     WaterfallBase              *backend_;
     RingBuffer2D<float>        *buffer_ = nullptr;
+    RingBuffer2D<float>        *rawBuffer_ = nullptr;     // raw I/Q, 2 floats per sample (src/FFTBackend.h:99)
     std::vector<RawDataHandle> *rawHandles_ = nullptr;
 };
 
@@ -71,6 +74,7 @@ struct WaterfallConfig {
     // device-side options (no counterpart in the reference)
     int         device = 0;
     int         max_batch_rows = 0;          // rows per kernel launch; small = low latency
+    bool        keep_raw = true;             // keep the raw I/Q ring (the reference always does: FFTBackend.cpp:217-223)
 };
 
 // Everything WaterfallBackend is to its recorders (src/WaterfallBackend.h:239-290 and the FFTBackend
@@ -108,6 +112,7 @@ public:
 
     // ---- inspection (tests)
     RingBuffer2D<float> &buffer() { return buffer_; }
+    RingBuffer2D<float> &rawBuffer() { return rawBuffer_; }
     const std::vector<RawDataHandle> &rawHandles() const { return rawHandles_; }
     int64_t rowsDelivered() const { return rowsDelivered_; }
     int rawCapacity() const { return rawCapacity_; }
@@ -130,7 +135,11 @@ protected:
     float fftSampleRate_ = 0.f;
     bool  scanEnabled_ = false;
 
+    // raw samples as (float)re, (float)im, one ring row per sample (src/FFTBackend.cpp:217-223)
+    void pushRaw(const Complex *data, size_t n);
+
     RingBuffer2D<float>        buffer_;
+    RingBuffer2D<float>        rawBuffer_;
     std::vector<RawDataHandle> rawHandles_;
     std::vector<Recorder *>    recorders_;
     int     rawCapacity_ = 1;
@@ -146,6 +155,7 @@ class ManualWaterfall : public WaterfallBase {
 public:
     explicit ManualWaterfall(const WaterfallConfig &cfg) : WaterfallBase(cfg) {}
     void startStream(const StreamInfo &info) { ro_bands_t b; scanEnabled_ = beginStream(info, &b); }
+    void pushSamples(const Complex *data, size_t n) { pushRaw(data, n); }
     void pushRow(const float *row, const ro_scan_record_t *scan, WFTime time, int rawMark)
     {
         DataInfo di;

@@ -55,15 +55,18 @@ void SnapshotRecorder::start()
     pending_.clear();                                                            //  the first file: App. B-4)
     queued_.clear();
     written_.clear();
+    writtenRaw_.clear();
 }
 
-std::string SnapshotRecorder::getFileName(WFTime time) const
+std::string SnapshotRecorder::getFileName(const char *typ, WFTime time) const
 {
     char name[1024];
     std::snprintf(name, sizeof(name), "%s%03d_%s_%s.%s", formatTime(time, "%Y%m%d%H%M%S").c_str(),
-                  (int)(time.usec / 1000), backend_->getOrigin().c_str(), cfg_.output_type.c_str(), "fits");
+                  (int)(time.usec / 1000), backend_->getOrigin().c_str(), typ, "fits");
     return joinPath(cfg_.output_dir, name);                           // :332-335 (the directory is joined twice
 }                                                                     //  in the reference's write(); once here)
+
+std::string SnapshotRecorder::getFileName(WFTime time) const { return getFileName(cfg_.output_type.c_str(), time); }
 
 void SnapshotRecorder::startWriting()
 {
@@ -85,7 +88,10 @@ void SnapshotRecorder::drainPending(bool final)
     std::vector<Snapshot> keep;
     for (const Snapshot &s : pending_) {
         if (buffer_->size(s.start) >= s.length) {
-            write(s);
+            if (cfg_.write_files) {
+                write(s);
+                if (s.includeRawData) writeRaw(s);                    // :80-81
+            }
             buffer_->freeReservation(s.reservation);
         } else if (!final) {
             keep.push_back(s);
@@ -131,6 +137,38 @@ bool SnapshotRecorder::write(const Snapshot &s)
     for (int y = 0; y < s.length; ++y, ++rowIndex) w.write(y, 1, buffer_->at(rowIndex) + leftBin_);   // :203-205
     const bool ok = w.close();
     if (ok) written_.push_back(s.fileName);
+    return ok;
+}
+
+// the raw I/Q behind a snapshot: a 2 x L float image (src/WaterfallBackend.cpp:214-267)
+bool SnapshotRecorder::writeRaw(const Snapshot &s)
+{
+    if (!rawBuffer_ || rawBuffer_->getCapacity() == 0) return false;
+    const int start = fftMarkToRaw(s.start);                          // :216
+    const int length = fftSamplesToRaw(s.length);                     // :217 (the recorder's int fft rate)
+    const WFTime time = fftMarkToTime(s.start);
+    const float sampleRate = (float)backend_->streamInfo().sampleRate;
+    const std::string name = getFileName("raws", time);
+    FITSWriter w;
+    if (!w.open("!" + name)) return false;
+    w.createImage(2, length);
+    w.comment("File created by radio-observer_amd (MI355X STFT path).");
+    w.comment("See https://github.com/MLAB-project/radio-observer.");
+    w.writeHeader("ORIGIN", backend_->getOrigin().c_str(), "");
+    w.date();
+    w.writeHeader("DATE-OBS", formatTime(time, "%Y-%m-%dT%H:%M:%S").c_str(), "observation date (UTC)");
+    w.writeHeader("CTYPE2", "TIME", "in seconds");
+    w.writeHeader("CRPIX2", 1, "");
+    w.writeHeader("CRVAL2", (long long)time.toMilliseconds(), "unix time of the first IQ sample in this file in ms");
+    w.writeHeader("CDELT2", 1000.0f / sampleRate, "time difference between two IQ samples in ms");
+    w.writeHeader("CTYPE1", "CHAN", "in Hz");
+    w.writeHeader("CRPIX1", 1.f, "");
+    w.writeHeader("CRVAL1", 0, "");
+    w.writeHeader("CDELT1", 1, "");
+    int rowIndex = start;
+    for (int y = 0; y < length; ++y, ++rowIndex) w.write(y, 1, rawBuffer_->at(rowIndex));            // :258-260
+    const bool ok = w.close();
+    if (ok) writtenRaw_.push_back(name);
     return ok;
 }
 

@@ -18,6 +18,7 @@ struct SnapshotConfig {
     bool  compress_output = true;       // accepted; files are always written uncompressed (FITSWriter.h)
     int   snapshot_length = 60;
     float low_freq = 0, hi_freq = 0;    // equal = full band (:368-374)
+    bool  write_files = true;           // false = keep the cadence/bookkeeping, touch no files (test rigs)
 };
 
 struct Snapshot {                        // src/WaterfallBackend.h:117-150
@@ -38,6 +39,7 @@ public:
 
     std::string getFileName(WFTime time) const;                      // :320-336
     const std::vector<std::string> &filesWritten() const { return written_; }
+    const std::vector<std::string> &rawFilesWritten() const { return writtenRaw_; }
     const std::vector<Snapshot> &snapshotsQueued() const { return queued_; }
     int snapshotRows() const { return snapshotRows_; }
     int leftBin() const { return leftBin_; }
@@ -46,6 +48,8 @@ public:
 protected:
     void startWriting();                 // :107-127
     bool write(const Snapshot &s);       // :141-211
+    bool writeRaw(const Snapshot &s);    // :214-267
+    std::string getFileName(const char *typ, WFTime time) const;
     void drainPending(bool final);
 
     SnapshotConfig cfg_;
@@ -54,7 +58,7 @@ protected:
     int   snapshotRows_ = 1, leftBin_ = 0, rightBin_ = 0;
     Snapshot nextSnapshot_;
     std::vector<Snapshot> pending_, queued_;
-    std::vector<std::string> written_;
+    std::vector<std::string> written_, writtenRaw_;
 };
 
 }  // namespace ro

@@ -67,6 +67,7 @@ void *ro_host_pipeline_create(int bins, int overlap, int sample_rate, int64_t st
     b.advance_time = advance_time;
     b.jitter_time = jitter_time;
     b.avg_freq_range = avg_range;
+    b.write_files = false;
     Pipeline *p = new Pipeline(w, b, SnapshotConfig(), false);
     StreamInfo si;
     si.sampleRate = sample_rate;
@@ -90,6 +91,7 @@ void *ro_host_pipeline_create_snap(int bins, int overlap, int sample_rate, int64
     sc.low_freq = lo_snap;
     sc.hi_freq = hi_snap;
     BolidConfig b;
+    b.output_dir = out_dir;
     b.snapshot_length = snapshot_length;
     b.low_detect_freq = 10300; b.hi_detect_freq = 10900; b.low_noise_freq = 9000; b.hi_noise_freq = 9600;
     b.advance_time = 2; b.jitter_time = 5;
@@ -106,6 +108,19 @@ int ro_host_pipeline_files(void *p, char *buf, int len)
     for (const auto &f : static_cast<Pipeline *>(p)->snap.filesWritten()) all += f + "\n";
     std::snprintf(buf, (size_t)len, "%s", all.c_str());
     return (int)static_cast<Pipeline *>(p)->snap.filesWritten().size();
+}
+static int joinNames(const std::vector<std::string> &v, char *buf, int len)
+{
+    std::string all;
+    for (const auto &f : v) all += f + "\n";
+    std::snprintf(buf, (size_t)len, "%s", all.c_str());
+    return (int)v.size();
+}
+// files of the detector: raw = 0 the band snapshots ("blid"), raw = 1 the raw I/Q captures ("raws")
+int ro_host_pipeline_bolid_files(void *p, int raw, char *buf, int len)
+{
+    const BolidRecorder &b = static_cast<Pipeline *>(p)->bolid;
+    return joinNames(raw ? b.rawFilesWritten() : b.filesWritten(), buf, len);
 }
 void ro_host_pipeline_destroy(void *p) { delete static_cast<Pipeline *>(p); }
 #define PIPE(p) static_cast<Pipeline *>(p)
@@ -285,6 +300,7 @@ void *ro_host_manual_create(int bins, int overlap, int sample_rate, int snapshot
     sc.low_freq = lo_snap;
     sc.hi_freq = hi_snap;
     BolidConfig b;
+    b.output_dir = out_dir;
     b.snapshot_length = snapshot_length;
     b.low_detect_freq = 10300; b.hi_detect_freq = 10900; b.low_noise_freq = 9000; b.hi_noise_freq = 9600;
     b.advance_time = advance_time; b.jitter_time = jitter_time;
@@ -301,6 +317,17 @@ void ro_host_manual_push(void *m, const float *row, float n, int p, float a, int
     ro_scan_record_t s{n, p, a};
     RIG(m)->source.pushRow(row, &s, WFTime(sec, usec), raw_mark);
 }
+// raw samples behind the rows (n complex doubles), as FFTBackend::process keeps them
+void ro_host_manual_push_samples(void *m, const double *iq, int n)
+{
+    RIG(m)->source.pushSamples(reinterpret_cast<const Complex *>(iq), (size_t)n);
+}
+int ro_host_manual_bolid_files(void *m, int raw, char *buf, int len)
+{
+    const BolidRecorder &b = RIG(m)->bolid;
+    return joinNames(raw ? b.rawFilesWritten() : b.filesWritten(), buf, len);
+}
+int ro_host_manual_raw_capacity(void *m) { return RIG(m)->source.rawBuffer().getCapacity(); }
 void ro_host_manual_end(void *m) { RIG(m)->source.endStream(); }
 int ro_host_manual_info(void *m, int *out6)
 {

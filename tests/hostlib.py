@@ -57,7 +57,7 @@ class HostPipeline:
 
     def __init__(self, bins, overlap, sample_rate=48000, start=(0, 0), max_batch_rows=0, snapshot_length=60,
                  detect=(10300.0, 10900.0), noise=(9000.0, 9600.0), advance_time=2.0, jitter_time=5.0,
-                 avg_range=40.0):
+                 avg_range=40.0, out_dir=None, origin="teststn", snap_band=(9000.0, 12000.0)):
         L = host_library()
         self.L = L
         L.ro_host_pipeline_create.restype = C.c_void_p
@@ -81,10 +81,20 @@ class HostPipeline:
                                                   C.POINTER(C.c_int64)]
         L.ro_host_pipeline_bands.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.ro_host_pipeline_events.argtypes = [C.c_void_p, C.POINTER(BolidEvent), C.c_int]
+        L.ro_host_pipeline_create_snap.restype = C.c_void_p
+        L.ro_host_pipeline_create_snap.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int,
+                                                   C.c_float, C.c_float, C.c_char_p, C.c_char_p]
+        L.ro_host_pipeline_bolid_files.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+        L.ro_host_pipeline_files.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         self.bins = bins
-        self.h = L.ro_host_pipeline_create(bins, overlap, sample_rate, start[0], start[1], max_batch_rows,
-                                           snapshot_length, detect[0], detect[1], noise[0], noise[1],
-                                           advance_time, jitter_time, avg_range)
+        if out_dir is None:                      # detector only, no files
+            self.h = L.ro_host_pipeline_create(bins, overlap, sample_rate, start[0], start[1], max_batch_rows,
+                                               snapshot_length, detect[0], detect[1], noise[0], noise[1],
+                                               advance_time, jitter_time, avg_range)
+        else:                                    # SnapshotRecorder + BolidRecorder (its default bands) writing FITS
+            self.h = L.ro_host_pipeline_create_snap(bins, overlap, sample_rate, start[0], start[1], max_batch_rows,
+                                                    snapshot_length, snap_band[0], snap_band[1],
+                                                    str(out_dir).encode(), origin.encode())
 
     def process(self, iq):
         import numpy as np
@@ -127,6 +137,16 @@ class HostPipeline:
         buf = (BolidEvent * 64)()
         n = self.L.ro_host_pipeline_events(self.h, buf, 64)
         return [buf[i] for i in range(min(n, 64))]
+
+    def snapshot_files(self):
+        buf = C.create_string_buffer(1 << 16)
+        self.L.ro_host_pipeline_files(self.h, buf, 1 << 16)
+        return buf.value.decode().split()
+
+    def bolid_files(self, raw=False):
+        buf = C.create_string_buffer(1 << 16)
+        self.L.ro_host_pipeline_bolid_files(self.h, 1 if raw else 0, buf, 1 << 16)
+        return buf.value.decode().split()
 
     def ring_capacity(self):
         return self.L.ro_host_pipeline_ring_capacity(self.h)

@@ -147,3 +147,47 @@ def test_c1_wav_to_fits_end_to_end(oracle, tmp_path):
     assert float(hdr["CRVAL1"]) == 9000.0 and abs(float(hdr["CDELT2"]) - 1000.0 / 93.75) < 1e-9
     # the tone sits where frequencyToBin puts it
     assert abs(int(want[5].argmax()) - oracle.lib().ro_oracle_frequency_to_bin(1024, 48000, 10400.0)) <= 1
+
+
+def test_event_capture_files_band_image_and_raw_iq(oracle, tmp_path):
+    """SURVEY.md §8(f) raw-I/Q event capture: a detected chirp makes BolidRecorder queue a snapshot with
+    includeRawData (src/BolidRecorder.cpp:262-263); the band image must be the GPU rows the detector saw and the
+    raw image the float32 samples behind them (src/WaterfallBackend.cpp:214-267)."""
+    from test_host_cpu import read_fits
+    bins, overlap, hop = 32768, 24576, 8192
+    rng = np.random.default_rng(0xF3)
+    rows = 90
+    iq = noise_iq(rng, bins + (rows - 1) * hop)
+    add_chirp(iq, 25 * hop, 2.0, 10800.0, -100.0, 3.0)
+    z = iq[:, 0].astype(np.float64) + 1j * iq[:, 1].astype(np.float64)
+    t0 = (1700000000, 250000)
+    p = HostPipeline(bins, overlap, start=t0, max_batch_rows=8, snapshot_length=60, out_dir=tmp_path)
+    for i in range(0, len(z), 4096):
+        p.process(z[i:i + 4096])
+    p.end()
+    assert p.error == "" and p.rows == rows
+    evs = p.events()
+    assert len(evs) == 1
+    e = evs[0]
+    blid, raws = p.bolid_files(False), p.bolid_files(True)
+    assert len(blid) == 1 and len(raws) == 1
+    lo = oracle.lib().ro_oracle_frequency_to_bin(bins, 48000, 9000.0)
+    hi = oracle.lib().ro_oracle_frequency_to_bin(bins, 48000, 12000.0)
+    want = oracle.stft(iq, bins, overlap)
+    hdr, data, _ = read_fits(blid[0])
+    assert data.shape == (e.length, hi - lo)
+    assert np.abs(data - want[e.start:e.start + e.length, lo:hi]).max() <= 1e-5 * want.max()
+    # the raw window: handle[start] carries the mark stamped with row start-1 (rawHandles_ one slot ahead)
+    hdr, data, _ = read_fits(raws[0])
+    L = int(e.length / float(int(48000.0 / hop)) * 48000)
+    first = (e.start * hop + 1) % p.raw_capacity()
+    assert e.rawLength == L and data.shape == (L, 2)
+    avail = min(L, len(iq) - first)                      # a capture may run past the end of a finished stream
+    assert avail > L // 2 and np.array_equal(data[:avail], iq[first:first + avail].astype(np.float32))
+    st = oracle.Stream(bins, overlap, 48000, t0)
+    infos = []
+    for i in range(0, len(z), 4096):
+        infos += st.process(z[i:i + 4096])[1]
+    _, sec, usec, _ = infos[e.start - 1]
+    assert int(hdr["CRVAL2"]) == int(sec * 1000 + usec / 1000.0)
+    p.close()

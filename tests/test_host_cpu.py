@@ -41,6 +41,11 @@ def H():
     L.ro_host_manual_snapshot.restype = C.c_int
     L.ro_host_manual_events.argtypes = [C.c_void_p, C.POINTER(BolidEvent), C.c_int]
     L.ro_host_manual_events.restype = C.c_int
+    L.ro_host_manual_push_samples.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+    L.ro_host_manual_bolid_files.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+    L.ro_host_manual_bolid_files.restype = C.c_int
+    L.ro_host_manual_raw_capacity.argtypes = [C.c_void_p]
+    L.ro_host_manual_raw_capacity.restype = C.c_int
     return L
 
 
@@ -271,4 +276,65 @@ def test_bolid_recorder_fsm_matches_oracle(H, oracle, tmp_path):
     info2 = (C.c_int * 6)()
     H.ro_host_manual_info(m, info2)
     assert info2[5] == fsm.f.state
+    H.ro_host_manual_destroy(m)
+
+
+def test_bolid_event_writes_band_snapshot_and_raw_iq(H, oracle, tmp_path):
+    """An event queues a snapshot with includeRawData (src/BolidRecorder.cpp:262-263); the worker writes the band
+    image [leftBin,rightBin) x length (src/WaterfallBackend.cpp:141-211) and the raw I/Q behind it as a 2 x L float
+    image, L = fftSamplesToRaw(length) from the recorder's int fft rate (:214-267, src/WaterfallBackend.h:283-287)."""
+    bins, overlap, rate = 4096, 2048, 48000
+    hop = bins - overlap
+    m, info = manual(H, tmp_path, bins=bins, overlap=overlap, snap_len=4, lo=9000.0, hi=12000.0, adv=0.1, jit=0.3)
+    raw_cap = H.ro_host_manual_raw_capacity(m)
+    assert raw_cap > 0
+    fft_rate = oracle.lib().ro_oracle_fft_sample_rate(rate, bins, overlap)
+    adv = int(0.1 * fft_rate)
+    lbin = oracle.lib().ro_oracle_frequency_to_bin(bins, rate, 9000.0)
+    rbin = oracle.lib().ro_oracle_frequency_to_bin(bins, rate, 12000.0)
+    rng = np.random.default_rng(11)
+    total = 80
+    rows = rng.random((total, bins)).astype(np.float32)
+    iq = rng.standard_normal((bins + total * hop, 2))
+    detect = np.zeros(total, bool)
+    detect[30:36] = True
+    t0 = 1700000000
+    fed = 0
+    for r in range(total):
+        need = bins + r * hop                                     # the samples row r ends at
+        blk = np.ascontiguousarray(iq[fed:need])
+        H.ro_host_manual_push_samples(m, blk.ctypes.data_as(C.POINTER(C.c_double)), len(blk))
+        fed = need
+        es, eu = C.c_int64(), C.c_int64()
+        oracle.lib().ro_oracle_wftime_add_samples(t0, 0, r * hop, rate, C.byref(es), C.byref(eu))
+        raw_mark = ((r + 1) * hop + 1) % raw_cap                  # FFTBackend.cpp:242,251 (overlap != 0)
+        H.ro_host_manual_push(m, rows[r].ctypes.data_as(C.POINTER(C.c_float)), 1.0, 5, 3.0 if detect[r] else 1.5,
+                              es.value, eu.value, raw_mark)
+    H.ro_host_manual_end(m)
+    evs = (BolidEvent * 4)()
+    assert H.ro_host_manual_events(m, evs, 4) == 1
+    e = evs[0]
+    buf = C.create_string_buffer(8192)
+    assert H.ro_host_manual_bolid_files(m, 0, buf, 8192) == 1
+    blid = buf.value.decode().split()[0]
+    assert H.ro_host_manual_bolid_files(m, 1, buf, 8192) == 1
+    raws = buf.value.decode().split()[0]
+    assert blid.endswith("_teststn_blid.fits") and raws.endswith("_teststn_raws.fits")
+    # detection at row 30 with mark() == 31: start = 31 - advance; length = 2*advance + the 6 detected rows
+    assert (e.start, e.length) == (31 - adv, 2 * adv + 6)
+    hdr, data, _ = read_fits(blid)
+    assert (int(hdr["NAXIS1"]), int(hdr["NAXIS2"])) == (rbin - lbin, e.length)
+    assert np.array_equal(data, rows[e.start:e.start + e.length, lbin:rbin])
+    assert float(hdr["CRVAL1"]) == 9000.0
+    # raw image: starts at the raw mark of handle `start` (which describes row start-1: Appendix B-4)
+    hdr, data, cards = read_fits(raws)
+    L = int(e.length / float(int(fft_rate)) * rate)               # (sampleCount / (float)(int)rate) * sampleRate
+    assert L == e.rawLength and (int(hdr["NAXIS1"]), int(hdr["NAXIS2"])) == (2, L)
+    first = (e.start * hop + 1) % raw_cap                         # handle[start] was stamped by row start-1
+    assert np.array_equal(data, iq[first:first + L].astype(np.float32))
+    assert hdr["CTYPE1"] == "CHAN" and hdr["CTYPE2"] == "TIME" and int(hdr["CRPIX2"]) == 1
+    assert abs(float(hdr["CDELT2"]) - 1000.0 / rate) < 1e-7 and all(len(c) == 80 for c in cards)
+    es, eu = C.c_int64(), C.c_int64()
+    oracle.lib().ro_oracle_wftime_add_samples(t0, 0, (e.start - 1) * hop, rate, C.byref(es), C.byref(eu))
+    assert int(hdr["CRVAL2"]) == int(es.value * 1000 + eu.value / 1000.0)
     H.ro_host_manual_destroy(m)
