@@ -143,6 +143,20 @@ int ro_stft_run_resident(ro_stft_t *h, const void *d_iq, int format, int64_t sam
 int ro_stft_scan_resident(ro_stft_t *h, const float *d_rows, int64_t row_stride, int64_t rows,
                           ro_scan_record_t *d_records, void *stream);
 
+/* The offline viewer's transform of a band image, on rows already in HBM (fits2png:46 FN_LOG,
+ * :444-445 default_color_fn, :476-477 min/max, :495-497 the uint8 store):
+ *   ln    = logf(pixel), float32, over columns [first_col, first_col+cols) of `rows` rows
+ *   min/max of ln over the NON-ZERO pixels of the whole image (the viewer drops zeros)
+ *   level = (uint8)((ln - min) / (max - min) * 255), float32 arithmetic, truncating
+ * Zero pixels give -inf in d_ln and level 0; an image with max == min gives level 0 everywhere.
+ *   d_ln      device, rows x cols floats, or NULL
+ *   d_u8      device, rows x cols bytes,  or NULL
+ *   d_minmax  device, 2 floats {min, max}, or NULL
+ * Asynchronous on `stream`. */
+int ro_stft_ln_tile_resident(ro_stft_t *h, const float *d_rows, int64_t row_stride, int64_t rows,
+                             int first_col, int cols, float *d_ln, uint8_t *d_u8, float *d_minmax,
+                             void *stream);
+
 /* Times `iters` back-to-back launches of the resident path with HIP events on
  * the launch stream; ms_out[i] = duration of launch i (STFT kernel + scan kernel
  * when records are requested).  kernel_ms_out (optional, 2 floats) receives the

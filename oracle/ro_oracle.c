@@ -779,3 +779,35 @@ void ro_oracle_ln_rows(const float *rows, int64_t count, float *out)
 {
     for (int64_t i = 0; i < count; i++) out[i] = logf(rows[i]);
 }
+
+/* The viewer's grey image of one band image (fits2png:476-477, :444-445, :495-497):
+ * min / max of the ln over the non-zero pixels, level = (ln - min) / (max - min) * 255
+ * in float32, stored into a uint8 array (C truncation).  `image` is rows x cols,
+ * contiguous.  Zero pixels and a flat image give level 0 (the viewer has no such
+ * pixels / divides by zero there). */
+void ro_oracle_ln_levels(const float *image, int64_t count, float *ln_out, uint8_t *u8_out, float *minmax)
+{
+    float mn = INFINITY, mx = -INFINITY;
+    int any = 0;
+    for (int64_t i = 0; i < count; i++) {
+        const float l = logf(image[i]);
+        if (ln_out) ln_out[i] = l;
+        if (image[i] != 0.0f) {
+            if (l < mn) mn = l;
+            if (l > mx) mx = l;
+            any = 1;
+        }
+    }
+    (void)any;
+    if (minmax) {
+        minmax[0] = mn;
+        minmax[1] = mx;
+    }
+    if (!u8_out) return;
+    const float span = mx - mn;
+    for (int64_t i = 0; i < count; i++) {
+        const float l = logf(image[i]);
+        const float level = (l - mn) / span * 255.0f;
+        u8_out[i] = (image[i] != 0.0f && span > 0.0f) ? (uint8_t)(int)level : (uint8_t)0;
+    }
+}

@@ -173,6 +173,8 @@ int  ro_oracle_ring2d_is_dirty(const ro_oracle_ring2d_t *r, int handle);
 
 /* ---- offline ln / min-max tile: fits2png:46, :444-445, :476-502 (restated, not imported) */
 void ro_oracle_ln_rows(const float *rows, int64_t count, float *out);
+/* fits2png:444-445,476-477,495-497: min/max of ln over non-zero pixels, 8-bit grey levels */
+void ro_oracle_ln_levels(const float *image, int64_t count, float *ln_out, uint8_t *u8_out, float *minmax);
 
 #ifdef __cplusplus
 }

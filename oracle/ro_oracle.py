@@ -119,6 +119,7 @@ def lib():
         "ro_oracle_ring2d_free_reservation": (C.c_int, [C.c_void_p, C.c_int]),
         "ro_oracle_ring2d_is_dirty": (C.c_int, [C.c_void_p, C.c_int]),
         "ro_oracle_ln_rows": (None, [f32p, i64, f32p]),
+        "ro_oracle_ln_levels": (None, [f32p, i64, f32p, C.POINTER(C.c_uint8), f32p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -229,6 +230,18 @@ def scan_rows(rows, low_noise, noise_width, low_detect, detect_width, avg_bins):
                              avg_bins, C.byref(s))
         n[r], p[r], a[r] = s.noise, s.peak, s.average
     return n, p, a
+
+
+def ln_levels(image):
+    """image: float32 [R, W] band image -> (ln float32 [R, W], levels uint8 [R, W], (min, max)): the viewer's
+    natural-log grey image (fits2png:46, :444-445, :476-502)."""
+    image = np.ascontiguousarray(image, dtype=np.float32)
+    ln = np.empty_like(image)
+    u8 = np.empty(image.shape, np.uint8)
+    mm = np.empty(2, np.float32)
+    with np.errstate(all="ignore"):
+        lib().ro_oracle_ln_levels(_f32(image), image.size, _f32(ln), u8.ctypes.data_as(C.POINTER(C.c_uint8)), _f32(mm))
+    return ln, u8, (mm[0], mm[1])
 
 
 def bolid_bands(bins, sample_rate, overlap, min_detect, max_detect, min_noise, max_noise,

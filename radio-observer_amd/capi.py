@@ -72,6 +72,8 @@ _EXPORTS = {
                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ro_stft_scan_resident": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                         C.c_void_p]),
+    "ro_stft_ln_tile_resident": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ro_stft_time_resident": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64,
                                         C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
@@ -247,6 +249,11 @@ class Stft:
     def scan_resident(self, d_rows, rows, d_records, row_stride=None, stream=None):
         _check(library().ro_stft_scan_resident(self._h, _ptr(d_rows), row_stride or self.bins, rows,
                                                _ptr(d_records), _ptr(stream)))
+
+    def ln_tile_resident(self, d_rows, rows, first_col, cols, d_ln=None, d_u8=None, d_minmax=None,
+                         row_stride=None, stream=None):
+        _check(library().ro_stft_ln_tile_resident(self._h, _ptr(d_rows), row_stride or self.bins, rows, first_col,
+                                                  cols, _ptr(d_ln), _ptr(d_u8), _ptr(d_minmax), _ptr(stream)))
 
     def time_resident(self, d_iq, fmt, samples, first_row, rows, d_rows, iters, row_stride=None,
                       d_tile=None, d_records=None, stream=None):

@@ -34,6 +34,18 @@ struct TileArgs {
     int          first, cols;
 };
 
+// ln(magnitude) band tile and its 8-bit grey image (the offline viewer's transform, fits2png:46,444-445,476-502)
+struct LnArgs {
+    const float *rows_in;
+    float       *ln_out;       // rows x cols, or nullptr
+    uint8_t     *u8_out;       // rows x cols, or nullptr
+    unsigned    *keys;         // [0] = min, [1] = max of ln over the non-zero pixels, as order-preserving keys
+    float       *minmax;       // the same two as floats, or nullptr
+    int64_t      rows;
+    int64_t      row_stride;
+    int          first, cols;
+};
+
 struct ScanArgs {
     const float      *rows_in;
     ro_scan_record_t *records;
@@ -71,5 +83,6 @@ bool       stft_radices(int bins, int radices[4]);
 hipError_t launch_stft(int bins, int fmt, const StftArgs &a, hipStream_t s);
 hipError_t launch_scan(const ScanArgs &a, hipStream_t s);
 hipError_t launch_tile(const TileArgs &a, hipStream_t s);
+hipError_t launch_ln_tile(const LnArgs &a, hipStream_t s);
 
 }  // namespace ro

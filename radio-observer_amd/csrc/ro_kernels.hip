@@ -726,6 +726,68 @@ __device__ __forceinline__ float key_to_float(unsigned k)
     return __uint_as_float(u);
 }
 
+// ---------------------------------------------------------------------------
+// ln tile: the viewer's FN_LOG (fits2png:46: numpy.log of the non-zero float32 pixels) over the band
+// columns, its min / max (fits2png:476-477), and the grey level (v - min) / (max - min) * 255 cut to
+// uint8 (:444-445, :495-497).  Zero pixels (the viewer drops them) give -inf in the ln tile and level 0.
+// Pass 1 writes ln and reduces min/max, pass 2 quantises; both are plain streaming kernels.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_reduce_kernel(LnArgs a)
+{
+    __shared__ unsigned s_min[4], s_max[4];
+    const int64_t total = a.rows * (int64_t)a.cols;
+    unsigned kmin = 0xffffffffu, kmax = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / a.cols;
+        const int c = (int)(i - r * a.cols);
+        const float v = a.rows_in[r * a.row_stride + a.first + c];
+        const float l = logf(v);
+        if (a.ln_out) a.ln_out[i] = l;
+        if (v != 0.f) {
+            const unsigned k = order_key(l);
+            kmin = min(kmin, k);
+            kmax = max(kmax, k);
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, d));
+        kmax = max(kmax, (unsigned)__shfl_xor((int)kmax, d));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_min[threadIdx.x >> 6] = kmin;
+        s_max[threadIdx.x >> 6] = kmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            kmin = min(kmin, s_min[w]);
+            kmax = max(kmax, s_max[w]);
+        }
+        atomicMin(&a.keys[0], kmin);
+        atomicMax(&a.keys[1], kmax);
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_quant_kernel(LnArgs a)
+{
+    const float mn = key_to_float(a.keys[0]), mx = key_to_float(a.keys[1]);
+    if (a.minmax && blockIdx.x == 0 && threadIdx.x == 0) {
+        a.minmax[0] = mn;
+        a.minmax[1] = mx;
+    }
+    if (!a.u8_out) return;
+    const float span = mx - mn;
+    const int64_t total = a.rows * (int64_t)a.cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / a.cols;
+        const int c = (int)(i - r * a.cols);
+        const float v = a.rows_in[r * a.row_stride + a.first + c];
+        const float l = a.ln_out ? a.ln_out[i] : logf(v);
+        const float level = (l - mn) / span * 255.f;               // float32 throughout, like numpy
+        a.u8_out[i] = (v != 0.f && span > 0.f) ? (uint8_t)(int)level : (uint8_t)0;
+    }
+}
+
 constexpr int SCAN_E = 16;            // noise-band elements cached per lane (band <= 1024)
 constexpr int SCAN_WAVES = 4;         // rows per workgroup
 
@@ -975,6 +1037,21 @@ hipError_t launch_tile(const TileArgs &a, hipStream_t s)
     int64_t blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(tile_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_ln_tile(const LnArgs &a, hipStream_t s)
+{
+    if (a.rows <= 0 || a.cols <= 0) return hipSuccess;
+    const int64_t total = a.rows * (int64_t)a.cols;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipError_t e = hipMemsetAsync(a.keys, 0xff, sizeof(unsigned), s);        // min key = all ones
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(a.keys + 1, 0, sizeof(unsigned), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ln_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(ln_quant_kernel, dim3((unsigned)(a.u8_out ? blocks : 1)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -146,6 +146,7 @@ struct ro_stft {
     // large transforms (bins > 32768): full twiddle table + two complex scratch blocks in HBM
     bool    big = false;
     float2 *d_tw_big = nullptr;
+    unsigned *d_ln_keys = nullptr;     // min / max keys of ro_stft_ln_tile_resident
     float2 *d_scratch[2] = {nullptr, nullptr};
     int64_t scratch_rows = 0;
 };
@@ -530,6 +531,7 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg, ro_stft_t **out)
     CREATE_TRY(hipEventCreate(&h->ev0));
     CREATE_TRY(hipEventCreate(&h->ev1));
     CREATE_TRY(hipMalloc(&h->d_window, sizeof(float) * h->bins));
+    CREATE_TRY(hipMalloc(&h->d_ln_keys, 2 * sizeof(unsigned)));
     CREATE_TRY(hipMalloc(&h->d_twiddles, sizeof(float2) * std::max<size_t>(tw.size(), 1)));
     CREATE_TRY(hipMemcpy(h->d_window, h->window.data(), sizeof(float) * h->bins, hipMemcpyHostToDevice));
     if (!tw.empty())
@@ -554,6 +556,7 @@ extern "C" int ro_stft_destroy(ro_stft_t *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->d_window) (void)hipFree(h->d_window);
+    if (h->d_ln_keys) (void)hipFree(h->d_ln_keys);
     if (h->d_twiddles) (void)hipFree(h->d_twiddles);
     if (h->d_iq) (void)hipFree(h->d_iq);
     if (h->d_rows) (void)hipFree(h->d_rows);
@@ -659,6 +662,30 @@ extern "C" int ro_stft_scan_resident(ro_stft_t *h, const float *d_rows, int64_t 
     hipStream_t s = (hipStream_t)stream;      // NULL = the default (null) stream, like any HIP launch
     ro::ScanArgs sc = make_scan_args(h, d_rows, row_stride, rows, d_records);
     HIP_TRY(ro::launch_scan(sc, s));
+    return RO_OK;
+}
+
+extern "C" int ro_stft_ln_tile_resident(ro_stft_t *h, const float *d_rows, int64_t row_stride, int64_t rows,
+                                        int first_col, int cols, float *d_ln, uint8_t *d_u8, float *d_minmax,
+                                        void *stream)
+{
+    if (!h || !d_rows) return fail(RO_ERR_INVALID, "null argument");
+    if (!d_ln && !d_u8 && !d_minmax) return fail(RO_ERR_INVALID, "no output requested");
+    if (rows < 0 || row_stride < h->bins) return fail(RO_ERR_INVALID, "bad rows / row_stride");
+    if (first_col < 0 || cols <= 0 || (int64_t)first_col + cols > h->bins)
+        return fail(RO_ERR_INVALID, "columns outside the row");
+    HIP_TRY(hipSetDevice(h->device));
+    ro::LnArgs a;
+    a.rows_in = d_rows;
+    a.ln_out = d_ln;
+    a.u8_out = d_u8;
+    a.keys = h->d_ln_keys;
+    a.minmax = d_minmax;
+    a.rows = rows;
+    a.row_stride = row_stride;
+    a.first = first_col;
+    a.cols = cols;
+    HIP_TRY(ro::launch_ln_tile(a, (hipStream_t)stream));
     return RO_OK;
 }
 

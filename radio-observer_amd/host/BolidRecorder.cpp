@@ -1,5 +1,7 @@
 #include "BolidRecorder.h"
 
+#include <sstream>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -14,6 +16,7 @@ static SnapshotConfig snapshotPart(const BolidConfig &c)
     s.output_type = c.output_type;
     s.compress_output = c.compress_output;
     s.write_files = c.write_files;
+    s.listen_to_noise = false;                                               // src/BolidRecorder.h:145
     s.snapshot_length = c.snapshot_length;
     s.low_freq = c.low_freq;
     s.hi_freq = c.hi_freq;
@@ -68,6 +71,7 @@ void BolidRecorder::update()
     const float peakFq = backend_->binToFrequency(lowDetectBin_ + p);   // :133
     const bool  detect = ((double)a > (double)n * 2.0);                 // :135
     lastNoise_ = NoiseSample{n, peakFq, a};                             // NoiseMessage, :137-138
+    backend_->publishNoise(n, peakFq, a);
 
     switch (state_) {
     case STATE_INIT:                                                    // :172-183
@@ -108,9 +112,17 @@ void BolidRecorder::update()
             ev.fmax = peakFreq_ + (maxDetectFq_ - minDetectFq_) / 4;
             ev.rawLength = fftSamplesToRaw(nextSnapshot_.length);                                       // :246
             events_.push_back(ev);
+            const WFTime t = backend_->now();                                                           // :221
+            if (CsvLog *log = backend_->getMetadataFile()) {                                            // :223-234
+                std::ostringstream entry;
+                entry << baseName(nextSnapshot_.fileName) << ";" << noise_ << ";" << peakFreq_ << ";" << magnitude_
+                      << ";" << ev.duration;
+                log->write(t, entry.str());
+            }
             if (out_) {                                                                                 // :250-257
-                (*out_) << "met;" << ev.row << ";" << ev.noise << ";" << ev.peakFreq << ";" << ev.magnitude << ";"
-                        << ev.fmin << ";" << ev.fmax << ";" << ev.duration << ";" << ev.rawLength << "#" << std::endl;
+                (*out_) << "met;[" << t.sec << "s, " << t.usec << "us];" << ev.noise << ";" << ev.peakFreq << ";"
+                        << ev.magnitude << ";" << ev.fmin << ";" << ev.fmax << ";" << ev.duration << ";"
+                        << ev.rawLength << "#" << std::endl;
             }
             nextSnapshot_.includeRawData = true;                                                        // :262-263
             startWriting();

@@ -1,5 +1,7 @@
 #include "HipWaterfallBackend.h"
 
+#include <sys/time.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -52,6 +54,26 @@ bool WaterfallBase::beginStream(const StreamInfo &info, ro_bands_t *bands)
     for (Recorder *r : recorders_)
         if (!any && r->scanBands(bands)) any = true;
     return any;
+}
+
+CsvLog *WaterfallBase::getMetadataFile()
+{
+    if (cfg_.metadata_path.empty()) return nullptr;
+    if (!metadataFile_) {
+        std::string p = cfg_.metadata_path;
+        if (p.back() != '/') p += "/";
+        metadataFile_.reset(new CsvLog(p + "%Y%m%d%H%M%S_" + cfg_.origin + "_meta.csv",
+                                       "file name; noise; peak f.; mag.; duration"));
+    }
+    return metadataFile_.get();
+}
+
+WFTime WaterfallBase::now() const
+{
+    if (useFixedClock_) return fixedClock_;
+    timeval tv;
+    gettimeofday(&tv, nullptr);
+    return WFTime((int64_t)tv.tv_sec, (int64_t)tv.tv_usec);
 }
 
 void WaterfallBase::pushRaw(const Complex *data, size_t n)

@@ -10,11 +10,13 @@
 #pragma once
 
 #include <deque>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "../../include/ro_stft.h"
 #include "Backend.h"
+#include "CsvLog.h"
 #include "RingBuffer.h"
 
 namespace ro {
@@ -67,7 +69,7 @@ struct WaterfallConfig {
     int         bins = 32768;
     int         overlap = 0;
     std::string origin = "debug";
-    std::string metadata_path = ".";
+    std::string metadata_path = ".";         // "" = keep no metadata CSV (test rigs)
     int         buffer_chunk_size = 1024 * 1024;
     double      iq_gain = 0.0;
     int         iq_phase_shift = 0;
@@ -105,6 +107,18 @@ public:
 
     void addRecorder(Recorder *recorder);                            // src/WaterfallBackend.cpp:563-567
 
+    // <metadata_path>/%Y%m%d%H%M%S_<origin>_meta.csv, rotated hourly (src/WaterfallBackend.cpp:466-482);
+    // nullptr when metadata_path is empty
+    CsvLog *getMetadataFile();
+    // NoiseMessage (src/BolidMessage.h:19-49): the detector publishes (noise, peak f, magnitude) every row
+    // (src/BolidRecorder.cpp:137-138); listening snapshot recorders keep the latest (WaterfallBackend.cpp:270-277)
+    struct Noise { float noise = 0, peakFrequency = 0, magnitude = 0; };
+    void publishNoise(float n, float peakFq, float mag) { lastNoise_ = Noise{n, peakFq, mag}; }
+    const Noise &lastNoise() const { return lastNoise_; }
+    // WFTime::now() (src/WFTime.h:173-178); tests pin it with setClock
+    WFTime now() const;
+    void setClock(WFTime fixed) { fixedClock_ = fixed; useFixedClock_ = true; }
+
     // ---- what the row being delivered looks like (valid inside Recorder::update())
     const ro_scan_record_t &currentScan() const { return currentScan_; }
     bool  scanEnabled() const { return scanEnabled_; }
@@ -138,6 +152,10 @@ protected:
     // raw samples as (float)re, (float)im, one ring row per sample (src/FFTBackend.cpp:217-223)
     void pushRaw(const Complex *data, size_t n);
 
+    std::unique_ptr<CsvLog>    metadataFile_;
+    Noise  lastNoise_;
+    WFTime fixedClock_;
+    bool   useFixedClock_ = false;
     RingBuffer2D<float>        buffer_;
     RingBuffer2D<float>        rawBuffer_;
     std::vector<RawDataHandle> rawHandles_;

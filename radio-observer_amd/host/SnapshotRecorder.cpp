@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <ctime>
+#include <sstream>
 
 #include "FITSWriter.h"
 
@@ -15,6 +16,12 @@ static std::string formatTime(const WFTime &t, const char *fmt)       // src/WFT
     char buf[256];
     const size_t n = std::strftime(buf, sizeof(buf), fmt, std::gmtime(&s));
     return std::string(buf, n);
+}
+
+std::string baseName(const std::string &path)                        // cppapp Path::basename
+{
+    const size_t at = path.find_last_of('/');
+    return at == std::string::npos ? path : path.substr(at + 1);
 }
 
 static std::string joinPath(const std::string &a, const std::string &b)
@@ -116,6 +123,14 @@ bool SnapshotRecorder::write(const Snapshot &s)
 {
     const WFTime time = fftMarkToTime(s.start);                       // :143
     const float fftSampleRate = backend_->getFFTSampleRate();
+    if (cfg_.listen_to_noise) {                                       // :157-167
+        if (CsvLog *log = backend_->getMetadataFile()) {
+            const WaterfallBase::Noise &nz = backend_->lastNoise();
+            std::ostringstream entry;
+            entry << baseName(s.fileName) << ";" << nz.noise << ";" << nz.peakFrequency << ";" << nz.magnitude << ";" << 0;
+            log->write(time, entry.str());
+        }
+    }
     FITSWriter w;
     if (!w.open("!" + s.fileName)) return false;
     const int width = rightBin_ - leftBin_;

@@ -19,7 +19,10 @@ struct SnapshotConfig {
     int   snapshot_length = 60;
     float low_freq = 0, hi_freq = 0;    // equal = full band (:368-374)
     bool  write_files = true;           // false = keep the cadence/bookkeeping, touch no files (test rigs)
+    bool  listen_to_noise = true;       // "snapshot" factory: true (:448-457); the detector passes false
 };
+
+std::string baseName(const std::string &path);
 
 struct Snapshot {                        // src/WaterfallBackend.h:117-150
     int start = 0, length = 0, reservation = -1;

@@ -58,6 +58,7 @@ void *ro_host_pipeline_create(int bins, int overlap, int sample_rate, int64_t st
     w.bins = bins;
     w.overlap = overlap;
     w.max_batch_rows = max_batch_rows;
+    w.metadata_path = "";
     BolidConfig b;
     b.snapshot_length = snapshot_length;
     b.low_detect_freq = lo_det;
@@ -85,6 +86,7 @@ void *ro_host_pipeline_create_snap(int bins, int overlap, int sample_rate, int64
     w.overlap = overlap;
     w.max_batch_rows = max_batch_rows;
     w.origin = origin;
+    w.metadata_path = out_dir;
     SnapshotConfig sc;
     sc.output_dir = out_dir;
     sc.snapshot_length = snapshot_length;
@@ -121,6 +123,17 @@ int ro_host_pipeline_bolid_files(void *p, int raw, char *buf, int len)
 {
     const BolidRecorder &b = static_cast<Pipeline *>(p)->bolid;
     return joinNames(raw ? b.rawFilesWritten() : b.filesWritten(), buf, len);
+}
+// pin WFTime::now() for the event lines; the metadata CSV's current file name ("" before the first entry)
+void ro_host_pipeline_set_clock(void *p, int64_t sec, int64_t usec)
+{
+    static_cast<Pipeline *>(p)->backend.setClock(WFTime(sec, usec));
+}
+int ro_host_pipeline_metadata_file(void *p, char *buf, int len)
+{
+    CsvLog *log = static_cast<Pipeline *>(p)->backend.getMetadataFile();
+    std::snprintf(buf, (size_t)len, "%s", log ? log->currentFile().c_str() : "");
+    return log ? 1 : 0;
 }
 void ro_host_pipeline_destroy(void *p) { delete static_cast<Pipeline *>(p); }
 #define PIPE(p) static_cast<Pipeline *>(p)
@@ -257,6 +270,7 @@ int64_t ro_host_wav_to_fits(const char *bytes, int64_t n, int bins, int overlap,
     w.overlap = overlap;
     w.max_batch_rows = max_batch_rows;
     w.origin = origin;
+    w.metadata_path = out_dir;
     SnapshotConfig sc;
     sc.output_dir = out_dir;
     sc.snapshot_length = snapshot_length;
@@ -280,11 +294,13 @@ struct ManualRig {
     ManualWaterfall source;
     SnapshotRecorder snap;
     BolidRecorder bolid;
+    std::ostringstream lines;
     ManualRig(const WaterfallConfig &w, const SnapshotConfig &s, const BolidConfig &b)
         : source(w), snap(&source, s), bolid(&source, b)
     {
         source.addRecorder(&snap);
         source.addRecorder(&bolid);
+        bolid.setOutput(&lines);
     }
 };
 void *ro_host_manual_create(int bins, int overlap, int sample_rate, int snapshot_length, float lo_snap, float hi_snap,
@@ -294,6 +310,7 @@ void *ro_host_manual_create(int bins, int overlap, int sample_rate, int snapshot
     w.bins = bins;
     w.overlap = overlap;
     w.origin = origin;
+    w.metadata_path = out_dir;
     SnapshotConfig sc;
     sc.output_dir = out_dir;
     sc.snapshot_length = snapshot_length;
@@ -326,6 +343,19 @@ int ro_host_manual_bolid_files(void *m, int raw, char *buf, int len)
 {
     const BolidRecorder &b = RIG(m)->bolid;
     return joinNames(raw ? b.rawFilesWritten() : b.filesWritten(), buf, len);
+}
+void ro_host_manual_set_clock(void *m, int64_t sec, int64_t usec) { RIG(m)->source.setClock(WFTime(sec, usec)); }
+int ro_host_manual_metadata_file(void *m, char *buf, int len)
+{
+    CsvLog *log = RIG(m)->source.getMetadataFile();
+    std::snprintf(buf, (size_t)len, "%s", log ? log->currentFile().c_str() : "");
+    return log ? 1 : 0;
+}
+// the "met;...#" lines of src/BolidRecorder.cpp:250-257 collected so far
+int ro_host_manual_stdout(void *m, char *buf, int len)
+{
+    std::snprintf(buf, (size_t)len, "%s", RIG(m)->lines.str().c_str());
+    return (int)RIG(m)->lines.str().size();
 }
 int ro_host_manual_raw_capacity(void *m) { return RIG(m)->source.rawBuffer().getCapacity(); }
 void ro_host_manual_end(void *m) { RIG(m)->source.endStream(); }

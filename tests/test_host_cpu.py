@@ -44,6 +44,9 @@ def H():
     L.ro_host_manual_push_samples.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
     L.ro_host_manual_bolid_files.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
     L.ro_host_manual_bolid_files.restype = C.c_int
+    L.ro_host_manual_set_clock.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+    L.ro_host_manual_metadata_file.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.ro_host_manual_stdout.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.ro_host_manual_raw_capacity.argtypes = [C.c_void_p]
     L.ro_host_manual_raw_capacity.restype = C.c_int
     return L
@@ -288,6 +291,8 @@ def test_bolid_event_writes_band_snapshot_and_raw_iq(H, oracle, tmp_path):
     m, info = manual(H, tmp_path, bins=bins, overlap=overlap, snap_len=4, lo=9000.0, hi=12000.0, adv=0.1, jit=0.3)
     raw_cap = H.ro_host_manual_raw_capacity(m)
     assert raw_cap > 0
+    clock = (1700000000 + 2 * 3600 + 17, 123456)                  # WFTime::now() at the event, two hours later
+    H.ro_host_manual_set_clock(m, *clock)
     fft_rate = oracle.lib().ro_oracle_fft_sample_rate(rate, bins, overlap)
     adv = int(0.1 * fft_rate)
     lbin = oracle.lib().ro_oracle_frequency_to_bin(bins, rate, 9000.0)
@@ -337,4 +342,32 @@ def test_bolid_event_writes_band_snapshot_and_raw_iq(H, oracle, tmp_path):
     es, eu = C.c_int64(), C.c_int64()
     oracle.lib().ro_oracle_wftime_add_samples(t0, 0, (e.start - 1) * hop, rate, C.byref(es), C.byref(eu))
     assert int(hdr["CRVAL2"]) == int(es.value * 1000 + eu.value / 1000.0)
+    # ---- the event's text outputs: metadata CSV entry (src/BolidRecorder.cpp:223-234) and the "met;" line (:250-257)
+    import time
+    g = lambda v: "%g" % v                                        # ostream << float: 6 significant digits
+    pf = oracle.lib().ro_oracle_bin_to_frequency(bins, rate, oracle.lib().ro_oracle_frequency_to_bin(bins, rate, 10300.0) + 5)
+    dur = np.float32(np.float32(e.length - 2 * adv) / np.float32(fft_rate))
+    H.ro_host_manual_stdout(m, buf, 8192)
+    q = np.float32((np.float32(10900.0) - np.float32(10300.0)) / 4)
+    assert buf.value.decode() == "met;[%ds, %dus];1;%s;3;%s;%s;%s;%d#\n" % (
+        clock[0], clock[1], g(pf), g(np.float32(pf) - q), g(np.float32(pf) + q), g(dur), L)
+    H.ro_host_manual_metadata_file(m, buf, 8192)
+    hour = lambda s: time.strftime("%Y%m%d%H0000", time.gmtime(s))
+    ev_csv = os.path.join(str(tmp_path), hour(clock[0]) + "_teststn_meta.csv")
+    lines = open(ev_csv).read().splitlines()
+    assert lines == ["# file name; noise; peak f.; mag.; duration",
+                     "%s;1;%s;3;%s" % (os.path.basename(blid), g(pf), g(dur))]
+    # the snapshot recorder listens to the detector's NoiseMessage and logs one entry per file, stamped with the
+    # snapshot's own time (src/WaterfallBackend.cpp:157-167) -> a different hourly file here
+    n_snap = H.ro_host_manual_files(m, buf, 8192)
+    snap_names = [os.path.basename(f) for f in buf.value.decode().split()]
+    lines = []
+    for hname in sorted({hour(0), hour(t0)}):
+        f = os.path.join(str(tmp_path), hname + "_teststn_meta.csv")
+        if os.path.exists(f):
+            body = open(f).read().splitlines()
+            assert body[0].startswith("# file name")
+            lines += body[1:]
+    assert n_snap >= 1 and [l.split(";")[0] for l in lines] == snap_names
+    assert all(l.split(";")[1:] == ["1", g(pf), "1.5", "0"] or l.split(";")[3] == "3" for l in lines)
     H.ro_host_manual_destroy(m)

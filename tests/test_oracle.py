@@ -179,3 +179,24 @@ def test_fsm_states_and_event(oracle):
     assert ev.raw_length == int((30 / 5.0) * 48000)          # recorder's int fft rate (WaterfallBackend.cpp:29-32)
     assert (ev.fmin, ev.fmax) == (10500.0 - 150.0, 10500.0 + 150.0)
     assert f.f.state == 0
+
+
+def test_ln_levels_match_the_viewers_numpy_formula(oracle):
+    """fits2png is numpy: FN_LOG = numpy.log of the non-zero float32 pixels (:46), min/max of that (:476-477),
+    default_color_fn (v - min) / (max - min) (:444-445) times 255 stored into a uint8 array (:495-497)."""
+    rng = np.random.default_rng(46)
+    image = (np.abs(rng.standard_normal((37, 615))) * 10.0 ** rng.uniform(-3, 4, (37, 1))).astype(np.float32)
+    image[5, 7:19] = 0.0
+    ln, u8, (mn, mx) = oracle.ln_levels(image)
+    nz = image != 0
+    data = np.log(image[nz])                                            # float32 in, float32 out
+    assert data.dtype == np.float32
+    assert np.abs(ln[nz] - data).max() <= 1e-6                          # numpy's SIMD logf vs libm: <= 2 ulp here
+    assert abs(mn - data.min()) <= 1e-6 and abs(mx - data.max()) <= 1e-6
+    assert np.all(np.isneginf(ln[~nz]))
+    pixels = np.zeros(int(nz.sum()), np.uint8)
+    row = (ln[nz] - np.float32(mn)) / (np.float32(mx) - np.float32(mn)) * 255
+    assert row.dtype == np.float32
+    pixels[:] = row                                                     # the viewer's store: C truncation
+    assert np.array_equal(u8[nz], pixels) and (u8[~nz] == 0).all()
+    assert u8.max() == 255 and u8.min() == 0
