@@ -44,6 +44,7 @@ template <> struct W32<15> { static constexpr float c = -RO_C1, s = RO_C7; };
 // (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32, two flops per lane per issue slot), the
 // .yx / .xx swizzles fold into op_sel, and constant pairs live in SGPRs.
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 // a * w for a twiddle held in registers: (ax wx - ay wy, ay wx + ax wy) in two packed ops.
 // hipcc builds the (-wy, wy) operand with an extra v_xor; the VOP3P modifiers do it for free:

@@ -14,7 +14,8 @@ namespace ro {
 
 struct StftArgs {
     const void   *iq;          // sample 0 of the stream (device)
-    const float  *window;      // bins floats (device)
+    const float  *window;      // bins floats (device), natural order
+    const float  *window_k;    // the same coefficients in kernel order (stft_window_layout)
     const float2 *twiddles;    // per-stage tables (device), see stft_fill_twiddles
     float        *rows_out;    // rows x row_stride
     int64_t       first_row;
@@ -80,6 +81,7 @@ hipError_t launch_big_pass(int radix, bool first, bool last, int fmt, const BigA
 bool       stft_supported(int bins);
 int        stft_twiddle_count(int bins);          // float2 entries, <0 if unsupported
 bool       stft_radices(int bins, int radices[4]);
+bool       stft_window_layout(int bins, const float *w, float *out);   // host: bins floats -> bins floats
 hipError_t launch_stft(int bins, int fmt, const StftArgs &a, hipStream_t s);
 hipError_t launch_scan(const ScanArgs &a, hipStream_t s);
 hipError_t launch_tile(const TileArgs &a, hipStream_t s);

@@ -24,9 +24,9 @@
 #ifndef RO_ABLATE
 #define RO_ABLATE 0
 #endif
-// cache policy of the row stores (gfx950 aux bits: 1 = sc0, 2 = nt, 16 = sc1)
+// cache policy of the row stores (gfx950 aux bits: 1 = sc0, 2 = nt, 16 = sc1); nt measured 2.5 % faster (rows are write-once)
 #ifndef RO_STORE_AUX
-#define RO_STORE_AUX 0
+#define RO_STORE_AUX 2
 #endif
 // Diagnostic only: -DRO_STAMPS=1 accumulates s_memtime deltas per phase of the row loop and
 // lets lane 0 of wave 0 of every workgroup write them to StftArgs::stamps (9 x u64 per
@@ -37,6 +37,15 @@
 // 16-byte sample loads shared by lane pairs (see load_row); 0 = one 8-byte load per sample
 #ifndef RO_PAIRED_LOADS
 #define RO_PAIRED_LOADS 1
+#endif
+// window coefficients in the kernel's own order (16-byte loads, see stft_window_layout); 0 = natural table, 8-byte loads
+#ifndef RO_WIN_PERM
+#define RO_WIN_PERM 1
+#endif
+// N = 32768 plan: lanes l and l+32 share their sample columns and trade halves with v_permlane32_swap_b32
+// (1 VALU op per register) instead of lanes l and l^1 with a DPP move + select (2 ops); needs RO_USE_ADDTID
+#ifndef RO_SWAP32
+#define RO_SWAP32 1
 #endif
 // LDS exchange of the N = 32768 plan through ds_write_addtid_b32 (1) or plain ds_write_b32 (0)
 #ifndef RO_USE_ADDTID
@@ -75,6 +84,28 @@ struct Plan {
     static_assert(R0 * R1 * R2 * R3 == N, "radices must multiply to N");
     static_assert(P % R0 == 0 && P % R1 == 0 && P % R2 == 0 && P % R3 == 0, "radix must divide P");
 };
+
+// the N = 32768 plan exchanges through ds_write_addtid_b32 (see exchange_addtid)
+template <class PL> constexpr bool plan_addtid()
+{
+    return RO_USE_ADDTID && PL::N == 32768 && PL::T == 1024 && PL::P == 32 && PL::R0 == 32 && PL::R1 == 32 &&
+           PL::R2 == 32 && PL::R3 == 1 && PL::SPLIT;
+}
+template <class PL> constexpr bool plan_swap32() { return plan_addtid<PL>() && RO_SWAP32 && RO_PAIRED_LOADS; }
+
+// Paired sample loads: which stage-0 column a thread transforms, and the first sample it fetches.
+// Lanes l, l^1 (default) or l, l+32 (swap32) fetch the SAME two adjacent columns with 16-byte loads, one lane
+// for legs [0, R0/2), the other for legs [R0/2, R0), then trade halves so each ends up with one whole column.
+template <class PL> __host__ __device__ constexpr int plan_column(int tid)
+{
+    if constexpr (plan_swap32<PL>()) return (tid & ~63) + 2 * (tid & 31) + ((tid >> 5) & 1);
+    else return tid;
+}
+template <class PL> __host__ __device__ constexpr int plan_pair_off(int tid)
+{
+    const int c = plan_column<PL>(tid);
+    return (c & ~1) + (c & 1) * (PL::R0 / 2) * (PL::N / PL::R0);
+}
 
 // ---------------------------------------------------------------------------
 // stage helpers (all indices compile-time after unrolling -> v[] stays in VGPRs)
@@ -324,21 +355,27 @@ template <int ROWB, typename F> __device__ __forceinline__ void addtid_scatter32
 }
 
 // XCH = 1: between stage 0 and 1, XCH = 2: between stage 1 and 2   (N = 32768, T = 1024, radix 32 everywhere)
-template <int XCH, typename ST>
+// With swap32 pairing the stage-0 thread at position t of a row holds column (t&~63) + 2(t&31) + ((t>>5)&1), so
+// column j = 32 r' + q sits at 64 (r'>>1) + 16 (r'&1) + 32 (q&1) + (q>>1): still one base + a literal per slot.
+template <int XCH, bool SWAP32, typename ST>
 __device__ __forceinline__ void exchange_addtid(void *smem, v2f (&v)[32], int tid, ST sub)
 {
     if constexpr (RO_ABLATE & 4) return;
     constexpr int ROW = XCH == 1 ? 1025 : 1024;                   // floats per register-slot row of the image
+    constexpr bool PERM = XCH == 1 && SWAP32;
     const float *lds = reinterpret_cast<const float *>(smem);
     const unsigned wave_bytes = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6) * 256u;
-    const float *g = lds + (XCH == 1 ? (tid & 31) * 1025 + (tid >> 5) : (tid >> 5) * 1024 + (tid & 31));
+    const int q = tid >> 5;
+    const float *g = lds + (XCH == 1 ? (tid & 31) * 1025 + (PERM ? 32 * (q & 1) + (q >> 1) : q)
+                                     : (tid >> 5) * 1024 + (tid & 31));
+    auto goff = [](int r) constexpr { return PERM ? 64 * (r >> 1) + 16 * (r & 1) : 32 * r; };
     addtid_scatter32<ROW * 4>(wave_bytes, [&](int q) { return v[bitrev<32>(q)].x; });
     sub(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     sub(1);
 #pragma unroll
-    for (int r = 0; r < 32; ++r) v[r].x = g[32 * r];
+    for (int r = 0; r < 32; ++r) v[r].x = g[goff(r)];
     sub(2);
     __syncthreads();
     sub(3);
@@ -348,7 +385,7 @@ __device__ __forceinline__ void exchange_addtid(void *smem, v2f (&v)[32], int ti
     __builtin_amdgcn_s_barrier();
     sub(1);
 #pragma unroll
-    for (int r = 0; r < 32; ++r) v[r].y = g[32 * r];
+    for (int r = 0; r < 32; ++r) v[r].y = g[goff(r)];
     sub(2);
     __syncthreads();
     sub(3);
@@ -399,9 +436,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
 {
     constexpr int N = PL::N, T = PL::T, P = PL::P;
     constexpr int R0 = PL::R0;
-    // the N = 32768 plan exchanges through ds_write_addtid_b32 (see exchange_addtid)
-    constexpr bool ADDTID = RO_USE_ADDTID && N == 32768 && T == 1024 && P == 32 && PL::R0 == 32 && PL::R1 == 32 &&
-                            PL::R2 == 32 && PL::R3 == 1 && PL::SPLIT;
+    constexpr bool ADDTID = plan_addtid<PL>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using S = Sample<FMT>;
 
@@ -441,7 +476,8 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
     // two lanes puts every sample into its natural slot.
     constexpr bool PAIRED = (P == R0) && (R0 % 2 == 0) && RO_PAIRED_LOADS;
     constexpr int H = R0 / 2;
-    const int pair_off = (tid & ~1) + (tid & 1) * H * (N / R0);      // first sample this lane fetches
+    constexpr bool SWAP32 = plan_swap32<PL>();
+    const int pair_off = plan_pair_off<PL>(tid);                     // first sample this lane fetches
     auto load_row = [&](const __amdgpu_buffer_rsrc_t &rs) {
         if constexpr (PAIRED) {
 #pragma unroll
@@ -477,13 +513,26 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
     stamp(-1);
     // window coefficients of the row about to be transformed (fetched in the previous
     // epilogue / the prologue, all at once: P floats)
+    constexpr bool WPERM = PAIRED && RO_WIN_PERM;
     constexpr int NW = PAIRED ? H : P;
     using wtype = std::conditional_t<PAIRED, v2f, float>;
-    wtype w[NW];
+    wtype w[WPERM ? 1 : NW];
+    v4f w4[WPERM ? NW / 2 : 1];        // kernel-order table: legs 2q, 2q+1 as {even, odd, even, odd} column coefficients
     // first..last-1 of the NW coefficient registers
     auto load_window = [&](const __amdgpu_buffer_rsrc_t &rs_win, auto first_c, auto last_c) {
         constexpr int first = decltype(first_c)::value, last = decltype(last_c)::value;
-        if constexpr (PAIRED) {
+        if constexpr (WPERM) {
+            // kernel-order table: 16 bytes per lane = the coefficient pairs of legs k, k+1
+            static_assert(first % 2 == 0 && last % 2 == 0, "window chunks are pairs of legs");
+#pragma unroll
+            for (int k = first; k < last; k += 2) {
+                if constexpr (RO_ABLATE & 2) w4[k / 2] = (v4f){0.5f, 0.5f, 0.5f, 0.5f};
+                else {
+                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_win, tid * 16, (k / 2) * T * 16, 0);
+                    w4[k / 2] = (v4f){__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
+                }
+            }
+        } else if constexpr (PAIRED) {
 #pragma unroll
             for (int k = first; k < last; ++k) {
                 if constexpr (RO_ABLATE & 2) w[k] = (v2f){0.5f, 0.5f};
@@ -500,11 +549,12 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
     // Coefficients [0, NW_EARLY) of the next row are requested right after the window stage
     // (their registers are free for the whole transform, so these loads cost nothing); the
     // rest would not fit the 128-VGPR budget next to the butterflies and follows in the epilogue.
-    constexpr int NW_EARLY = (NW * RO_WIN_EARLY_PCT) / 100;
+    constexpr int NW_EARLY = ((NW * RO_WIN_EARLY_PCT) / 100) & ~1;
     using c0 = std::integral_constant<int, 0>;
     using cE = std::integral_constant<int, NW_EARLY>;
     using cN = std::integral_constant<int, NW>;
-    load_window(make_rsrc(a.window, N * 4), c0{}, cN{});
+    const float *win_tab = WPERM ? a.window_k : a.window;
+    load_window(make_rsrc(win_tab, N * 4), c0{}, cN{});
 
     for (;;) {
         // ---- stage 0: window.  Coefficients arrive in chunks of WIN_CHUNK, two chunks in
@@ -520,8 +570,25 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
                 const bool odd = tid & 1;
 #pragma unroll
                 for (int k = 0; k < H; ++k) {
-                    const v2f e = v[k] * w[k].xx;                  // even column, leg k (H+k on odd lanes)
-                    const v2f o = v[H + k] * w[k].yy;              // odd column
+                    v2f we, wo;                                    // coefficient of the even / odd column, both halves
+                    if constexpr (WPERM) {
+                        we = (k & 1) ? w4[k / 2].zz : w4[k / 2].xx;
+                        wo = (k & 1) ? w4[k / 2].ww : w4[k / 2].yy;
+                    } else {
+                        we = w[k].xx;
+                        wo = w[k].yy;
+                    }
+                    const v2f e = v[k] * we;                       // even column, leg k (H+k on odd lanes)
+                    const v2f o = v[H + k] * wo;                   // odd column
+                    if constexpr (SWAP32) {
+                        // lanes 0..31 hold legs k, lanes 32..63 legs H+k of both columns: the upper half of slot k
+                        // trades places with the lower half of slot H+k (v_permlane32_swap_b32)
+                        const auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(e.x), __float_as_uint(o.x), false, false);
+                        const auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(e.y), __float_as_uint(o.y), false, false);
+                        v[k] = (v2f){__uint_as_float(rx[0]), __uint_as_float(ry[0])};
+                        v[H + k] = (v2f){__uint_as_float(rx[1]), __uint_as_float(ry[1])};
+                        continue;
+                    }
                     // even lane keeps e in slot k and takes the partner's e (leg H+k) into slot H+k;
                     // odd lane keeps o in slot H+k and takes the partner's o (leg k) into slot k.
                     const v2f pe = (v2f){dpp_quad<0xB1>(e.x), dpp_quad<0xB1>(e.y)};
@@ -537,7 +604,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         // The coefficients for the NEXT row are requested right away: their registers are free
         // from here on and the loads overlap the whole transform instead of the epilogue's
         // memory burst.  (Unconditional: the same table every row.)
-        load_window(make_rsrc(a.window, N * 4), c0{}, cE{});
+        load_window(make_rsrc(win_tab, N * 4), c0{}, cE{});
         stamp(0);                                   // window multiply (+ wait for samples)
 
         v2f tw1[PL::R1 > 1 ? P / PL::R1 : 1][TW_SET];
@@ -547,7 +614,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
 
         // ---- stage 1
         if constexpr (PL::R1 > 1) {
-            if constexpr (ADDTID) exchange_addtid<1>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
+            if constexpr (ADDTID) exchange_addtid<1, SWAP32>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             else exchange<PL, PL::R0, 1, PL::R1>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             stamp(3);                               // exchange 1
             tw_apply<P, PL::R1>(v, tw1);
@@ -558,7 +625,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         if constexpr (PL::R2 > 1) {
             v2f tw2[P / PL::R2][TW_SET];
             tw_prefetch<P, T, PL::R2, PL::NS2, PL::TW2>(tw2, rs_tw, tid);
-            if constexpr (ADDTID) exchange_addtid<2>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
+            if constexpr (ADDTID) exchange_addtid<2, SWAP32>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             else exchange<PL, PL::R1, PL::NS1, PL::R2>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             stamp(5);                               // exchange 2
             tw_apply<P, PL::R2>(v, tw2);
@@ -604,7 +671,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
                            has_next ? N * S::BYTES : 0));
         // unconditional (zero-sized descriptor after the last row): a branch here would keep the
         // old coefficients alive next to the new ones
-        load_window(make_rsrc(a.window, has_next ? N * 4 : 0), cE{}, cN{});
+        load_window(make_rsrc(win_tab, has_next ? N * 4 : 0), cE{}, cN{});
         stamp(7);                                   // next-row loads issued
         __syncthreads();
         stamp(11);                                  // barrier 1
@@ -894,6 +961,14 @@ template <class PL, int FMT> static hipError_t launch_plan(const StftArgs &a, hi
     int64_t slots = resident / 8;                       // workgroups per XCD
     if (slots < 1) slots = 1;
     if (slots > per_xcd) slots = per_xcd;
+    {
+        static int cap = -1;                           // experiment knob: RO_SLOTS=<workgroups per XCD>
+        if (cap < 0) {
+            const char *e = getenv("RO_SLOTS");
+            cap = e ? atoi(e) : 0;
+        }
+        if (cap > 0 && slots > cap) slots = cap;
+    }
     const unsigned grid = (unsigned)(slots * 8);
     StftArgs b = a;
     {
@@ -947,6 +1022,38 @@ int stft_twiddle_count(int bins)
     case 512:   return Plan512::TW_TOTAL;
     case 256:   return Plan256::TW_TOTAL;
     default:    return -1;
+    }
+}
+
+// The window table in the order the kernel consumes it (StftArgs::window_k): thread `tid` of the plan reads
+// 16 bytes at ((k/2)*T + tid)*16 = {w[c + k*S], w[c+1 + k*S], w[c + (k+1)*S], w[c+1 + (k+1)*S]} with
+// S = N/R0 and c = the first sample it fetches (plan_pair_off), k = 0, 2, .. R0/2-2.
+template <class PL> static void window_layout(const float *w, float *out)
+{
+    constexpr int N = PL::N, T = PL::T, R0 = PL::R0, H = R0 / 2, S = N / R0;
+    static_assert(PL::P == R0 && H % 2 == 0, "paired plan");
+    for (int tid = 0; tid < T; ++tid) {
+        const int c = plan_pair_off<PL>(tid);
+        for (int k = 0; k < H; ++k) {
+            float *o = out + ((size_t)(k / 2) * T + tid) * 4 + 2 * (k % 2);
+            o[0] = w[c + k * S];
+            o[1] = w[c + 1 + k * S];
+        }
+    }
+}
+
+bool stft_window_layout(int bins, const float *w, float *out)
+{
+    switch (bins) {
+    case 32768: window_layout<Plan32768>(w, out); return true;
+    case 16384: window_layout<Plan16384>(w, out); return true;
+    case 8192:  window_layout<Plan8192>(w, out);  return true;
+    case 4096:  window_layout<Plan4096>(w, out);  return true;
+    case 2048:  window_layout<Plan2048>(w, out);  return true;
+    case 1024:  window_layout<Plan1024>(w, out);  return true;
+    case 512:   window_layout<Plan512>(w, out);   return true;
+    case 256:   window_layout<Plan256>(w, out);   return true;
+    default:    return false;
     }
 }
 

@@ -120,6 +120,7 @@ struct ro_stft {
     std::string device_name;
     std::vector<float> window;
     float *d_window = nullptr;
+    float *d_window_k = nullptr;       // kernel-order copy (single-pass plans)
     float2 *d_twiddles = nullptr;
     hipStream_t stream = nullptr;
 
@@ -197,6 +198,7 @@ ro::StftArgs make_stft_args(const ro_stft *h, const void *d_iq, int64_t first_ro
     ro::StftArgs a{};
     a.iq = d_iq;
     a.window = h->d_window;
+    a.window_k = h->d_window_k;
     a.twiddles = h->d_twiddles;
     a.rows_out = d_rows;
     a.first_row = first_row;
@@ -534,6 +536,15 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg, ro_stft_t **out)
     CREATE_TRY(hipMalloc(&h->d_ln_keys, 2 * sizeof(unsigned)));
     CREATE_TRY(hipMalloc(&h->d_twiddles, sizeof(float2) * std::max<size_t>(tw.size(), 1)));
     CREATE_TRY(hipMemcpy(h->d_window, h->window.data(), sizeof(float) * h->bins, hipMemcpyHostToDevice));
+    if (!h->big) {
+        std::vector<float> wk((size_t)h->bins);
+        if (!ro::stft_window_layout(h->bins, h->window.data(), wk.data())) {
+            ro_stft_destroy(h);
+            return fail(RO_ERR_UNSUPPORTED, "no window layout for bins=%d", h->bins);
+        }
+        CREATE_TRY(hipMalloc(&h->d_window_k, sizeof(float) * h->bins));
+        CREATE_TRY(hipMemcpy(h->d_window_k, wk.data(), sizeof(float) * h->bins, hipMemcpyHostToDevice));
+    }
     if (!tw.empty())
         CREATE_TRY(hipMemcpy(h->d_twiddles, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice));
     if (h->big) {
@@ -556,6 +567,7 @@ extern "C" int ro_stft_destroy(ro_stft_t *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->d_window) (void)hipFree(h->d_window);
+    if (h->d_window_k) (void)hipFree(h->d_window_k);
     if (h->d_ln_keys) (void)hipFree(h->d_ln_keys);
     if (h->d_twiddles) (void)hipFree(h->d_twiddles);
     if (h->d_iq) (void)hipFree(h->d_iq);

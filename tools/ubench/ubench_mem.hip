@@ -35,6 +35,21 @@ __global__ __launch_bounds__(1024) void load_k(const float *in, float *sink, int
     }
     if (acc.x == 0x12345678u && acc.y == 77u) sink[tid] = 1.f;
 }
+__global__ __launch_bounds__(1024) void load32_k(const float *in, float *sink, int rows_per_wg)
+{
+    const int tid = threadIdx.x;
+    unsigned acc = 0;
+    __amdgpu_buffer_rsrc_t r = rsrc(in, 32768 * 4);
+    for (int i = 0; i < rows_per_wg; ++i) {
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            unsigned t = __builtin_amdgcn_raw_buffer_load_b32(r, tid * 4, q * 4096, 0);
+            acc ^= t;
+        }
+        asm volatile("" ::: "memory");
+    }
+    if (acc == 0x12345678u) sink[tid] = 1.f;
+}
 int main()
 {
     const int total_rows = 16384;
@@ -67,6 +82,31 @@ int main()
         float ms; hipEventElapsedTime(&ms, e0, e1);
         double bytes = (double)g * rpw * 262144.0;
         printf("load hop=%5d floats grid %4d: %.3f ms  %.2f TB/s total  %.1f GB/s per WG  (%.1f B/clk/WG)\n", hop, g, ms,
+               bytes / ms / 1e9, bytes / ms / 1e6 / g, bytes / ms / 1e6 / g / 2.1);
+    }
+    // L2-resident: every workgroup re-reads the same 256 KiB (hop 0), and a 128 KiB table as b32 loads (the window shape)
+    for (int g : grids) {
+        const int rpw = 64;
+        for (int pass = 0; pass < 2; ++pass) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(load_k, dim3(g), dim3(1024), 0, 0, in, sink, rpw, 1, 0);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+        }
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        double bytes = (double)g * rpw * 262144.0;
+        printf("load same 256 KiB (L2 hits) grid %4d: %.3f ms  %.2f TB/s total  %.1f GB/s per WG  (%.1f B/clk/WG)\n", g, ms,
+               bytes / ms / 1e9, bytes / ms / 1e6 / g, bytes / ms / 1e6 / g / 2.1);
+    }
+    for (int g : grids) {
+        const int rpw = 64;
+        for (int pass = 0; pass < 2; ++pass) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(load32_k, dim3(g), dim3(1024), 0, 0, in, sink, rpw);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+        }
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        double bytes = (double)g * rpw * 131072.0;
+        printf("load same 128 KiB as b32 (window shape) grid %4d: %.3f ms  %.2f TB/s total  %.1f GB/s per WG  (%.1f B/clk/WG)\n", g, ms,
                bytes / ms / 1e9, bytes / ms / 1e6 / g, bytes / ms / 1e6 / g / 2.1);
     }
     return 0;
