@@ -16,7 +16,8 @@ struct StftArgs {
     const void   *iq;          // sample 0 of the stream (device)
     const float  *window;      // bins floats (device), natural order
     const float  *window_k;    // the same coefficients in kernel order (stft_window_layout)
-    const float2 *twiddles;    // per-stage tables (device), see stft_fill_twiddles
+    const float2 *twiddles;    // per-stage tables (device), see build_twiddles
+    const float4 *twiddles_k;  // radix-16/32 stages repacked for 16-byte loads (stft_pack_twiddles)
     float        *rows_out;    // rows x row_stride
     int64_t       first_row;
     int64_t       rows;
@@ -81,6 +82,8 @@ hipError_t launch_big_pass(int radix, bool first, bool last, int fmt, const BigA
 bool       stft_supported(int bins);
 int        stft_twiddle_count(int bins);          // float2 entries, <0 if unsupported
 bool       stft_radices(int bins, int radices[4]);
+int        stft_packed_twiddle_count(int bins);   // float4 units of StftArgs::twiddles_k, <0 if unsupported
+bool       stft_pack_twiddles(int bins, const float2 *tw, float4 *out);
 bool       stft_window_layout(int bins, const float *w, float *out);   // host: bins floats -> bins floats
 hipError_t launch_stft(int bins, int fmt, const StftArgs &a, hipStream_t s);
 hipError_t launch_scan(const ScanArgs &a, hipStream_t s);

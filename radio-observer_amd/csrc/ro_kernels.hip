@@ -47,6 +47,36 @@
 #ifndef RO_SWAP32
 #define RO_SWAP32 1
 #endif
+// twiddles of the radix-16/32 stages from a packed table (16-byte loads: {w1,w2} {w3,w4} {w8,w12} {w16,-} per
+// butterfly); 0 = 8-byte loads from the generic per-stage table
+#ifndef RO_TW_PACKED
+#define RO_TW_PACKED 1
+#endif
+// N = 32768 plan: the barrier that closes an exchange (all gathers done before the LDS is written again) sits in
+// front of the NEXT LDS writer instead of behind the gather, so a wave starts its twiddles/butterflies on the
+// values that have arrived while the rest of the gather is still in flight.  0 = barrier right after the gather.
+#ifndef RO_LATE_BARRIER
+#define RO_LATE_BARRIER 0
+#endif
+// N = 32768 plan: the row leaves through wave-private LDS staging (no workgroup barrier in the epilogue: every
+// wave reads back only what it wrote itself); 0 = the generic epilogue with two barriers.  Needs RO_USE_ADDTID.
+#ifndef RO_WAVE_EPILOGUE
+#define RO_WAVE_EPILOGUE 0
+#endif
+// The hop new samples of the workgroup's NEXT row are touched (one dword per 64 bytes, value unused) right after
+// the window stage, a whole transform before the epilogue asks for them: they come from HBM, every other byte of
+// the row from L2, and that one miss latency sat on the critical path of every row.  0 = no prefetch.
+#ifndef RO_PREFETCH_NEXT
+#define RO_PREFETCH_NEXT 1
+#endif
+// EXPERIMENT (results wrong by design): RO_EXP_SKIP = number of the 16 sample chunks NOT loaded in the epilogue,
+// RO_EXP_DIRECT = 1 stores the row with dword stores straight from registers (no LDS staging)
+#ifndef RO_EXP_SKIP
+#define RO_EXP_SKIP 0
+#endif
+#ifndef RO_EXP_DIRECT
+#define RO_EXP_DIRECT 0
+#endif
 // LDS exchange of the N = 32768 plan through ds_write_addtid_b32 (1) or plain ds_write_b32 (0)
 #ifndef RO_USE_ADDTID
 #define RO_USE_ADDTID 1
@@ -79,6 +109,12 @@ struct Plan {
     static constexpr int TW2 = TW1 + (R1 > 1 ? (R1 - 1) * NS1 : 0);
     static constexpr int TW3 = TW2 + (R2 > 1 ? (R2 - 1) * NS2 : 0);
     static constexpr int TW_TOTAL = TW3 + (R3 > 1 ? (R3 - 1) * NS3 : 0);
+    // packed table (16-byte units): stage s with radix >= 16 holds PKQ(R) x NS units, unit q*NS + k = the q-th pair
+    static constexpr int pkq(int r) { return r == 32 ? 4 : (r == 16 ? 3 : 0); }
+    static constexpr int PK1 = 0;
+    static constexpr int PK2 = PK1 + pkq(R1) * NS1;
+    static constexpr int PK3 = PK2 + pkq(R2) * NS2;
+    static constexpr int PK_TOTAL = PK3 + pkq(R3) * NS3;
     static constexpr int LDS_ELEMS = N + N / 32;                    // padded
     static constexpr int LDS_BYTES = LDS_ELEMS * (SPLIT ? 4 : 8);
     static_assert(R0 * R1 * R2 * R3 == N, "radices must multiply to N");
@@ -179,14 +215,26 @@ __device__ __forceinline__ v2f tw_load(__amdgpu_buffer_rsrc_t tw, int koff, int 
 // of the stage and land while the workgroup sits in its barriers.
 constexpr int TW_SET = 7;     // twiddles held per butterfly: R=32: 7, R=16: 6, R<=8: R-1
 
-template <int P, int T, int R, int NS, int OFF>
-__device__ __forceinline__ void tw_prefetch(v2f (&t)[P / R][TW_SET], __amdgpu_buffer_rsrc_t tw, int tid)
+template <int P, int T, int R, int NS, int OFF, int PK>
+__device__ __forceinline__ void tw_prefetch(v2f (&t)[P / R][TW_SET], __amdgpu_buffer_rsrc_t tw,
+                                            __amdgpu_buffer_rsrc_t twk, int tid)
 {
     static_assert(R == 32 || R == 16 || R <= 8, "unsupported radix");
 #pragma unroll
     for (int b = 0; b < P / R; ++b) {
         const int koff = ((tid + T * b) & (NS - 1)) * 8;
-        if constexpr (R >= 16) {
+        if constexpr (R >= 16 && RO_TW_PACKED && !(RO_ABLATE & 1)) {
+#pragma unroll
+            for (int q = 0; q < (R == 32 ? 4 : 3); ++q) {
+                const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(twk, koff * 2, (PK + q * NS) * 16, 0);
+                const v2f lo = (v2f){__uint_as_float(u.x), __uint_as_float(u.y)};
+                const v2f hi = (v2f){__uint_as_float(u.z), __uint_as_float(u.w)};
+                if (q == 0) { t[b][0] = lo; t[b][1] = hi; }        // w1, w2
+                else if (q == 1) { t[b][2] = lo; t[b][3] = hi; }   // w3, w4
+                else if (q == 2) { t[b][4] = lo; t[b][5] = hi; }   // w8, w12
+                else t[b][6] = lo;                                 // w16
+            }
+        } else if constexpr (R >= 16) {
 #pragma unroll
             for (int c = 1; c < 4; ++c) t[b][c - 1] = tw_load(tw, koff, OFF + (c - 1) * NS);
 #pragma unroll
@@ -369,13 +417,20 @@ __device__ __forceinline__ void exchange_addtid(void *smem, v2f (&v)[32], int ti
     const float *g = lds + (XCH == 1 ? (tid & 31) * 1025 + (PERM ? 32 * (q & 1) + (q >> 1) : q)
                                      : (tid >> 5) * 1024 + (tid & 31));
     auto goff = [](int r) constexpr { return PERM ? 64 * (r >> 1) + 16 * (r & 1) : 32 * r; };
+    // the previous row's epilogue staged its magnitudes in this LDS without a closing barrier (wave-private
+    // pieces): every wave must be done reading its own before anyone's scatter lands on them
+    if constexpr ((XCH == 1 && RO_WAVE_EPILOGUE) || (XCH == 2 && RO_LATE_BARRIER)) __syncthreads();
+    // volatile: keeps the 32 gathers single ds_read_b32 -- merged into ds_read2_b32 they come back as register
+    // pairs of one plane and cost a v_mov each to interleave with the other plane (96 VALU ops per row)
+    typedef const volatile __attribute__((address_space(3))) float lds_vfloat;
+    lds_vfloat *gv = (lds_vfloat *)g;
     addtid_scatter32<ROW * 4>(wave_bytes, [&](int q) { return v[bitrev<32>(q)].x; });
     sub(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     sub(1);
 #pragma unroll
-    for (int r = 0; r < 32; ++r) v[r].x = g[goff(r)];
+    for (int r = 0; r < 32; ++r) v[r].x = gv[goff(r)];
     sub(2);
     __syncthreads();
     sub(3);
@@ -385,9 +440,9 @@ __device__ __forceinline__ void exchange_addtid(void *smem, v2f (&v)[32], int ti
     __builtin_amdgcn_s_barrier();
     sub(1);
 #pragma unroll
-    for (int r = 0; r < 32; ++r) v[r].y = g[goff(r)];
+    for (int r = 0; r < 32; ++r) v[r].y = gv[goff(r)];
     sub(2);
-    __syncthreads();
+    if constexpr (!RO_LATE_BARRIER) __syncthreads();
     sub(3);
 }
 
@@ -463,6 +518,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
 
     const int tid = threadIdx.x;
     const __amdgpu_buffer_rsrc_t rs_tw = make_rsrc(a.twiddles, PL::TW_TOTAL * 8);
+    const __amdgpu_buffer_rsrc_t rs_twk = make_rsrc(a.twiddles_k, PL::PK_TOTAL * 16);
     const char *iq = reinterpret_cast<const char *>(a.iq);
 
     v2f v[P];
@@ -482,7 +538,8 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         if constexpr (PAIRED) {
 #pragma unroll
             for (int k = 0; k < H; ++k) {
-                if constexpr (RO_ABLATE & 32) { v[k] = (v2f){(float)(tid + k), 1.0f}; v[H + k] = v[k]; }
+                if constexpr ((RO_ABLATE & 32) != 0) { v[k] = (v2f){(float)(tid + k), 1.0f}; v[H + k] = v[k]; }
+                else if (k < RO_EXP_SKIP) { v[k] = (v2f){(float)(tid + k), 1.0f}; v[H + k] = v[k]; }
                 else S::load_pair(rs, pair_off * S::BYTES, k * (N / R0) * S::BYTES, v[k], v[H + k]);
             }
         } else {
@@ -605,11 +662,22 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         // from here on and the loads overlap the whole transform instead of the epilogue's
         // memory burst.  (Unconditional: the same table every row.)
         load_window(make_rsrc(win_tab, N * 4), c0{}, cE{});
+        const int64_t next = row + stride;
+        const bool has_next = next < xcd_end;
+        unsigned touched0 = 0, touched1 = 0;
+        if constexpr (RO_PREFETCH_NEXT) {
+            // samples [next*hop + N - hop, next*hop + N) = hop * BYTES bytes: one dword per 128-byte line, two per
+            // thread (reaches hop = N; whatever lies past the descriptor's end costs nothing)
+            const int64_t s0 = (a.first_row + (has_next ? next : row)) * (int64_t)a.hop + (N - a.hop);
+            const __amdgpu_buffer_rsrc_t rs_new = make_rsrc(iq + s0 * S::BYTES, has_next ? a.hop * S::BYTES : 0);
+            touched0 = __builtin_amdgcn_raw_buffer_load_b32(rs_new, tid * 128, 0, 0);
+            touched1 = __builtin_amdgcn_raw_buffer_load_b32(rs_new, tid * 128, T * 128, 0);
+        }
         stamp(0);                                   // window multiply (+ wait for samples)
 
         v2f tw1[PL::R1 > 1 ? P / PL::R1 : 1][TW_SET];
         butterflies<P, R0>(v);
-        if constexpr (PL::R1 > 1) tw_prefetch<P, T, PL::R1, PL::NS1, PL::TW1>(tw1, rs_tw, tid);
+        if constexpr (PL::R1 > 1) tw_prefetch<P, T, PL::R1, PL::NS1, PL::TW1, PL::PK1>(tw1, rs_tw, rs_twk, tid);
         stamp(2);                                   // butterflies 0
 
         // ---- stage 1
@@ -624,7 +692,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         // ---- stage 2
         if constexpr (PL::R2 > 1) {
             v2f tw2[P / PL::R2][TW_SET];
-            tw_prefetch<P, T, PL::R2, PL::NS2, PL::TW2>(tw2, rs_tw, tid);
+            tw_prefetch<P, T, PL::R2, PL::NS2, PL::TW2, PL::PK2>(tw2, rs_tw, rs_twk, tid);
             if constexpr (ADDTID) exchange_addtid<2, SWAP32>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             else exchange<PL, PL::R1, PL::NS1, PL::R2>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             stamp(5);                               // exchange 2
@@ -635,7 +703,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         // ---- stage 3
         if constexpr (PL::R3 > 1) {
             v2f tw3[P / PL::R3][TW_SET];
-            tw_prefetch<P, T, PL::R3, PL::NS3, PL::TW3>(tw3, rs_tw, tid);
+            tw_prefetch<P, T, PL::R3, PL::NS3, PL::TW3, PL::PK3>(tw3, rs_tw, rs_twk, tid);
             exchange<PL, PL::R2, PL::NS2, PL::R3>(smem, v, tid, [](int) {});
             tw_apply<P, PL::R3>(v, tw3);
             butterflies<P, PL::R3>(v);
@@ -649,8 +717,46 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         // requested into the freed registers, and only then the row is read back 16 bytes per
         // lane and stored -- 1 KiB per wave-instruction, the stores being the LAST thing in the
         // VMEM queue.
-        const int64_t next = row + stride;
-        const bool has_next = next < xcd_end;
+        if constexpr (RO_PREFETCH_NEXT) asm volatile("" ::"v"(touched0), "v"(touched1));   // keeps the touches alive
+        if constexpr (ADDTID && RO_WAVE_EPILOGUE) {
+            // Wave-private staging.  Slot q of lane `tid` is column tid + 1024 q of the transform; the wave writes
+            // its 32 x 256 bytes lane-linearly into image[q][tid] (ds_write_addtid_b32) and reads the SAME bytes
+            // back 16 per lane -- lanes 16a..16a+15 take the 256-byte piece of slot 4i+a -- so one store
+            // instruction carries four 256-byte pieces of the row.  No other wave's data is touched: no barrier,
+            // each wave goes on to the next row's window stage as soon as its own loads are in flight.
+            float m[32];
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                const v2f x = v[bitrev<32>(r)];
+                const v2f sq = x * x;
+                m[r] = __builtin_amdgcn_sqrtf(sq.x + sq.y);      // v_sqrt_f32, 1 ulp
+            }
+            const unsigned wave_bytes = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6) * 256u;
+            if constexpr (!RO_EXP_DIRECT) addtid_scatter32<4096>(wave_bytes, [&](int q) { return m[q]; });
+            stamp(10);                              // magnitudes -> LDS writes issued
+            load_row(make_rsrc(iq + (a.first_row + (has_next ? next : row)) * (int64_t)a.hop * S::BYTES,
+                               has_next ? N * S::BYTES : 0));
+            load_window(make_rsrc(win_tab, has_next ? N * 4 : 0), cE{}, cN{});
+            stamp(7);                               // next-row loads issued
+            const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(a.rows_out + row * a.row_stride, N * 4);
+            const int lane = tid & 63;
+            const char *piece = smem + (lane >> 4) * 4096 + (tid >> 6) * 256 + (lane & 15) * 16;
+            const int voff = ((tid & ~63) + 4 * (lane & 15) + 1024 * (lane >> 4)) * 4;
+            if constexpr (RO_EXP_DIRECT) {
+#pragma unroll
+                for (int r = 0; r < 32; ++r) buf_store_f(m[r], rs_out, tid * 4, ((1024 * r + N / 2) & (N - 1)) * 4);
+            } else
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 x = *reinterpret_cast<const float4 *>(piece + i * 4 * 4096);
+                const int soff = ((4096 * i + N / 2) & (N - 1)) * 4;     // fft-shift: column k goes to (k + N/2) mod N
+                if constexpr (RO_ABLATE & 16) asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
+                else buf_store_f4(x.x, x.y, x.z, x.w, rs_out, voff, soff);
+                if (i & 1) asm volatile("" ::: "memory");
+            }
+            stamp(12);                              // LDS read-back + row stores issued
+        } else {
+        if constexpr (ADDTID && RO_LATE_BARRIER) __syncthreads();   // closes exchange 2 (see RO_LATE_BARRIER)
         {
             float *lds_m = reinterpret_cast<float *>(smem);
 #pragma unroll
@@ -691,6 +797,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         stamp(12);                                  // LDS read-back + row stores issued
         __syncthreads();                            // LDS is reused by the next row's exchange
         stamp(8);                                   // barrier 2
+        }
         st_acc[9] += 1;
         if (!has_next) break;
         row = next;
@@ -1053,6 +1160,54 @@ bool stft_window_layout(int bins, const float *w, float *out)
     case 1024:  window_layout<Plan1024>(w, out);  return true;
     case 512:   window_layout<Plan512>(w, out);   return true;
     case 256:   window_layout<Plan256>(w, out);   return true;
+    default:    return false;
+    }
+}
+
+// packed twiddle table (StftArgs::twiddles_k) from the generic one: for every stage of radix 16 / 32, unit
+// q*NS + k = {w^a(k), w^b(k)} with (a, b) = (1,2) (3,4) (8,12) (16,16); generic entry (c-1)*NS + k = w^c(k).
+template <class PL> static void pack_twiddles(const float2 *tw, float4 *out)
+{
+    const int radix[3] = {PL::R1, PL::R2, PL::R3}, ns[3] = {PL::NS1, PL::NS2, PL::NS3};
+    const int off[3] = {PL::TW1, PL::TW2, PL::TW3}, pk[3] = {PL::PK1, PL::PK2, PL::PK3};
+    static const int pairs[4][2] = {{1, 2}, {3, 4}, {8, 12}, {16, 16}};
+    for (int s = 0; s < 3; ++s) {
+        const int nq = PL::pkq(radix[s]);
+        for (int q = 0; q < nq; ++q)
+            for (int k = 0; k < ns[s]; ++k) {
+                const float2 a = tw[off[s] + (pairs[q][0] - 1) * ns[s] + k];
+                const float2 b = tw[off[s] + (pairs[q][1] - 1) * ns[s] + k];
+                out[pk[s] + q * ns[s] + k] = make_float4(a.x, a.y, b.x, b.y);
+            }
+    }
+}
+
+int stft_packed_twiddle_count(int bins)      // float4 units, <0 if unsupported
+{
+    switch (bins) {
+    case 32768: return Plan32768::PK_TOTAL;
+    case 16384: return Plan16384::PK_TOTAL;
+    case 8192:  return Plan8192::PK_TOTAL;
+    case 4096:  return Plan4096::PK_TOTAL;
+    case 2048:  return Plan2048::PK_TOTAL;
+    case 1024:  return Plan1024::PK_TOTAL;
+    case 512:   return Plan512::PK_TOTAL;
+    case 256:   return Plan256::PK_TOTAL;
+    default:    return -1;
+    }
+}
+
+bool stft_pack_twiddles(int bins, const float2 *tw, float4 *out)
+{
+    switch (bins) {
+    case 32768: pack_twiddles<Plan32768>(tw, out); return true;
+    case 16384: pack_twiddles<Plan16384>(tw, out); return true;
+    case 8192:  pack_twiddles<Plan8192>(tw, out);  return true;
+    case 4096:  pack_twiddles<Plan4096>(tw, out);  return true;
+    case 2048:  pack_twiddles<Plan2048>(tw, out);  return true;
+    case 1024:  pack_twiddles<Plan1024>(tw, out);  return true;
+    case 512:   pack_twiddles<Plan512>(tw, out);   return true;
+    case 256:   pack_twiddles<Plan256>(tw, out);   return true;
     default:    return false;
     }
 }

@@ -122,6 +122,7 @@ struct ro_stft {
     float *d_window = nullptr;
     float *d_window_k = nullptr;       // kernel-order copy (single-pass plans)
     float2 *d_twiddles = nullptr;
+    float4 *d_twiddles_k = nullptr;    // packed copy for the radix-16/32 stages
     hipStream_t stream = nullptr;
 
     // streaming state
@@ -200,6 +201,7 @@ ro::StftArgs make_stft_args(const ro_stft *h, const void *d_iq, int64_t first_ro
     a.window = h->d_window;
     a.window_k = h->d_window_k;
     a.twiddles = h->d_twiddles;
+    a.twiddles_k = h->d_twiddles_k;
     a.rows_out = d_rows;
     a.first_row = first_row;
     a.rows = rows;
@@ -547,6 +549,13 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg, ro_stft_t **out)
     }
     if (!tw.empty())
         CREATE_TRY(hipMemcpy(h->d_twiddles, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice));
+    if (!h->big) {
+        const int units = ro::stft_packed_twiddle_count(h->bins);
+        std::vector<float4> pk((size_t)std::max(units, 1));
+        if (units > 0) ro::stft_pack_twiddles(h->bins, tw.data(), pk.data());
+        CREATE_TRY(hipMalloc(&h->d_twiddles_k, sizeof(float4) * pk.size()));
+        CREATE_TRY(hipMemcpy(h->d_twiddles_k, pk.data(), sizeof(float4) * pk.size(), hipMemcpyHostToDevice));
+    }
     if (h->big) {
         std::vector<float2> full = build_full_twiddles(h->bins);
         CREATE_TRY(hipMalloc(&h->d_tw_big, sizeof(float2) * full.size()));
@@ -570,6 +579,7 @@ extern "C" int ro_stft_destroy(ro_stft_t *h)
     if (h->d_window_k) (void)hipFree(h->d_window_k);
     if (h->d_ln_keys) (void)hipFree(h->d_ln_keys);
     if (h->d_twiddles) (void)hipFree(h->d_twiddles);
+    if (h->d_twiddles_k) (void)hipFree(h->d_twiddles_k);
     if (h->d_iq) (void)hipFree(h->d_iq);
     if (h->d_rows) (void)hipFree(h->d_rows);
     if (h->d_records) (void)hipFree(h->d_records);
