@@ -120,6 +120,88 @@ template <int R> __device__ __forceinline__ void dif(v2f *v)
     dif_rec<R>(v, tok);
 }
 
+// ---------------------------------------------------------------------------
+// Decimation-in-time form of the same in-register transform (RO_DIT, the default): same positions and pairs per
+// level as dif<R>, result k again at v[bitrev_R(k)], but the constant twiddle sits BEFORE the butterfly, on the
+// second operand, and is the same for a whole block: block `u` at depth l uses W32^E with E = bitrev_l(u) * (16 >> l),
+// i.e. the two halves of a block with exponent E continue with E/2 and E/2 + 8.  That form fuses:
+//   a' = a + w b    two packed FMAs  (b.xx * (c,-s) + a, then b.yy * (s,c) + that)
+//   b' = a - w b  = 2 a - a'         one packed FMA
+// three issue slots per butterfly instead of four (add, sub, two for the product), two instead of three for w = -i.
+// ---------------------------------------------------------------------------
+#ifndef RO_DIT
+#define RO_DIT 1
+#endif
+
+// acc + x * w for a twiddle held in registers: two packed FMAs (same modifier trick as cmul)
+__device__ __forceinline__ v2f cmadd(v2f x, v2f w, v2f acc)
+{
+    v2f t, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(x), "v"(w), "v"(acc));     // x * (wx, wx) + acc
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"               // (xy,xx)*(-wy,wy) + t
+        : "=v"(r)
+        : "v"(x), "v"(w), "v"(t));
+    return r;
+}
+
+// (a, b) <- (a + W32^E b, a - W32^E b)
+template <int E> __device__ __forceinline__ void dit_pair(v2f &a, v2f &b)
+{
+    if constexpr (E == 0) {
+        const v2f s = a + b;
+        b = a - b;
+        a = s;
+    } else if constexpr (E == 8) {            // w b = (b.y, -b.x)
+        const v2f s = __builtin_elementwise_fma(b.yx, (v2f){1.0f, -1.0f}, a);
+        b = __builtin_elementwise_fma(b.yx, (v2f){-1.0f, 1.0f}, a);
+        a = s;
+    } else {                                  // w b = (b.x c + b.y s, b.y c - b.x s)
+        constexpr float c = (E == 4) ? RO_C4 : (E == 12) ? -RO_C4 : W32<E == 4 || E == 12 ? 1 : E>::c;
+        constexpr float sn = (E == 4 || E == 12) ? RO_C4 : W32<E == 4 || E == 12 ? 1 : E>::s;
+        const v2f t = __builtin_elementwise_fma(b.xx, (v2f){c, -sn}, a);
+        const v2f s = __builtin_elementwise_fma(b.yy, (v2f){sn, c}, t);
+        b = __builtin_elementwise_fma(a, (v2f){2.0f, 2.0f}, -s);
+        a = s;
+    }
+}
+
+template <int R, int E, int I> __device__ __forceinline__ void dit_bfly(v2f *v, const v2f *&tok)
+{
+    if constexpr (I % SEQ_G == 0) tie(v[I], *tok);
+    dit_pair<E>(v[I], v[I + R / 2]);
+    tok = &v[I + R / 2];
+}
+
+template <int R, int E, int... Is>
+__device__ __forceinline__ void dit_level(v2f *v, const v2f *&tok, std::integer_sequence<int, Is...>)
+{
+    (dit_bfly<R, E, Is>(v, tok), ...);
+}
+
+template <int R, int E> __device__ __forceinline__ void dit_rec(v2f *v, const v2f *&tok)
+{
+    if constexpr (R >= 2) {
+        dit_level<R, E>(v, tok, std::make_integer_sequence<int, R / 2>{});
+        dit_rec<R / 2, E / 2>(v, tok);
+        dit_rec<R / 2, E / 2 + 8>(v + R / 2, tok);
+    }
+}
+
+// In-place DFT of R points, decimation in time; result k sits at v[bitrev_R(k)].
+template <int R> __device__ __forceinline__ void dit(v2f *v)
+{
+    const v2f *tok = &v[R - 1];
+    dit_rec<R, 0>(v, tok);
+}
+
+// the transform minus its first level (the caller has done the R/2 butterflies v[i], v[i + R/2] itself)
+template <int R> __device__ __forceinline__ void dit_after_first_level(v2f *v)
+{
+    const v2f *tok = &v[R - 1];
+    dit_rec<R / 2, 0>(v, tok);
+    dit_rec<R / 2, 8>(v + R / 2, tok);
+}
+
 template <int R> __host__ __device__ constexpr int bitrev(int k)
 {
     int r = 0;

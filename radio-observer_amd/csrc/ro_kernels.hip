@@ -150,7 +150,10 @@ template <int P, int R> __device__ __forceinline__ void butterflies(v2f (&v)[P])
 {
     if constexpr (RO_ABLATE & 8) return;
 #pragma unroll
-    for (int b = 0; b < P / R; ++b) dif<R>(&v[b * R]);
+    for (int b = 0; b < P / R; ++b) {
+        if constexpr (RO_DIT) dit<R>(&v[b * R]);
+        else dif<R>(&v[b * R]);
+    }
 }
 
 // Buffer-descriptor helpers.  All global traffic of the STFT kernel goes through
@@ -272,6 +275,59 @@ __device__ __forceinline__ void tw_apply(v2f (&v)[P], const v2f (&t)[P / R][TW_S
 #pragma unroll
             for (int r = 1; r < R; ++r) x[r] = cmul(x[r], t[b][r - 1]);
         }
+    }
+}
+
+// Twiddles and butterflies of one stage.  Radix 16 / 32 in DIT form fuse the stage twiddles into the first level:
+//   A = x[r] w^r (two ops),  a' = A + x[r+R/2] w^(r+R/2) (two FMAs),  b' = 2A - a' (one)
+// five issue slots per pair where twiddling both and then adding / subtracting takes six.
+template <int P, int R>
+__device__ __forceinline__ void tw_butterflies(v2f (&v)[P], const v2f (&t)[P / R][TW_SET])
+{
+    if constexpr (RO_DIT && R >= 16 && !(RO_ABLATE & 8)) {
+#pragma unroll
+        for (int b = 0; b < P / R; ++b) {
+            v2f *x = &v[b * R];
+            constexpr int H = R / 2;
+            // w^r for r = 4m + c (c, m in 0..3) from the held set {w1,w2,w3,w4,w8,w12,(w16)}, as in tw_apply
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int r = 4 * m + c;
+                    if constexpr (R == 32) {
+                        // pair (r, 16 + r): w^(16+r) = w^r w^16
+                        if (r == 0) {
+                            const v2f A = x[0];
+                            const v2f s = cmadd(x[16], t[b][6], A);
+                            x[16] = __builtin_elementwise_fma(A, (v2f){2.0f, 2.0f}, -s);
+                            x[0] = s;
+                        } else {
+                            const v2f w = (m == 0) ? t[b][c - 1] : (c == 0) ? t[b][2 + m] : cmul(t[b][2 + m], t[b][c - 1]);
+                            const v2f A = cmul(x[r], w);
+                            const v2f s = cmadd(x[16 + r], cmul(w, t[b][6]), A);
+                            x[16 + r] = __builtin_elementwise_fma(A, (v2f){2.0f, 2.0f}, -s);
+                            x[r] = s;
+                        }
+                    } else {
+                        // R == 16: pairs (r, 8 + r) for r < 8; r >= 8 is the partner's twiddle w^(8+r')
+                        if (r >= H) continue;
+                        const v2f wlo = (r == 0) ? (v2f){1.0f, 0.0f}
+                                        : (m == 0) ? t[b][c - 1] : (c == 0) ? t[b][2 + m] : cmul(t[b][2 + m], t[b][c - 1]);
+                        const int rh = r + H, mh = rh / 4, ch = rh % 4;
+                        const v2f whi = (ch == 0) ? t[b][2 + mh] : cmul(t[b][2 + mh], t[b][ch - 1]);
+                        const v2f A = (r == 0) ? x[0] : cmul(x[r], wlo);
+                        const v2f s = cmadd(x[rh], whi, A);
+                        x[rh] = __builtin_elementwise_fma(A, (v2f){2.0f, 2.0f}, -s);
+                        x[r] = s;
+                    }
+                }
+            }
+            dit_after_first_level<R>(x);
+        }
+    } else {
+        tw_apply<P, R>(v, t);
+        butterflies<P, R>(v);
     }
 }
 
@@ -685,8 +741,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             if constexpr (ADDTID) exchange_addtid<1, SWAP32>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             else exchange<PL, PL::R0, 1, PL::R1>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             stamp(3);                               // exchange 1
-            tw_apply<P, PL::R1>(v, tw1);
-            butterflies<P, PL::R1>(v);
+            tw_butterflies<P, PL::R1>(v, tw1);
             stamp(4);                               // twiddles + butterflies 1
         }
         // ---- stage 2
@@ -696,8 +751,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             if constexpr (ADDTID) exchange_addtid<2, SWAP32>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             else exchange<PL, PL::R1, PL::NS1, PL::R2>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             stamp(5);                               // exchange 2
-            tw_apply<P, PL::R2>(v, tw2);
-            butterflies<P, PL::R2>(v);
+            tw_butterflies<P, PL::R2>(v, tw2);
             stamp(6);                               // twiddles + butterflies 2
         }
         // ---- stage 3
@@ -705,8 +759,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             v2f tw3[P / PL::R3][TW_SET];
             tw_prefetch<P, T, PL::R3, PL::NS3, PL::TW3, PL::PK3>(tw3, rs_tw, rs_twk, tid);
             exchange<PL, PL::R2, PL::NS2, PL::R3>(smem, v, tid, [](int) {});
-            tw_apply<P, PL::R3>(v, tw3);
-            butterflies<P, PL::R3>(v);
+            tw_butterflies<P, PL::R3>(v, tw3);
         }
 
         // ---- epilogue: |X[k]| -> column (k + N/2) mod N  (src/WaterfallBackend.cpp:492-505).
