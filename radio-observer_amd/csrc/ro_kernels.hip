@@ -52,30 +52,12 @@
 #ifndef RO_TW_PACKED
 #define RO_TW_PACKED 1
 #endif
-// N = 32768 plan: the barrier that closes an exchange (all gathers done before the LDS is written again) sits in
-// front of the NEXT LDS writer instead of behind the gather, so a wave starts its twiddles/butterflies on the
-// values that have arrived while the rest of the gather is still in flight.  0 = barrier right after the gather.
-#ifndef RO_LATE_BARRIER
-#define RO_LATE_BARRIER 0
-#endif
-// N = 32768 plan: the row leaves through wave-private LDS staging (no workgroup barrier in the epilogue: every
-// wave reads back only what it wrote itself); 0 = the generic epilogue with two barriers.  Needs RO_USE_ADDTID.
-#ifndef RO_WAVE_EPILOGUE
-#define RO_WAVE_EPILOGUE 0
-#endif
-// The hop new samples of the workgroup's NEXT row are touched (one dword per 64 bytes, value unused) right after
-// the window stage, a whole transform before the epilogue asks for them: they come from HBM, every other byte of
-// the row from L2, and that one miss latency sat on the critical path of every row.  0 = no prefetch.
+// The hop new samples of the workgroup's NEXT row are touched (one dword per 128-byte line, value unused) well
+// before the epilogue asks for them: they come from HBM, every other byte of the row from L2, and that one miss
+// latency sat on the critical path of every row.  Where: 1 = after the window stage, 2 = after the first exchange
+// (default: nothing queues behind the misses there; measured 5 % faster than 1), 3 = after the second; 0 = never.
 #ifndef RO_PREFETCH_NEXT
-#define RO_PREFETCH_NEXT 1
-#endif
-// EXPERIMENT (results wrong by design): RO_EXP_SKIP = number of the 16 sample chunks NOT loaded in the epilogue,
-// RO_EXP_DIRECT = 1 stores the row with dword stores straight from registers (no LDS staging)
-#ifndef RO_EXP_SKIP
-#define RO_EXP_SKIP 0
-#endif
-#ifndef RO_EXP_DIRECT
-#define RO_EXP_DIRECT 0
+#define RO_PREFETCH_NEXT 2
 #endif
 // LDS exchange of the N = 32768 plan through ds_write_addtid_b32 (1) or plain ds_write_b32 (0)
 #ifndef RO_USE_ADDTID
@@ -473,9 +455,6 @@ __device__ __forceinline__ void exchange_addtid(void *smem, v2f (&v)[32], int ti
     const float *g = lds + (XCH == 1 ? (tid & 31) * 1025 + (PERM ? 32 * (q & 1) + (q >> 1) : q)
                                      : (tid >> 5) * 1024 + (tid & 31));
     auto goff = [](int r) constexpr { return PERM ? 64 * (r >> 1) + 16 * (r & 1) : 32 * r; };
-    // the previous row's epilogue staged its magnitudes in this LDS without a closing barrier (wave-private
-    // pieces): every wave must be done reading its own before anyone's scatter lands on them
-    if constexpr ((XCH == 1 && RO_WAVE_EPILOGUE) || (XCH == 2 && RO_LATE_BARRIER)) __syncthreads();
     // volatile: keeps the 32 gathers single ds_read_b32 -- merged into ds_read2_b32 they come back as register
     // pairs of one plane and cost a v_mov each to interleave with the other plane (96 VALU ops per row)
     typedef const volatile __attribute__((address_space(3))) float lds_vfloat;
@@ -498,7 +477,7 @@ __device__ __forceinline__ void exchange_addtid(void *smem, v2f (&v)[32], int ti
 #pragma unroll
     for (int r = 0; r < 32; ++r) v[r].y = gv[goff(r)];
     sub(2);
-    if constexpr (!RO_LATE_BARRIER) __syncthreads();
+    __syncthreads();
     sub(3);
 }
 
@@ -595,7 +574,6 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
 #pragma unroll
             for (int k = 0; k < H; ++k) {
                 if constexpr ((RO_ABLATE & 32) != 0) { v[k] = (v2f){(float)(tid + k), 1.0f}; v[H + k] = v[k]; }
-                else if (k < RO_EXP_SKIP) { v[k] = (v2f){(float)(tid + k), 1.0f}; v[H + k] = v[k]; }
                 else S::load_pair(rs, pair_off * S::BYTES, k * (N / R0) * S::BYTES, v[k], v[H + k]);
             }
         } else {
@@ -721,14 +699,15 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         const int64_t next = row + stride;
         const bool has_next = next < xcd_end;
         unsigned touched0 = 0, touched1 = 0;
-        if constexpr (RO_PREFETCH_NEXT) {
+        auto touch_next = [&]() {
             // samples [next*hop + N - hop, next*hop + N) = hop * BYTES bytes: one dword per 128-byte line, two per
             // thread (reaches hop = N; whatever lies past the descriptor's end costs nothing)
             const int64_t s0 = (a.first_row + (has_next ? next : row)) * (int64_t)a.hop + (N - a.hop);
             const __amdgpu_buffer_rsrc_t rs_new = make_rsrc(iq + s0 * S::BYTES, has_next ? a.hop * S::BYTES : 0);
             touched0 = __builtin_amdgcn_raw_buffer_load_b32(rs_new, tid * 128, 0, 0);
             touched1 = __builtin_amdgcn_raw_buffer_load_b32(rs_new, tid * 128, T * 128, 0);
-        }
+        };
+        if constexpr (RO_PREFETCH_NEXT == 1) touch_next();
         stamp(0);                                   // window multiply (+ wait for samples)
 
         v2f tw1[PL::R1 > 1 ? P / PL::R1 : 1][TW_SET];
@@ -741,6 +720,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             if constexpr (ADDTID) exchange_addtid<1, SWAP32>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             else exchange<PL, PL::R0, 1, PL::R1>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             stamp(3);                               // exchange 1
+            if constexpr (RO_PREFETCH_NEXT == 2) touch_next();
             tw_butterflies<P, PL::R1>(v, tw1);
             stamp(4);                               // twiddles + butterflies 1
         }
@@ -751,6 +731,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             if constexpr (ADDTID) exchange_addtid<2, SWAP32>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             else exchange<PL, PL::R1, PL::NS1, PL::R2>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             stamp(5);                               // exchange 2
+            if constexpr (RO_PREFETCH_NEXT == 3) touch_next();
             tw_butterflies<P, PL::R2>(v, tw2);
             stamp(6);                               // twiddles + butterflies 2
         }
@@ -771,12 +752,9 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         // lane and stored -- 1 KiB per wave-instruction, the stores being the LAST thing in the
         // VMEM queue.
         if constexpr (RO_PREFETCH_NEXT) asm volatile("" ::"v"(touched0), "v"(touched1));   // keeps the touches alive
-        if constexpr (ADDTID && RO_WAVE_EPILOGUE) {
-            // Wave-private staging.  Slot q of lane `tid` is column tid + 1024 q of the transform; the wave writes
-            // its 32 x 256 bytes lane-linearly into image[q][tid] (ds_write_addtid_b32) and reads the SAME bytes
-            // back 16 per lane -- lanes 16a..16a+15 take the 256-byte piece of slot 4i+a -- so one store
-            // instruction carries four 256-byte pieces of the row.  No other wave's data is touched: no barrier,
-            // each wave goes on to the next row's window stage as soon as its own loads are in flight.
+        if constexpr (ADDTID) {
+            // slot q of thread `tid` is column tid + 1024 q: byte 4096 q + 4 tid of the LDS image, i.e. the row in
+            // natural order, written lane-linearly (ds_write_addtid_b32); the fft-shift moves into the store offsets
             float m[32];
 #pragma unroll
             for (int r = 0; r < 32; ++r) {
@@ -785,32 +763,8 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
                 m[r] = __builtin_amdgcn_sqrtf(sq.x + sq.y);      // v_sqrt_f32, 1 ulp
             }
             const unsigned wave_bytes = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6) * 256u;
-            if constexpr (!RO_EXP_DIRECT) addtid_scatter32<4096>(wave_bytes, [&](int q) { return m[q]; });
-            stamp(10);                              // magnitudes -> LDS writes issued
-            load_row(make_rsrc(iq + (a.first_row + (has_next ? next : row)) * (int64_t)a.hop * S::BYTES,
-                               has_next ? N * S::BYTES : 0));
-            load_window(make_rsrc(win_tab, has_next ? N * 4 : 0), cE{}, cN{});
-            stamp(7);                               // next-row loads issued
-            const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(a.rows_out + row * a.row_stride, N * 4);
-            const int lane = tid & 63;
-            const char *piece = smem + (lane >> 4) * 4096 + (tid >> 6) * 256 + (lane & 15) * 16;
-            const int voff = ((tid & ~63) + 4 * (lane & 15) + 1024 * (lane >> 4)) * 4;
-            if constexpr (RO_EXP_DIRECT) {
-#pragma unroll
-                for (int r = 0; r < 32; ++r) buf_store_f(m[r], rs_out, tid * 4, ((1024 * r + N / 2) & (N - 1)) * 4);
-            } else
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float4 x = *reinterpret_cast<const float4 *>(piece + i * 4 * 4096);
-                const int soff = ((4096 * i + N / 2) & (N - 1)) * 4;     // fft-shift: column k goes to (k + N/2) mod N
-                if constexpr (RO_ABLATE & 16) asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
-                else buf_store_f4(x.x, x.y, x.z, x.w, rs_out, voff, soff);
-                if (i & 1) asm volatile("" ::: "memory");
-            }
-            stamp(12);                              // LDS read-back + row stores issued
+            addtid_scatter32<4096>(wave_bytes, [&](int q) { return m[q]; });
         } else {
-        if constexpr (ADDTID && RO_LATE_BARRIER) __syncthreads();   // closes exchange 2 (see RO_LATE_BARRIER)
-        {
             float *lds_m = reinterpret_cast<float *>(smem);
 #pragma unroll
             for (int b = 0; b < P / RL; ++b) {
@@ -841,6 +795,8 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             for (int q = 0; q < P / 4; ++q) {
                 const float4 x = lds_m4[tid + T * q];
                 if constexpr (RO_ABLATE & 16) asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
+                else if constexpr (ADDTID)      // natural-order image: column k leaves for (k + N/2) mod N
+                    buf_store_f4(x.x, x.y, x.z, x.w, rs_out, tid * 16, ((q * T * 4 + N / 2) & (N - 1)) * 4);
                 else buf_store_f4(x.x, x.y, x.z, x.w, rs_out, tid * 16, q * T * 16);
                 // two reads in flight at most: hoisting all P/4 of them would need P more VGPRs
                 // while the next row's samples and window are already landing in theirs
@@ -850,7 +806,6 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         stamp(12);                                  // LDS read-back + row stores issued
         __syncthreads();                            // LDS is reused by the next row's exchange
         stamp(8);                                   // barrier 2
-        }
         st_acc[9] += 1;
         if (!has_next) break;
         row = next;
