@@ -46,8 +46,8 @@ JSON_BOLID = dict(min_detect=10300.0, max_detect=10900.0, min_noise=9000.0, max_
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=30)
     p.add_argument("--rows", type=int, default=16384, help="rows per step per GPU")
     p.add_argument("--bins", type=int, default=32768, help="FFT size (default = the headline C3/C4 workload)")
     p.add_argument("--overlap", type=int, default=None, help="overlap in samples (default 75 %% of bins)")

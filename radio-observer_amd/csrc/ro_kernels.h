@@ -26,6 +26,7 @@ struct StftArgs {
     float         gain;
     unsigned long long *stamps; // diagnostic builds only (RO_STAMPS), else nullptr
     int           stagger;     // start delay per workgroup slot, shader cycles (0 = none)
+    int           prefetch;    // set by the launcher: touch the next row's new samples ahead of time
 };
 
 struct TileArgs {

@@ -707,7 +707,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             touched0 = __builtin_amdgcn_raw_buffer_load_b32(rs_new, tid * 128, 0, 0);
             touched1 = __builtin_amdgcn_raw_buffer_load_b32(rs_new, tid * 128, T * 128, 0);
         };
-        if constexpr (RO_PREFETCH_NEXT == 1) touch_next();
+        if constexpr (RO_PREFETCH_NEXT == 1) { if (a.prefetch) touch_next(); }
         stamp(0);                                   // window multiply (+ wait for samples)
 
         v2f tw1[PL::R1 > 1 ? P / PL::R1 : 1][TW_SET];
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             if constexpr (ADDTID) exchange_addtid<1, SWAP32>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             else exchange<PL, PL::R0, 1, PL::R1>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             stamp(3);                               // exchange 1
-            if constexpr (RO_PREFETCH_NEXT == 2) touch_next();
+            if constexpr (RO_PREFETCH_NEXT == 2) { if (a.prefetch) touch_next(); }
             tw_butterflies<P, PL::R1>(v, tw1);
             stamp(4);                               // twiddles + butterflies 1
         }
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             if constexpr (ADDTID) exchange_addtid<2, SWAP32>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             else exchange<PL, PL::R1, PL::NS1, PL::R2>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             stamp(5);                               // exchange 2
-            if constexpr (RO_PREFETCH_NEXT == 3) touch_next();
+            if constexpr (RO_PREFETCH_NEXT == 3) { if (a.prefetch) touch_next(); }
             tw_butterflies<P, PL::R2>(v, tw2);
             stamp(6);                               // twiddles + butterflies 2
         }
@@ -981,49 +981,96 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void scan_kernel(ScanArgs a)
     const float *__restrict__ src = a.rows_in + row * a.row_stride;
 
     // ---- noise(): element floor(W/4) of the ascending noise band, times two.
-    // Order statistic by a 32-step bisection on the order-preserving integer
-    // image of the floats: result = largest key K with #(key < K) <= k.
+    // Order statistic by a 4-pass radix select (8 bits per pass, most significant first) on the order-preserving
+    // integer image of the floats: every pass histograms the digit of the keys that still match the prefix found so
+    // far (256 bins per wave in LDS, ds_add_u32), a wave scan over the bins finds the bin holding rank k, and k is
+    // reduced by the count below it.  Exact: the result is an element of the band, bit for bit.
     const float *nb = src + a.low_noise;
     const int W = a.noise_width;
-    const int kth = W / 4;
+    __shared__ __attribute__((aligned(16))) unsigned hist[SCAN_WAVES][256];
+    unsigned *h = hist[threadIdx.x >> 6];
     unsigned keys[SCAN_E];
     const bool cached = W <= 64 * SCAN_E;
     if (cached) {
 #pragma unroll
         for (int e = 0; e < SCAN_E; ++e) {
             const int i = lane + 64 * e;
-            keys[e] = i < W ? order_key(nb[i]) : 0xffffffffu;   // padding sorts last
+            keys[e] = i < W ? order_key(nb[i]) : 0xffffffffu;
         }
     }
-    unsigned result = 0;
-    for (int bit = 31; bit >= 0; --bit) {
-        const unsigned trial = result | (1u << bit);
-        int below = 0;
-        if (cached) {
+    unsigned result = 0xffffffffu;                 // W == 0: the reference indexes an empty array (undefined)
+    if (W > 0) {
+        unsigned prefix = 0;
+        int k = W / 4;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            reinterpret_cast<uint4 *>(h)[lane] = make_uint4(0u, 0u, 0u, 0u);
+            auto count = [&](unsigned key, bool valid) {
+                // keys whose higher digits equal the prefix (all of them in pass 0: shifting by 32 is not defined)
+                const bool match = pass == 0 || (key >> (shift + 8)) == prefix;
+                if (valid && match) atomicAdd(&h[(key >> shift) & 255u], 1u);
+            };
+            if (cached) {
 #pragma unroll
-            for (int e = 0; e < SCAN_E; ++e)
-                below += __popcll(__ballot(keys[e] < trial));
-        } else {
-            for (int i0 = 0; i0 < W; i0 += 64) {
-                const int i = i0 + lane;
-                const bool lt = i < W && order_key(nb[i]) < trial;
-                below += __popcll(__ballot(lt));
+                for (int e = 0; e < SCAN_E; ++e)
+                    if (64 * e < W) count(keys[e], lane + 64 * e < W);
+            } else {
+                for (int i0 = 0; i0 < W; i0 += 64) {
+                    const int i = i0 + lane;
+                    count(i < W ? order_key(nb[i]) : 0u, i < W);
+                }
             }
+            const uint4 b = reinterpret_cast<const uint4 *>(h)[lane];          // bins 4 lane .. 4 lane + 3
+            const unsigned s = b.x + b.y + b.z + b.w;
+            unsigned inc = s;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned t = __shfl_up(inc, d);
+                if (lane >= d) inc += t;
+            }
+            const unsigned exc = inc - s;
+            const bool mine = exc <= (unsigned)k && (unsigned)k < inc;         // exactly one lane: total > k
+            unsigned below = exc, bin = 0;
+            if ((unsigned)k >= below + b.x) {
+                below += b.x; bin = 1;
+                if ((unsigned)k >= below + b.y) {
+                    below += b.y; bin = 2;
+                    if ((unsigned)k >= below + b.z) { below += b.z; bin = 3; }
+                }
+            }
+            const int owner = __ffsll((long long)__ballot(mine)) - 1;
+            const unsigned digit = (unsigned)__shfl((int)(4 * lane + bin), owner);
+            k -= __shfl((int)below, owner);
+            prefix = (prefix << 8) | digit;
         }
-        if (below <= kth) result = trial;
+        result = prefix;
     }
-    // padding keys (0xffffffff) are never counted as "< trial" unless trial is larger, which
-    // cannot happen, so `below` only ever counts real elements.
     const float q = key_to_float(result);
     const float noise = (float)((double)q * 2.0);
 
-    // ---- peak(): last index of the maximum of the detect band
+    // ---- peak(): last index of the maximum of the detect band.  All loads first (one miss latency, not one per
+    // 64 columns), then the per-lane arg-max-last in index order and the cross-lane reduction.
     const float *db = src + a.low_detect;
+    const int DW = a.detect_width;
     float best = 0.f;
     int best_i = -1;
-    for (int i = lane; i < a.detect_width; i += 64) {
-        const float x = db[i];
-        if (best_i < 0 || x >= best) { best = x; best_i = i; }
+    if (DW <= 64 * SCAN_E) {
+        float xs[SCAN_E];
+#pragma unroll
+        for (int e = 0; e < SCAN_E; ++e) {
+            const int i = lane + 64 * e;
+            xs[e] = i < DW ? db[i] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < SCAN_E; ++e) {
+            const int i = lane + 64 * e;
+            if (i < DW && (best_i < 0 || xs[e] >= best)) { best = xs[e]; best_i = i; }
+        }
+    } else {
+        for (int i = lane; i < DW; i += 64) {
+            const float x = db[i];
+            if (best_i < 0 || x >= best) { best = x; best_i = i; }
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -1034,16 +1081,23 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void scan_kernel(ScanArgs a)
     }
     const int peak = best_i < 0 ? 0 : best_i;
 
-    // ---- average(): sequential double sum in index order, like the reference
-    if (lane == 0) {
-        const int start = a.low_detect + peak - a.avg_bins / 2;
-        double acc = 0.0;
-        for (int i = 0; i < a.avg_bins; ++i) {
-            const int c = start + i;
-            // the reference reads outside the row here when the window leaves it (UB);
-            // columns outside [0, bins) contribute nothing in this implementation.
-            if (c >= 0 && c < a.bins) acc += (double)src[c];
+    // ---- average(): sequential double sum in index order, like the reference.  64 columns are fetched at a time
+    // (one load per lane), then every lane adds them up in the same order from the other lanes' registers.
+    const int start = a.low_detect + peak - a.avg_bins / 2;
+    double acc = 0.0;
+    for (int base = 0; base < a.avg_bins; base += 64) {
+        const int c = start + base + lane;
+        // the reference reads outside the row here when the window leaves it (UB);
+        // columns outside [0, bins) contribute nothing in this implementation.
+        const float x = (base + lane < a.avg_bins && c >= 0 && c < a.bins) ? src[c] : 0.f;
+        const int n = a.avg_bins - base < 64 ? a.avg_bins - base : 64;
+        for (int i = 0; i < n; ++i) {
+            const int ci = start + base + i;
+            const float xi = __shfl(x, i);
+            if (ci >= 0 && ci < a.bins) acc += (double)xi;
         }
+    }
+    if (lane == 0) {
         ro_scan_record_t rec;
         rec.noise = noise;
         rec.peak = peak;
@@ -1086,6 +1140,18 @@ template <class PL, int FMT> static hipError_t launch_plan(const StftArgs &a, hi
     }
     const unsigned grid = (unsigned)(slots * 8);
     StftArgs b = a;
+    // The touches park hop*BYTES per resident workgroup in the XCD's 4 MiB L2 for most of a row time.  Past half of
+    // it they push out the rows being transformed and every line is fetched twice (seen at overlap 0: FETCH_SIZE x2,
+    // 19 % slower).  Plans with several workgroups per CU hide the miss behind each other and gain nothing (measured).
+    b.prefetch = (PL::T == 1024 && slots * (int64_t)a.hop * Sample<FMT>::BYTES <= (2 << 20)) ? 1 : 0;
+    {
+        static int force = -2;                         // experiment knob: RO_PREFETCH=0/1 overrides the rule
+        if (force == -2) {
+            const char *e = getenv("RO_PREFETCH");
+            force = e ? atoi(e) : -1;
+        }
+        if (force >= 0) b.prefetch = force;
+    }
     {
         static int stagger = -1;                       // experiment knob: RO_STAGGER=<cycles per slot>
         if (stagger < 0) {
