@@ -69,7 +69,7 @@
 #endif
 // share (percent) of the next row's window coefficients that is prefetched across the transform
 #ifndef RO_WIN_EARLY_PCT
-#define RO_WIN_EARLY_PCT 25
+#define RO_WIN_EARLY_PCT 50
 #endif
 // window coefficients in flight per chunk (two chunks are outstanding)
 #ifndef RO_WIN_CHUNK
@@ -639,7 +639,8 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
     };
     // Coefficients [0, NW_EARLY) of the next row are requested right after the window stage
     // (their registers are free for the whole transform, so these loads cost nothing); the
-    // rest would not fit the 128-VGPR budget next to the butterflies and follows in the epilogue.
+    // rest follows in the epilogue.  (Keeping all of them resident instead -- they are the same for every row --
+    // makes hipcc spill 31 registers; prefetching 100 % fits but leaves no VGPR to spare and gains 1 %.)
     constexpr int NW_EARLY = ((NW * RO_WIN_EARLY_PCT) / 100) & ~1;
     using c0 = std::integral_constant<int, 0>;
     using cE = std::integral_constant<int, NW_EARLY>;

@@ -12,13 +12,25 @@ def counters(sub):
             acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     return acc
 
-print("== kernel-trace stats (rocprofv3 --kernel-trace --stats, bench.py --steps 10 --warmup 2)")
+print("== kernel-trace stats (rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-parity)")
 for f in glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")):
     for row in csv.DictReader(open(f)):
         if "ro::" in row["Name"]:
             print("  %-70s calls %4s  avg %10.1f us  min %10.1f  max %10.1f" % (
                 row["Name"][:70], row["Calls"], float(row["AverageNs"]) / 1e3, float(row["MinNs"]) / 1e3,
                 float(row["MaxNs"]) / 1e3))
+# per-launch durations from the trace itself: bench.py issues W warm-up steps, K timed steps, then K launches
+# inside ro_stft_time_resident (the HIP-event kernel time of the roofline); the device needs ~20 launches after
+# idle to reach its steady clocks, so the --stats average over ALL launches sits above the steady-state figure
+for f in glob.glob(os.path.join(d, "trace", "*", "*_kernel_trace.csv")):
+    dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(f))
+           if "stft_kernel" in r["Kernel_Name"]]
+    if dur:
+        n = len(dur)
+        k = (n - 30) // 2 if n > 40 else n // 2
+        print("  stft_kernel launches in issue order, us: first 12 = %s" % [round(x) for x in dur[:12]])
+        print("  mean of the last %d launches (the ones bench.py's HIP events time): %.1f us; of the %d before them "
+              "(the timed steps): %.1f us" % (k, sum(dur[-k:]) / k, k, sum(dur[-2 * k:-k]) / k))
 bj = os.path.join(d, "bench_trace.json")
 if os.path.exists(bj):
     for line in open(bj):
