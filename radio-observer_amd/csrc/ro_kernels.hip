@@ -996,7 +996,9 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void scan_kernel(ScanArgs a)
 #pragma unroll
         for (int e = 0; e < SCAN_E; ++e) {
             const int i = lane + 64 * e;
-            keys[e] = i < W ? order_key(nb[i]) : 0xffffffffu;
+            // clamped index instead of a guarded load: no divergent branch, never outside the band
+            const unsigned key = order_key(nb[i < W ? i : (W > 0 ? W - 1 : 0)]);
+            keys[e] = i < W ? key : 0xffffffffu;
         }
     }
     unsigned result = 0xffffffffu;                 // W == 0: the reference indexes an empty array (undefined)
@@ -1007,9 +1009,10 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void scan_kernel(ScanArgs a)
             const int shift = 24 - 8 * pass;
             reinterpret_cast<uint4 *>(h)[lane] = make_uint4(0u, 0u, 0u, 0u);
             auto count = [&](unsigned key, bool valid) {
-                // keys whose higher digits equal the prefix (all of them in pass 0: shifting by 32 is not defined)
+                // keys whose higher digits equal the prefix (all of them in pass 0: shifting by 32 is not defined);
+                // the others add 0 -- no divergent branch around the atomic
                 const bool match = pass == 0 || (key >> (shift + 8)) == prefix;
-                if (valid && match) atomicAdd(&h[(key >> shift) & 255u], 1u);
+                atomicAdd(&h[(key >> shift) & 255u], (valid && match) ? 1u : 0u);
             };
             if (cached) {
 #pragma unroll
@@ -1060,7 +1063,7 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void scan_kernel(ScanArgs a)
 #pragma unroll
         for (int e = 0; e < SCAN_E; ++e) {
             const int i = lane + 64 * e;
-            xs[e] = i < DW ? db[i] : 0.f;
+            xs[e] = db[i < DW ? i : (DW > 0 ? DW - 1 : 0)];
         }
 #pragma unroll
         for (int e = 0; e < SCAN_E; ++e) {
