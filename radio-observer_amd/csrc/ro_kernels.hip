@@ -175,6 +175,18 @@ template <int CTRL> __device__ __forceinline__ float dpp_quad(float x)
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xF, 0xF, false));
 }
 
+// Workgroup barrier that the optimiser may not move memory operations across.  __syncthreads() alone is not enough:
+// with a branch behind an exchange, hipcc sank the plain LDS gather loads of the exchange below its closing barrier
+// (two s_barrier back to back in the ISA, the ds_reads after them) and rows went wrong at random once several
+// workgroups shared a CU (tests/test_gpu_fullsize.py caught it).  The empty asm statements claim to touch memory,
+// so no load or store crosses them in either direction.
+__device__ __forceinline__ void wg_sync()
+{
+    asm volatile("" ::: "memory");
+    __syncthreads();
+    asm volatile("" ::: "memory");
+}
+
 // Ordering by fake data dependence: returns `off` unchanged, but the compiler must
 // assume it was recomputed from `x`, so loads addressed with the result cannot be
 // issued before `x` exists.  (A "memory" clobber does not stop the scheduler from
@@ -366,26 +378,26 @@ __device__ __forceinline__ void exchange(void *smem, v2f (&v)[PL::P], int tid, S
         float *lds = reinterpret_cast<float *>(smem);
         lds_scatter<P, T, RA, NS>(lds, v, tid, [](v2f e) { return e.x; });
         sub(0);
-        __syncthreads();
+        wg_sync();
         sub(1);
         lds_gather<N, P, T, RB>(lds, v, tid, [](v2f &d, float s) { d.x = s; });
         sub(2);
-        __syncthreads();
+        wg_sync();
         sub(3);
         lds_scatter<P, T, RA, NS>(lds, v, tid, [](v2f e) { return e.y; });
         sub(0);
-        __syncthreads();
+        wg_sync();
         sub(1);
         lds_gather<N, P, T, RB>(lds, v, tid, [](v2f &d, float s) { d.y = s; });
         sub(2);
-        __syncthreads();
+        wg_sync();
         sub(3);
     } else {
         v2f *lds = reinterpret_cast<v2f *>(smem);
         lds_scatter<P, T, RA, NS>(lds, v, tid, [](v2f e) { return e; });
-        __syncthreads();
+        wg_sync();
         lds_gather<N, P, T, RB>(lds, v, tid, [](v2f &d, v2f s) { d = s; });
-        __syncthreads();
+        wg_sync();
     }
 }
 
@@ -463,21 +475,23 @@ __device__ __forceinline__ void exchange_addtid(void *smem, v2f (&v)[32], int ti
     sub(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     sub(1);
 #pragma unroll
     for (int r = 0; r < 32; ++r) v[r].x = gv[goff(r)];
     sub(2);
-    __syncthreads();
+    wg_sync();
     sub(3);
     addtid_scatter32<ROW * 4>(wave_bytes, [&](int q) { return v[bitrev<32>(q)].y; });
     sub(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     sub(1);
 #pragma unroll
     for (int r = 0; r < 32; ++r) v[r].y = gv[goff(r)];
     sub(2);
-    __syncthreads();
+    wg_sync();
     sub(3);
 }
 
@@ -704,11 +718,13 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             // samples [next*hop + N - hop, next*hop + N) = hop * BYTES bytes: one dword per 128-byte line, two per
             // thread (reaches hop = N; whatever lies past the descriptor's end costs nothing)
             const int64_t s0 = (a.first_row + (has_next ? next : row)) * (int64_t)a.hop + (N - a.hop);
-            const __amdgpu_buffer_rsrc_t rs_new = make_rsrc(iq + s0 * S::BYTES, has_next ? a.hop * S::BYTES : 0);
+            // switched off (a.prefetch == 0, last row) by a zero-sized descriptor, not by a branch
+            const __amdgpu_buffer_rsrc_t rs_new =
+                make_rsrc(iq + s0 * S::BYTES, (has_next && a.prefetch) ? a.hop * S::BYTES : 0);
             touched0 = __builtin_amdgcn_raw_buffer_load_b32(rs_new, tid * 128, 0, 0);
             touched1 = __builtin_amdgcn_raw_buffer_load_b32(rs_new, tid * 128, T * 128, 0);
         };
-        if constexpr (RO_PREFETCH_NEXT == 1) { if (a.prefetch) touch_next(); }
+        if constexpr (RO_PREFETCH_NEXT == 1) touch_next();
         stamp(0);                                   // window multiply (+ wait for samples)
 
         v2f tw1[PL::R1 > 1 ? P / PL::R1 : 1][TW_SET];
@@ -721,7 +737,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             if constexpr (ADDTID) exchange_addtid<1, SWAP32>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             else exchange<PL, PL::R0, 1, PL::R1>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             stamp(3);                               // exchange 1
-            if constexpr (RO_PREFETCH_NEXT == 2) { if (a.prefetch) touch_next(); }
+            if constexpr (RO_PREFETCH_NEXT == 2) touch_next();
             tw_butterflies<P, PL::R1>(v, tw1);
             stamp(4);                               // twiddles + butterflies 1
         }
@@ -732,7 +748,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             if constexpr (ADDTID) exchange_addtid<2, SWAP32>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             else exchange<PL, PL::R1, PL::NS1, PL::R2>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             stamp(5);                               // exchange 2
-            if constexpr (RO_PREFETCH_NEXT == 3) { if (a.prefetch) touch_next(); }
+            if constexpr (RO_PREFETCH_NEXT == 3) touch_next();
             tw_butterflies<P, PL::R2>(v, tw2);
             stamp(6);                               // twiddles + butterflies 2
         }
@@ -787,7 +803,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         // old coefficients alive next to the new ones
         load_window(make_rsrc(win_tab, has_next ? N * 4 : 0), cE{}, cN{});
         stamp(7);                                   // next-row loads issued
-        __syncthreads();
+        wg_sync();
         stamp(11);                                  // barrier 1
         {
             const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(a.rows_out + row * a.row_stride, N * 4);
@@ -805,7 +821,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             }
         }
         stamp(12);                                  // LDS read-back + row stores issued
-        __syncthreads();                            // LDS is reused by the next row's exchange
+        wg_sync();                            // LDS is reused by the next row's exchange
         stamp(8);                                   // barrier 2
         st_acc[9] += 1;
         if (!has_next) break;
@@ -940,7 +956,7 @@ __global__ __launch_bounds__(256) void ln_reduce_kernel(LnArgs a)
         s_min[threadIdx.x >> 6] = kmin;
         s_max[threadIdx.x >> 6] = kmax;
     }
-    __syncthreads();
+    wg_sync();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; ++w) {
             kmin = min(kmin, s_min[w]);
