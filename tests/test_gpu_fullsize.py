@@ -6,6 +6,8 @@ the FP64 oracle would take minutes: size-independent properties of the transform
   * scaling           -- rows(2^k x) == 2^k rows(x), bit for bit (every operation of the path is homogeneous)
   * Parseval          -- sum_k row[k]^2 == N * sum_n (w[n] |x[r hop + n]|)^2 to fp32 accuracy, EVERY row
   * scan records      -- bit-exact against the oracle's scan of the same rows, on a sample of rows
+The other plans run at sizes that keep every CU busy with several workgroups at once -- the regime in which a
+compiler-reordered barrier once corrupted rows that every small-size parity test got right.
 """
 import numpy as np
 import pytest
@@ -32,7 +34,10 @@ def run(ro, torch, st, iq, first, rows, out):
     st.run_resident(iq, ro.RO_IQ_F32, iq.shape[0], first, rows, out, stream=torch.cuda.current_stream().cuda_stream)
 
 
-@pytest.mark.parametrize("bins,overlap,R,seed", [(32768, 24576, 16384, 0xC3), (4096, 2048, 65536, 0xC2)])
+@pytest.mark.parametrize("bins,overlap,R,seed", [(32768, 24576, 16384, 0xC3), (4096, 2048, 65536, 0xC2),
+                                                 (16384, 12288, 16384, 5), (8192, 6144, 32768, 6),
+                                                 (2048, 0, 65536, 7), (1024, 512, 131072, 0xC1), (512, 384, 65536, 8),
+                                                 (256, 128, 262144, 9)])
 def test_full_size_properties(ro, oracle, torch_cuda, bins, overlap, R, seed):
     torch = torch_cuda
     hop = bins - overlap
@@ -54,7 +59,7 @@ def test_full_size_properties(ro, oracle, torch_cuda, bins, overlap, R, seed):
 
         # ---- shift invariance: row r == row 0 of the stream that starts at sample r*hop
         one = torch.empty((1, bins), dtype=torch.float32, device="cuda")
-        for r in (1, 4097, R - 1):
+        for r in (1, min(4097, R - 2), R - 1):
             sub = iq[r * hop:r * hop + bins]
             run(ro, torch, st, sub, 0, 1, one)
             torch.cuda.synchronize()
