@@ -121,7 +121,8 @@ template <int R> __device__ __forceinline__ void dif(v2f *v)
 }
 
 // ---------------------------------------------------------------------------
-// Decimation-in-time form of the same in-register transform (RO_DIT, the default): same positions and pairs per
+// Decimation-in-time form of the same in-register transform (what the single-pass kernels use; the DIF form above
+// remains for the multi-pass kernels, whose twiddles come from a table per element): same positions and pairs per
 // level as dif<R>, result k again at v[bitrev_R(k)], but the constant twiddle sits BEFORE the butterfly, on the
 // second operand, and is the same for a whole block: block `u` at depth l uses W32^E with E = bitrev_l(u) * (16 >> l),
 // i.e. the two halves of a block with exponent E continue with E/2 and E/2 + 8.  That form fuses:
@@ -129,16 +130,23 @@ template <int R> __device__ __forceinline__ void dif(v2f *v)
 //   b' = a - w b  = 2 a - a'         one packed FMA
 // three issue slots per butterfly instead of four (add, sub, two for the product), two instead of three for w = -i.
 // ---------------------------------------------------------------------------
-#ifndef RO_DIT
-#define RO_DIT 1
-#endif
-
 // acc + x * w for a twiddle held in registers: two packed FMAs (same modifier trick as cmul)
 __device__ __forceinline__ v2f cmadd(v2f x, v2f w, v2f acc)
 {
     v2f t, r;
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(x), "v"(w), "v"(acc));     // x * (wx, wx) + acc
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"               // (xy,xx)*(-wy,wy) + t
+        : "=v"(r)
+        : "v"(x), "v"(w), "v"(t));
+    return r;
+}
+
+// acc + x * (-i w): the same two FMAs with the halves of w swapped and one sign moved
+__device__ __forceinline__ v2f cmadd_mi(v2f x, v2f w, v2f acc)
+{
+    v2f t, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(t) : "v"(x), "v"(w), "v"(acc));   // x * (wy, wy) + acc
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]"                          // (xy,xx)*(wx,-wx) + t
         : "=v"(r)
         : "v"(x), "v"(w), "v"(t));
     return r;
@@ -200,6 +208,67 @@ template <int R> __device__ __forceinline__ void dit_after_first_level(v2f *v)
     const v2f *tok = &v[R - 1];
     dit_rec<R / 2, 0>(v, tok);
     dit_rec<R / 2, 8>(v + R / 2, tok);
+}
+
+// ---------------------------------------------------------------------------
+// Radix-32 stage WITH its stage twiddles (element r of the butterfly enters multiplied by w^r, w per thread), the
+// twiddles factored through the levels:  x_r w^r + x_{r+16} w^{r+16} = w^r (x_r + w^16 x_{r+16}), so level l only
+// needs g_l = w^(16 >> l) on its second operands (times the block's constant W32^E) and the common factor w^r
+// shrinks to w^0 = 1 at the last level.  Every butterfly is cmadd + (2a - a') = 3 issue slots; the constants cost
+// 11 products per stage (E and E+8 share one: -i is a modifier), against 24 composed twiddles + 31 products when
+// the twiddles are applied up front.  Only w, w^2, w^4, w^8, w^16 are loaded.  Result k at v[bitrev_32(k)].
+// ---------------------------------------------------------------------------
+template <int BITS> __host__ __device__ constexpr int bitrev_bits(int k)
+{
+    int r = 0;
+    for (int b = 0; b < BITS; ++b) { r = (r << 1) | (k & 1); k >>= 1; }
+    return r;
+}
+
+template <int L, int U, int I> __device__ __forceinline__ void fdit_bfly(v2f *x, const v2f (&tw)[8], const v2f *&tok)
+{
+    constexpr int S = 32 >> L, E = bitrev_bits<L>(U) * (16 >> L), base = U * S;
+    v2f &a = x[base + I], &b = x[base + I + S / 2];
+    if constexpr (I % SEQ_G == 0) tie(a, *tok);
+    const v2f s = (E >= 8) ? cmadd_mi(b, tw[E & 7], a) : cmadd(b, tw[E & 7], a);
+    b = __builtin_elementwise_fma(a, (v2f){2.0f, 2.0f}, -s);
+    a = s;
+    tok = &b;
+}
+
+template <int L, int U, int... Is>
+__device__ __forceinline__ void fdit_block(v2f *x, const v2f (&tw)[8], const v2f *&tok, std::integer_sequence<int, Is...>)
+{
+    (fdit_bfly<L, U, Is>(x, tw, tok), ...);
+}
+
+template <int L, int... Us>
+__device__ __forceinline__ void fdit_blocks(v2f *x, const v2f (&tw)[8], const v2f *&tok, std::integer_sequence<int, Us...>)
+{
+    (fdit_block<L, Us>(x, tw, tok, std::make_integer_sequence<int, (16 >> L)>{}), ...);
+}
+
+// level L of the stage; g = w^(16 >> L)
+template <int L> __device__ __forceinline__ void fdit_level(v2f *x, v2f g, const v2f *&tok)
+{
+    v2f tw[8];
+    tw[0] = g;
+    constexpr int STEP = 16 >> L;                       // exponents in use at this level: multiples of STEP below 8
+    if constexpr (STEP <= 4) tw[4] = mul_w32<4>(g);
+    if constexpr (STEP <= 2) { tw[2] = mul_w32<2>(g); tw[6] = mul_w32<6>(g); }
+    if constexpr (STEP <= 1) { tw[1] = mul_w32<1>(g); tw[3] = mul_w32<3>(g); tw[5] = mul_w32<5>(g); tw[7] = mul_w32<7>(g); }
+    fdit_blocks<L>(x, tw, tok, std::make_integer_sequence<int, (1 << L)>{});
+}
+
+// x[0..32) <- DFT32 of (x[r] w^r); g16..g1 = w^16, w^8, w^4, w^2, w
+__device__ __forceinline__ void fdit32(v2f *x, v2f g16, v2f g8, v2f g4, v2f g2, v2f g1)
+{
+    const v2f *tok = &x[31];
+    fdit_level<0>(x, g16, tok);
+    fdit_level<1>(x, g8, tok);
+    fdit_level<2>(x, g4, tok);
+    fdit_level<3>(x, g2, tok);
+    fdit_level<4>(x, g1, tok);
 }
 
 template <int R> __host__ __device__ constexpr int bitrev(int k)

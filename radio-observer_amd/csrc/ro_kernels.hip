@@ -47,11 +47,6 @@
 #ifndef RO_SWAP32
 #define RO_SWAP32 1
 #endif
-// twiddles of the radix-16/32 stages from a packed table (16-byte loads: {w1,w2} {w3,w4} {w8,w12} {w16,-} per
-// butterfly); 0 = 8-byte loads from the generic per-stage table
-#ifndef RO_TW_PACKED
-#define RO_TW_PACKED 1
-#endif
 // The hop new samples of the workgroup's NEXT row are touched (one dword per 128-byte line, value unused) well
 // before the epilogue asks for them: they come from HBM, every other byte of the row from L2, and that one miss
 // latency sat on the critical path of every row.  Where: 1 = after the window stage, 2 = after the first exchange
@@ -91,8 +86,9 @@ struct Plan {
     static constexpr int TW2 = TW1 + (R1 > 1 ? (R1 - 1) * NS1 : 0);
     static constexpr int TW3 = TW2 + (R2 > 1 ? (R2 - 1) * NS2 : 0);
     static constexpr int TW_TOTAL = TW3 + (R3 > 1 ? (R3 - 1) * NS3 : 0);
-    // packed table (16-byte units): stage s with radix >= 16 holds PKQ(R) x NS units, unit q*NS + k = the q-th pair
-    static constexpr int pkq(int r) { return r == 32 ? 4 : (r == 16 ? 3 : 0); }
+    // packed table (16-byte units): stage s with radix >= 16 holds 3 x NS units, unit q*NS + k = the q-th pair of
+    // twiddles of butterfly k: radix 32 {w,w^2} {w^4,w^8} {w^16,-}; radix 16 {w,w^2} {w^3,w^4} {w^8,w^12}
+    static constexpr int pkq(int r) { return (r == 32 || r == 16) ? 3 : 0; }
     static constexpr int PK1 = 0;
     static constexpr int PK2 = PK1 + pkq(R1) * NS1;
     static constexpr int PK3 = PK2 + pkq(R2) * NS2;
@@ -133,8 +129,7 @@ template <int P, int R> __device__ __forceinline__ void butterflies(v2f (&v)[P])
     if constexpr (RO_ABLATE & 8) return;
 #pragma unroll
     for (int b = 0; b < P / R; ++b) {
-        if constexpr (RO_DIT) dit<R>(&v[b * R]);
-        else dif<R>(&v[b * R]);
+        dit<R>(&v[b * R]);
     }
 }
 
@@ -203,14 +198,13 @@ __device__ __forceinline__ v2f tw_load(__amdgpu_buffer_rsrc_t tw, int koff, int 
     return buf_load_f2(tw, koff, entry * 8);
 }
 
-// Composed form.  The kernel is bound by its memory pipes, not by the VALU (ablation:
-// removing every butterfly changes nothing, removing the 62 twiddle loads saved 14 %),
-// so for radix 32 only w^1..w^3, w^4, w^8, w^12 and w^16 are loaded (7 instead of 31)
-// and w^(16a+4b+c) = w^(16a) * (w^(4b) * w^c) is built with packed multiplies: at most
-// two extra roundings (~1e-7) on top of the table's correctly rounded entries.
-// The loads are split from their use so that they can be issued BEFORE the LDS exchange
-// of the stage and land while the workgroup sits in its barriers.
-constexpr int TW_SET = 7;     // twiddles held per butterfly: R=32: 7, R=16: 6, R<=8: R-1
+// Stage twiddles.  A radix-R stage needs w^r, r = 1..R-1, per butterfly, w = exp(-2 pi i k / (NS R)) depending on
+// the thread.  Radix <= 8 loads them all (8-byte loads from the generic table).  Radix 16 / 32 load a few powers
+// from the packed table (three 16-byte loads) and get the rest by multiplication -- radix 32 needs only
+// w, w^2, w^4, w^8, w^16 (fdit32), radix 16 holds w, w^2, w^3, w^4, w^8, w^12 and composes w^(4m+c).  At most two
+// extra roundings (~1e-7) on top of the table's correctly rounded entries.  The loads are split from their use so
+// that they are issued BEFORE the LDS exchange of the stage and land while the workgroup sits in its barriers.
+constexpr int TW_SET = 7;     // twiddles held per butterfly: R=32: 5, R=16: 6, R<=8: R-1
 
 template <int P, int T, int R, int NS, int OFF, int PK>
 __device__ __forceinline__ void tw_prefetch(v2f (&t)[P / R][TW_SET], __amdgpu_buffer_rsrc_t tw,
@@ -220,23 +214,20 @@ __device__ __forceinline__ void tw_prefetch(v2f (&t)[P / R][TW_SET], __amdgpu_bu
 #pragma unroll
     for (int b = 0; b < P / R; ++b) {
         const int koff = ((tid + T * b) & (NS - 1)) * 8;
-        if constexpr (R >= 16 && RO_TW_PACKED && !(RO_ABLATE & 1)) {
+        if constexpr (R >= 16 && !(RO_ABLATE & 1)) {
 #pragma unroll
-            for (int q = 0; q < (R == 32 ? 4 : 3); ++q) {
+            for (int q = 0; q < 3; ++q) {
                 const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(twk, koff * 2, (PK + q * NS) * 16, 0);
                 const v2f lo = (v2f){__uint_as_float(u.x), __uint_as_float(u.y)};
                 const v2f hi = (v2f){__uint_as_float(u.z), __uint_as_float(u.w)};
-                if (q == 0) { t[b][0] = lo; t[b][1] = hi; }        // w1, w2
-                else if (q == 1) { t[b][2] = lo; t[b][3] = hi; }   // w3, w4
-                else if (q == 2) { t[b][4] = lo; t[b][5] = hi; }   // w8, w12
-                else t[b][6] = lo;                                 // w16
+                // radix 32: t = {w, w^2, w^4, w^8, w^16}; radix 16: t = {w, w^2, w^3, w^4, w^8, w^12}
+                if (q == 0) { t[b][0] = lo; t[b][1] = hi; }
+                else if (q == 1) { t[b][2] = lo; t[b][3] = hi; }
+                else { t[b][4] = lo; if constexpr (R == 16) t[b][5] = hi; }
             }
-        } else if constexpr (R >= 16) {
+        } else if constexpr (R >= 16) {          // RO_ABLATE & 1: no loads
 #pragma unroll
-            for (int c = 1; c < 4; ++c) t[b][c - 1] = tw_load(tw, koff, OFF + (c - 1) * NS);
-#pragma unroll
-            for (int m = 1; m < 4; ++m) t[b][2 + m] = tw_load(tw, koff, OFF + (4 * m - 1) * NS);
-            if constexpr (R == 32) t[b][6] = tw_load(tw, koff, OFF + (16 - 1) * NS);
+            for (int c = 0; c < TW_SET; ++c) t[b][c] = tw_load(tw, koff, 0);
         } else {
 #pragma unroll
             for (int r = 1; r < R; ++r) t[b][r - 1] = tw_load(tw, koff, OFF + (r - 1) * NS);
@@ -244,65 +235,39 @@ __device__ __forceinline__ void tw_prefetch(v2f (&t)[P / R][TW_SET], __amdgpu_bu
     }
 }
 
+// stage twiddles applied up front: x[r] *= w^r, all R-1 powers held (radix <= 8; larger radices go through
+// tw_butterflies' fused forms and only come here in the RO_ABLATE & 8 diagnostic build, where results do not matter)
 template <int P, int R>
 __device__ __forceinline__ void tw_apply(v2f (&v)[P], const v2f (&t)[P / R][TW_SET])
 {
 #pragma unroll
     for (int b = 0; b < P / R; ++b) {
         v2f *x = &v[b * R];
-        if constexpr (R >= 16) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int r = 4 * m + c;
-                    if (r == 0) {
-                        if constexpr (R == 32) x[16] = cmul(x[16], t[b][6]);
-                        continue;
-                    }
-                    const v2f w = (m == 0) ? t[b][c - 1] : (c == 0) ? t[b][2 + m] : cmul(t[b][2 + m], t[b][c - 1]);
-                    x[r] = cmul(x[r], w);
-                    if constexpr (R == 32) x[16 + r] = cmul(x[16 + r], cmul(w, t[b][6]));
-                }
-            }
-        } else {
-#pragma unroll
-            for (int r = 1; r < R; ++r) x[r] = cmul(x[r], t[b][r - 1]);
-        }
+        for (int r = 1; r < R; ++r) x[r] = cmul(x[r], t[b][R <= 8 ? r - 1 : r % 5]);
     }
 }
 
-// Twiddles and butterflies of one stage.  Radix 16 / 32 in DIT form fuse the stage twiddles into the first level:
+// Twiddles and butterflies of one stage.  Radix 32: the twiddles are factored through the levels (fdit32 in
+// ro_fft_device.h).  Radix 16 fuses them into the first level:
 //   A = x[r] w^r (two ops),  a' = A + x[r+R/2] w^(r+R/2) (two FMAs),  b' = 2A - a' (one)
 // five issue slots per pair where twiddling both and then adding / subtracting takes six.
 template <int P, int R>
 __device__ __forceinline__ void tw_butterflies(v2f (&v)[P], const v2f (&t)[P / R][TW_SET])
 {
-    if constexpr (RO_DIT && R >= 16 && !(RO_ABLATE & 8)) {
+    if constexpr (R >= 16 && !(RO_ABLATE & 8)) {
 #pragma unroll
         for (int b = 0; b < P / R; ++b) {
             v2f *x = &v[b * R];
             constexpr int H = R / 2;
-            // w^r for r = 4m + c (c, m in 0..3) from the held set {w1,w2,w3,w4,w8,w12,(w16)}, as in tw_apply
+            // radix 16: w^r for r = 4m + c (c, m in 0..3) from the held set t = {w, w^2, w^3, w^4, w^8, w^12}
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int r = 4 * m + c;
                     if constexpr (R == 32) {
-                        // pair (r, 16 + r): w^(16+r) = w^r w^16
-                        if (r == 0) {
-                            const v2f A = x[0];
-                            const v2f s = cmadd(x[16], t[b][6], A);
-                            x[16] = __builtin_elementwise_fma(A, (v2f){2.0f, 2.0f}, -s);
-                            x[0] = s;
-                        } else {
-                            const v2f w = (m == 0) ? t[b][c - 1] : (c == 0) ? t[b][2 + m] : cmul(t[b][2 + m], t[b][c - 1]);
-                            const v2f A = cmul(x[r], w);
-                            const v2f s = cmadd(x[16 + r], cmul(w, t[b][6]), A);
-                            x[16 + r] = __builtin_elementwise_fma(A, (v2f){2.0f, 2.0f}, -s);
-                            x[r] = s;
-                        }
+                        continue;                                   // handled below (fdit32)
                     } else {
                         // R == 16: pairs (r, 8 + r) for r < 8; r >= 8 is the partner's twiddle w^(8+r')
                         if (r >= H) continue;
@@ -317,7 +282,8 @@ __device__ __forceinline__ void tw_butterflies(v2f (&v)[P], const v2f (&t)[P / R
                     }
                 }
             }
-            dit_after_first_level<R>(x);
+            if constexpr (R == 32) fdit32(x, t[b][4], t[b][3], t[b][2], t[b][1], t[b][0]);
+            else dit_after_first_level<R>(x);
         }
     } else {
         tw_apply<P, R>(v, t);
@@ -1259,14 +1225,16 @@ bool stft_window_layout(int bins, const float *w, float *out)
 }
 
 // packed twiddle table (StftArgs::twiddles_k) from the generic one: for every stage of radix 16 / 32, unit
-// q*NS + k = {w^a(k), w^b(k)} with (a, b) = (1,2) (3,4) (8,12) (16,16); generic entry (c-1)*NS + k = w^c(k).
+// q*NS + k = {w^a(k), w^b(k)} with (a, b) = (1,2) (4,8) (16,-) for radix 32 and (1,2) (3,4) (8,12) for radix 16;
+// generic entry (c-1)*NS + k = w^c(k).
 template <class PL> static void pack_twiddles(const float2 *tw, float4 *out)
 {
     const int radix[3] = {PL::R1, PL::R2, PL::R3}, ns[3] = {PL::NS1, PL::NS2, PL::NS3};
     const int off[3] = {PL::TW1, PL::TW2, PL::TW3}, pk[3] = {PL::PK1, PL::PK2, PL::PK3};
-    static const int pairs[4][2] = {{1, 2}, {3, 4}, {8, 12}, {16, 16}};
+    static const int pairs32[3][2] = {{1, 2}, {4, 8}, {16, 16}}, pairs16[3][2] = {{1, 2}, {3, 4}, {8, 12}};
     for (int s = 0; s < 3; ++s) {
         const int nq = PL::pkq(radix[s]);
+        const int(*pairs)[2] = radix[s] == 32 ? pairs32 : pairs16;
         for (int q = 0; q < nq; ++q)
             for (int k = 0; k < ns[s]; ++k) {
                 const float2 a = tw[off[s] + (pairs[q][0] - 1) * ns[s] + k];
