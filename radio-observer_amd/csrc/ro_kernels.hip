@@ -42,6 +42,10 @@
 #ifndef RO_WIN_PERM
 #define RO_WIN_PERM 1
 #endif
+// experiment: the 512-thread form of the N = 32768 plan (-DRO_T32768=512) with its window resident in registers
+#ifndef RO_T512_RESW
+#define RO_T512_RESW 0
+#endif
 // Plans with registers to spare (N <= 8192: LDS, not VGPRs, limits their occupancy) keep their window coefficients
 // and stage twiddles in registers for the whole persistent loop instead of re-reading them from L2 for every row --
 // per row only the samples come in and the magnitudes go out (14-35 % faster).  0 = reload per row like N >= 16384,
@@ -65,7 +69,9 @@
 #ifndef RO_USE_ADDTID
 #define RO_USE_ADDTID 1
 #endif
-// threads per workgroup of the N = 32768 plan (1024: 32 points per thread; 512: 64)
+// threads per workgroup of the N = 32768 plan: 1024 (32 points per thread) or 512 (64 points: every thread runs two
+// of the scheme's 1024 "logical threads"; same bits, 5 % slower -- 2 waves per SIMD -- and its 256 VGPRs still do not
+// hold window + twiddles resident, which was the point of trying it)
 #ifndef RO_T32768
 #define RO_T32768 1024
 #endif
@@ -109,8 +115,9 @@ struct Plan {
 // the N = 32768 plan exchanges through ds_write_addtid_b32 (see exchange_addtid)
 template <class PL> constexpr bool plan_addtid()
 {
-    return RO_USE_ADDTID && PL::N == 32768 && PL::T == 1024 && PL::P == 32 && PL::R0 == 32 && PL::R1 == 32 &&
-           PL::R2 == 32 && PL::R3 == 1 && PL::SPLIT;
+    // T threads run the 1024 "logical threads" of the scheme, P / 32 each (1024 x 1 or 512 x 2)
+    return RO_USE_ADDTID && PL::N == 32768 && (PL::T == 1024 || PL::T == 512) && PL::T * (PL::P / 32) == 1024 &&
+           PL::R0 == 32 && PL::R1 == 32 && PL::R2 == 32 && PL::R3 == 1 && PL::SPLIT;
 }
 template <class PL> constexpr bool plan_swap32() { return plan_addtid<PL>() && RO_SWAP32 && RO_PAIRED_LOADS; }
 
@@ -428,41 +435,55 @@ template <int ROWB, typename F> __device__ __forceinline__ void addtid_scatter32
 // XCH = 1: between stage 0 and 1, XCH = 2: between stage 1 and 2   (N = 32768, T = 1024, radix 32 everywhere)
 // With swap32 pairing the stage-0 thread at position t of a row holds column (t&~63) + 2(t&31) + ((t>>5)&1), so
 // column j = 32 r' + q sits at 64 (r'>>1) + 16 (r'&1) + 32 (q&1) + (q>>1): still one base + a literal per slot.
-template <int XCH, bool SWAP32, typename ST>
-__device__ __forceinline__ void exchange_addtid(void *smem, v2f (&v)[32], int tid, ST sub)
+template <int XCH, bool SWAP32, int NB, int T, typename ST>
+__device__ __forceinline__ void exchange_addtid(void *smem, v2f (&v)[32 * NB], int tid, ST sub)
 {
     if constexpr (RO_ABLATE & 4) return;
     constexpr int ROW = XCH == 1 ? 1025 : 1024;                   // floats per register-slot row of the image
     constexpr bool PERM = XCH == 1 && SWAP32;
     const float *lds = reinterpret_cast<const float *>(smem);
-    const unsigned wave_bytes = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6) * 256u;
-    const int q = tid >> 5;
-    const float *g = lds + (XCH == 1 ? (tid & 31) * 1025 + (PERM ? 32 * (q & 1) + (q >> 1) : q)
-                                     : (tid >> 5) * 1024 + (tid & 31));
+    // logical thread j = tid + T*b (b < NB) owns registers v[32b .. 32b+31]; everything below is the 1024-thread
+    // scheme written in terms of j
+    auto wave_bytes = [&](int b) { return (unsigned)__builtin_amdgcn_readfirstlane((tid + T * b) >> 6) * 256u; };
+    auto gbase = [&](int b) {
+        const int j = tid + T * b, q = j >> 5;
+        return lds + (XCH == 1 ? (j & 31) * 1025 + (PERM ? 32 * (q & 1) + (q >> 1) : q) : (j >> 5) * 1024 + (j & 31));
+    };
     auto goff = [](int r) constexpr { return PERM ? 64 * (r >> 1) + 16 * (r & 1) : 32 * r; };
     // volatile: keeps the 32 gathers single ds_read_b32 -- merged into ds_read2_b32 they come back as register
     // pairs of one plane and cost a v_mov each to interleave with the other plane (96 VALU ops per row)
     typedef const volatile __attribute__((address_space(3))) float lds_vfloat;
-    lds_vfloat *gv = (lds_vfloat *)g;
-    addtid_scatter32<ROW * 4>(wave_bytes, [&](int q) { return v[bitrev<32>(q)].x; });
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        addtid_scatter32<ROW * 4>(wave_bytes(b), [&](int q) { return v[32 * b + bitrev<32>(q)].x; });
     sub(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     sub(1);
 #pragma unroll
-    for (int r = 0; r < 32; ++r) v[r].x = gv[goff(r)];
+    for (int b = 0; b < NB; ++b) {
+        lds_vfloat *gv = (lds_vfloat *)gbase(b);
+#pragma unroll
+        for (int r = 0; r < 32; ++r) v[32 * b + r].x = gv[goff(r)];
+    }
     sub(2);
     wg_sync();
     sub(3);
-    addtid_scatter32<ROW * 4>(wave_bytes, [&](int q) { return v[bitrev<32>(q)].y; });
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        addtid_scatter32<ROW * 4>(wave_bytes(b), [&](int q) { return v[32 * b + bitrev<32>(q)].y; });
     sub(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     sub(1);
 #pragma unroll
-    for (int r = 0; r < 32; ++r) v[r].y = gv[goff(r)];
+    for (int b = 0; b < NB; ++b) {
+        lds_vfloat *gv = (lds_vfloat *)gbase(b);
+#pragma unroll
+        for (int r = 0; r < 32; ++r) v[32 * b + r].y = gv[goff(r)];
+    }
     sub(2);
     wg_sync();
     sub(3);
@@ -552,16 +573,24 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
     // halves the load time).  v[k] / v[R0/2+k] then hold the even / odd column of leg k
     // (resp. R0/2+k); the window stage multiplies them in place and a DPP swap between the
     // two lanes puts every sample into its natural slot.
-    constexpr bool PAIRED = (P == R0) && (R0 % 2 == 0) && RO_PAIRED_LOADS;
+    // NB stage-0 butterflies per thread: "logical thread" j = tid + T*b (b < NB) owns v[R0*b .. R0*b + R0-1].  The
+    // paired scheme needs one butterfly per logical thread; the add-TID plan runs 1024 of them on 1024 or 512 threads.
+    constexpr int NB = P / R0, TL = T * NB;
+    constexpr bool PAIRED = (NB == 1 || ADDTID) && (R0 % 2 == 0) && RO_PAIRED_LOADS;
     constexpr int H = R0 / 2;
     constexpr bool SWAP32 = plan_swap32<PL>();
-    const int pair_off = plan_pair_off<PL>(tid);                     // first sample this lane fetches
+    auto pair_off = [&](int b) { return plan_pair_off<PL>(tid + T * b); };   // first sample logical thread b fetches
     auto load_row = [&](const __amdgpu_buffer_rsrc_t &rs) {
         if constexpr (PAIRED) {
 #pragma unroll
-            for (int k = 0; k < H; ++k) {
-                if constexpr ((RO_ABLATE & 32) != 0) { v[k] = (v2f){(float)(tid + k), 1.0f}; v[H + k] = v[k]; }
-                else S::load_pair(rs, pair_off * S::BYTES, k * (N / R0) * S::BYTES, v[k], v[H + k]);
+            for (int b = 0; b < NB; ++b) {
+                const int po = pair_off(b) * S::BYTES;
+#pragma unroll
+                for (int k = 0; k < H; ++k) {
+                    v2f &lo = v[R0 * b + k], &hi = v[R0 * b + H + k];
+                    if constexpr ((RO_ABLATE & 32) != 0) { lo = (v2f){1.0f + k, 0.5f}; hi = (v2f){0.25f, 2.0f + k}; }
+                    else S::load_pair(rs, po, k * (N / R0) * S::BYTES, lo, hi);
+                }
             }
         } else {
 #pragma unroll
@@ -595,7 +624,8 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
     constexpr int NW = PAIRED ? H : P;
     using wtype = std::conditional_t<PAIRED, v2f, float>;
     wtype w[WPERM ? 1 : NW];
-    v4f w4[WPERM ? NW / 2 : 1];        // kernel-order table: legs 2q, 2q+1 as {even, odd, even, odd} column coefficients
+    // kernel-order table: legs 2q, 2q+1 as {even, odd, even, odd} column coefficients, per logical thread
+    v4f w4[WPERM ? NB * (NW / 2) : 1];
     // first..last-1 of the NW coefficient registers
     auto load_window = [&](const __amdgpu_buffer_rsrc_t &rs_win, auto first_c, auto last_c) {
         constexpr int first = decltype(first_c)::value, last = decltype(last_c)::value;
@@ -603,18 +633,24 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             // kernel-order table: 16 bytes per lane = the coefficient pairs of legs k, k+1
             static_assert(first % 2 == 0 && last % 2 == 0, "window chunks are pairs of legs");
 #pragma unroll
-            for (int k = first; k < last; k += 2) {
-                if constexpr (RO_ABLATE & 2) w4[k / 2] = (v4f){0.5f, 0.5f, 0.5f, 0.5f};
-                else {
-                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_win, tid * 16, (k / 2) * T * 16, 0);
-                    w4[k / 2] = (v4f){__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
+            for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                for (int k = first; k < last; k += 2) {
+                    v4f &d = w4[b * (NW / 2) + k / 2];
+                    if constexpr (RO_ABLATE & 2) d = (v4f){0.5f, 0.5f, 0.5f, 0.5f};
+                    else {
+                        const u32x4 t =
+                            __builtin_amdgcn_raw_buffer_load_b128(rs_win, (tid + T * b) * 16, (k / 2) * TL * 16, 0);
+                        d = (v4f){__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
+                    }
                 }
             }
         } else if constexpr (PAIRED) {
+            static_assert(NB == 1 || WPERM, "several logical threads need the kernel-order window table");
 #pragma unroll
             for (int k = first; k < last; ++k) {
                 if constexpr (RO_ABLATE & 2) w[k] = (v2f){0.5f, 0.5f};
-                else w[k] = buf_load_f2(rs_win, pair_off * 4, k * (N / R0) * 4);
+                else w[k] = buf_load_f2(rs_win, pair_off(0) * 4, k * (N / R0) * 4);
             }
         } else {
 #pragma unroll
@@ -635,7 +671,9 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
     const float *win_tab = WPERM ? a.window_k : a.window;
     load_window(make_rsrc(win_tab, N * 4), c0{}, cN{});
     // window and twiddle tables resident in registers (see RO_RESIDENT_TABLES)
-    constexpr bool RES = RO_RESIDENT_TABLES && N <= 8192 && !RO_ABLATE;
+    constexpr bool RES = RO_RESIDENT_TABLES && N <= 8192 && !RO_ABLATE;              // twiddles (and window)
+    // the 512-thread form of the N = 32768 plan has 256 VGPRs per thread: the window stays, the twiddles do not fit
+    constexpr bool RESW = RES || (RO_T512_RESW && ADDTID && T == 512 && !RO_ABLATE);
     v2f tw1[PL::R1 > 1 ? P / PL::R1 : 1][TW_SET];
     v2f tw2[PL::R2 > 1 ? P / PL::R2 : 1][TW_SET];
     v2f tw3[PL::R3 > 1 ? P / PL::R3 : 1][TW_SET];
@@ -658,32 +696,37 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             if constexpr (PAIRED) {
                 const bool odd = tid & 1;
 #pragma unroll
+                for (int b = 0; b < NB; ++b) {
+#pragma unroll
                 for (int k = 0; k < H; ++k) {
+                    v2f &lo = v[R0 * b + k], &hi = v[R0 * b + H + k];
                     v2f we, wo;                                    // coefficient of the even / odd column, both halves
                     if constexpr (WPERM) {
-                        we = (k & 1) ? w4[k / 2].zz : w4[k / 2].xx;
-                        wo = (k & 1) ? w4[k / 2].ww : w4[k / 2].yy;
+                        const v4f c4 = w4[b * (NW / 2) + k / 2];
+                        we = (k & 1) ? c4.zz : c4.xx;
+                        wo = (k & 1) ? c4.ww : c4.yy;
                     } else {
                         we = w[k].xx;
                         wo = w[k].yy;
                     }
-                    const v2f e = v[k] * we;                       // even column, leg k (H+k on odd lanes)
-                    const v2f o = v[H + k] * wo;                   // odd column
+                    const v2f e = lo * we;                         // even column, leg k (H+k on odd lanes)
+                    const v2f o = hi * wo;                         // odd column
                     if constexpr (SWAP32) {
                         // lanes 0..31 hold legs k, lanes 32..63 legs H+k of both columns: the upper half of slot k
                         // trades places with the lower half of slot H+k (v_permlane32_swap_b32)
                         const auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(e.x), __float_as_uint(o.x), false, false);
                         const auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(e.y), __float_as_uint(o.y), false, false);
-                        v[k] = (v2f){__uint_as_float(rx[0]), __uint_as_float(ry[0])};
-                        v[H + k] = (v2f){__uint_as_float(rx[1]), __uint_as_float(ry[1])};
+                        lo = (v2f){__uint_as_float(rx[0]), __uint_as_float(ry[0])};
+                        hi = (v2f){__uint_as_float(rx[1]), __uint_as_float(ry[1])};
                         continue;
                     }
                     // even lane keeps e in slot k and takes the partner's e (leg H+k) into slot H+k;
                     // odd lane keeps o in slot H+k and takes the partner's o (leg k) into slot k.
                     const v2f pe = (v2f){dpp_quad<0xB1>(e.x), dpp_quad<0xB1>(e.y)};
                     const v2f po = (v2f){dpp_quad<0xB1>(o.x), dpp_quad<0xB1>(o.y)};
-                    v[k] = odd ? po : e;
-                    v[H + k] = odd ? o : pe;
+                    lo = odd ? po : e;
+                    hi = odd ? o : pe;
+                }
                 }
             } else {
 #pragma unroll
@@ -693,7 +736,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         // The coefficients for the NEXT row are requested right away: their registers are free
         // from here on and the loads overlap the whole transform instead of the epilogue's
         // memory burst.  (Unconditional: the same table every row.)
-        if constexpr (!RES) load_window(make_rsrc(win_tab, N * 4), c0{}, cE{});
+        if constexpr (!RESW) load_window(make_rsrc(win_tab, N * 4), c0{}, cE{});
         const int64_t next = row + stride;
         const bool has_next = next < xcd_end;
         unsigned touched0 = 0, touched1 = 0;
@@ -716,7 +759,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
 
         // ---- stage 1
         if constexpr (PL::R1 > 1) {
-            if constexpr (ADDTID) exchange_addtid<1, SWAP32>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
+            if constexpr (ADDTID) exchange_addtid<1, SWAP32, P / 32, T>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             else exchange<PL, PL::R0, 1, PL::R1>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             stamp(3);                               // exchange 1
             if constexpr (RO_PREFETCH_NEXT == 2) touch_next();
@@ -726,7 +769,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         // ---- stage 2
         if constexpr (PL::R2 > 1) {
             if constexpr (!RES) tw_prefetch<P, T, PL::R2, PL::NS2, PL::TW2, PL::PK2>(tw2, rs_tw, rs_twk, tid);
-            if constexpr (ADDTID) exchange_addtid<2, SWAP32>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
+            if constexpr (ADDTID) exchange_addtid<2, SWAP32, P / 32, T>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             else exchange<PL, PL::R1, PL::NS1, PL::R2>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             stamp(5);                               // exchange 2
             if constexpr (RO_PREFETCH_NEXT == 3) touch_next();
@@ -752,15 +795,18 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         if constexpr (ADDTID) {
             // slot q of thread `tid` is column tid + 1024 q: byte 4096 q + 4 tid of the LDS image, i.e. the row in
             // natural order, written lane-linearly (ds_write_addtid_b32); the fft-shift moves into the store offsets
-            float m[32];
 #pragma unroll
-            for (int r = 0; r < 32; ++r) {
-                const v2f x = v[bitrev<32>(r)];
-                const v2f sq = x * x;
-                m[r] = __builtin_amdgcn_sqrtf(sq.x + sq.y);      // v_sqrt_f32, 1 ulp
+            for (int b = 0; b < NB; ++b) {
+                float m[32];
+#pragma unroll
+                for (int r = 0; r < 32; ++r) {
+                    const v2f x = v[32 * b + bitrev<32>(r)];
+                    const v2f sq = x * x;
+                    m[r] = __builtin_amdgcn_sqrtf(sq.x + sq.y);      // v_sqrt_f32, 1 ulp
+                }
+                const unsigned wave_bytes = (unsigned)__builtin_amdgcn_readfirstlane((tid + T * b) >> 6) * 256u;
+                addtid_scatter32<4096>(wave_bytes, [&](int q) { return m[q]; });
             }
-            const unsigned wave_bytes = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6) * 256u;
-            addtid_scatter32<4096>(wave_bytes, [&](int q) { return m[q]; });
         } else {
             float *lds_m = reinterpret_cast<float *>(smem);
 #pragma unroll
@@ -781,7 +827,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
                            has_next ? N * S::BYTES : 0));
         // unconditional (zero-sized descriptor after the last row): a branch here would keep the
         // old coefficients alive next to the new ones
-        if constexpr (!RES) load_window(make_rsrc(win_tab, has_next ? N * 4 : 0), cE{}, cN{});
+        if constexpr (!RESW) load_window(make_rsrc(win_tab, has_next ? N * 4 : 0), cE{}, cN{});
         stamp(7);                                   // next-row loads issued
         wg_sync();
         stamp(11);                                  // barrier 1
@@ -1143,7 +1189,7 @@ template <class PL, int FMT> static hipError_t launch_plan(const StftArgs &a, hi
     // The touches park hop*BYTES per resident workgroup in the XCD's 4 MiB L2 for most of a row time.  Past half of
     // it they push out the rows being transformed and every line is fetched twice (seen at overlap 0: FETCH_SIZE x2,
     // 19 % slower).  Plans with several workgroups per CU hide the miss behind each other and gain nothing (measured).
-    b.prefetch = (PL::T == 1024 && slots * (int64_t)a.hop * Sample<FMT>::BYTES <= (2 << 20)) ? 1 : 0;
+    b.prefetch = (plan_addtid<PL>() && slots * (int64_t)a.hop * Sample<FMT>::BYTES <= (2 << 20)) ? 1 : 0;
     {
         static int force = -2;                         // experiment knob: RO_PREFETCH=0/1 overrides the rule
         if (force == -2) {
@@ -1211,8 +1257,9 @@ int stft_twiddle_count(int bins)
 // S = N/R0 and c = the first sample it fetches (plan_pair_off), k = 0, 2, .. R0/2-2.
 template <class PL> static void window_layout(const float *w, float *out)
 {
-    constexpr int N = PL::N, T = PL::T, R0 = PL::R0, H = R0 / 2, S = N / R0;
-    static_assert(PL::P == R0 && H % 2 == 0, "paired plan");
+    constexpr int N = PL::N, R0 = PL::R0, H = R0 / 2, S = N / R0;
+    constexpr int T = PL::T * (PL::P / R0);                      // logical threads: one stage-0 butterfly each
+    static_assert((PL::P == R0 || plan_addtid<PL>()) && H % 2 == 0, "paired plan");
     for (int tid = 0; tid < T; ++tid) {
         const int c = plan_pair_off<PL>(tid);
         for (int k = 0; k < H; ++k) {
