@@ -226,7 +226,10 @@ def main():
     iq = synth_iq(torch, samples, 0xC3 + rank, dev)       # this rank's time chunk
     rows = torch.empty((R, BINS), dtype=torch.float32, device=dev)
     recs = [torch.zeros((R, 3), dtype=torch.float32, device=dev) for _ in range(2)]   # ro_scan_record_t = 12 B
-    st = ro.Stft(bins=BINS, overlap=OVERLAP, sample_rate=FS, device=local_rank, bands=bands, tile=tile)
+    # N > 1: the STFT kernel of the large plans owns every register of the CUs it runs on, so the all-gather's
+    # kernels (side stream) would only run between two of its launches; one CU per XCD is left to them
+    st = ro.Stft(bins=BINS, overlap=OVERLAP, sample_rate=FS, device=local_rank, bands=bands, tile=tile,
+                 spare_cus_per_xcd=1 if world > 1 else 0)
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
 

@@ -81,6 +81,11 @@ typedef struct ro_stft_config {
     ro_bands_t   bands;            /* used when enable_scan                         */
     int32_t      tile_first_col;   /* compact band tile [tile_first_col, +tile_cols)*/
     int32_t      tile_cols;        /* 0 = no tile                                   */
+    int32_t      spare_cus_per_xcd;/* CUs per XCD the persistent STFT grid leaves    */
+                                   /* free (0..16).  The N >= 16384 kernels fill a   */
+                                   /* CU's registers, so nothing else runs beside    */
+                                   /* them; 1 lets a concurrent kernel on another    */
+                                   /* stream (an RCCL collective) make progress.     */
 } ro_stft_config_t;
 
 typedef struct ro_stft ro_stft_t;

@@ -45,7 +45,7 @@ class Config(C.Structure):
                 ("window_table", C.POINTER(C.c_float)), ("iq_gain", C.c_double),
                 ("iq_phase_shift", C.c_int32), ("device", C.c_int32), ("max_batch_rows", C.c_int32),
                 ("enable_scan", C.c_int32), ("bands", Bands), ("tile_first_col", C.c_int32),
-                ("tile_cols", C.c_int32)]
+                ("tile_cols", C.c_int32), ("spare_cus_per_xcd", C.c_int32)]
 
 
 _EXPORTS = {
@@ -178,7 +178,7 @@ class Stft:
 
     def __init__(self, bins=32768, overlap=0, sample_rate=48000, window=RO_WINDOW_NUTTALL,
                  window_table=None, iq_gain=0.0, iq_phase_shift=0, device=0, max_batch_rows=0,
-                 bands=None, tile=None):
+                 bands=None, tile=None, spare_cus_per_xcd=0):
         cfg = Config()
         cfg.struct_size = C.sizeof(Config)
         cfg.bins, cfg.overlap, cfg.sample_rate = bins, overlap, sample_rate
@@ -199,6 +199,7 @@ class Stft:
             cfg.bands = bands
         if tile is not None:
             cfg.tile_first_col, cfg.tile_cols = tile
+        cfg.spare_cus_per_xcd = spare_cus_per_xcd
         self._h = C.c_void_p()
         _check(library().ro_stft_create(C.byref(cfg), C.byref(self._h)))
         self.bins = bins

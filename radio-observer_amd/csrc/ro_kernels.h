@@ -27,6 +27,7 @@ struct StftArgs {
     unsigned long long *stamps; // diagnostic builds only (RO_STAMPS), else nullptr
     int           stagger;     // start delay per workgroup slot, shader cycles (0 = none)
     int           prefetch;    // set by the launcher: touch the next row's new samples ahead of time
+    int           spare_cus;   // CUs per XCD the persistent grid leaves to other kernels (ro_stft_config_t)
 };
 
 struct TileArgs {

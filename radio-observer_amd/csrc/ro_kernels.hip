@@ -1160,6 +1160,7 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void scan_kernel(ScanArgs a)
 template <class PL, int FMT> static hipError_t launch_plan(const StftArgs &a, hipStream_t s)
 {
     static int resident = 0;            // workgroups resident on the device (all CUs)
+    static int per_cu_static = 1;       // ... per CU
     if (resident == 0) {
         const void *fn = reinterpret_cast<const void *>(&stft_kernel<PL, FMT>);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PL::LDS_BYTES);
@@ -1170,10 +1171,12 @@ template <class PL, int FMT> static hipError_t launch_plan(const StftArgs &a, hi
         if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, PL::T, PL::LDS_BYTES)) != hipSuccess)
             return e;
         if (per_cu < 1) per_cu = 1;
+        per_cu_static = per_cu;
         resident = cus * per_cu;
     }
     const int64_t per_xcd = (a.rows + 7) / 8;
     int64_t slots = resident / 8;                       // workgroups per XCD
+    if (a.spare_cus > 0) slots -= (int64_t)a.spare_cus * per_cu_static;
     if (slots < 1) slots = 1;
     if (slots > per_xcd) slots = per_xcd;
     {

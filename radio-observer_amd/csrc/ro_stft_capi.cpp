@@ -209,6 +209,7 @@ ro::StftArgs make_stft_args(const ro_stft *h, const void *d_iq, int64_t first_ro
     a.hop = h->hop;
     a.gain = (float)h->cfg.iq_gain;
     a.stamps = h->d_stamps;
+    a.spare_cus = h->cfg.spare_cus_per_xcd;
     return a;
 }
 
@@ -473,6 +474,8 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg, ro_stft_t **out)
         return fail(RO_ERR_UNSUPPORTED, "iq_phase_shift != 0 is undefined behaviour in the reference "
                                         "(src/FFTBackend.cpp:67-71) and is not supported");
     if (cfg->sample_rate <= 0) return fail(RO_ERR_INVALID, "sample_rate must be positive");
+    if (cfg->spare_cus_per_xcd < 0 || cfg->spare_cus_per_xcd > 16)
+        return fail(RO_ERR_INVALID, "spare_cus_per_xcd must be in [0, 16]");
     if (cfg->window_kind == RO_WINDOW_CUSTOM && !cfg->window_table)
         return fail(RO_ERR_INVALID, "RO_WINDOW_CUSTOM needs window_table");
     if (cfg->window_kind < RO_WINDOW_NUTTALL || cfg->window_kind > RO_WINDOW_CUSTOM)
