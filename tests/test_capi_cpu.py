@@ -69,6 +69,22 @@ def test_supported_sizes(ro):
         assert not ro.bins_supported(b)
 
 
+def test_config_is_validated_before_any_device_work(ro):
+    """Argument errors come back as RO_ERR_INVALID / RO_ERR_UNSUPPORTED with or without a GPU."""
+    for kw, code in ((dict(bins=1000), -2), (dict(bins=1024, iq_phase_shift=1), -2),
+                     (dict(bins=1024, sample_rate=0), -1), (dict(bins=1024, spare_cus_per_xcd=17), -1),
+                     (dict(bins=1024, spare_cus_per_xcd=-1), -1)):
+        with pytest.raises(ro.StftError) as e:
+            ro.Stft(**kw)
+        assert e.value.code == code, (kw, str(e.value))
+    # the compiled struct and the ctypes mirror agree (ro_stft_create rejects a wrong struct_size)
+    cfg = ro.capi.Config()
+    cfg.struct_size = C.sizeof(ro.capi.Config) - 4
+    cfg.bins = 1024
+    h = C.c_void_p()
+    assert ro.library().ro_stft_create(C.byref(cfg), C.byref(h)) == -1
+
+
 def test_no_cpu_fallback(ro):
     """Without a HIP device the product must refuse, not compute on the CPU."""
     import torch
