@@ -51,6 +51,8 @@ def parse():
     p.add_argument("--rows", type=int, default=16384, help="rows per step per GPU")
     p.add_argument("--bins", type=int, default=32768, help="FFT size (default = the headline C3/C4 workload)")
     p.add_argument("--overlap", type=int, default=None, help="overlap in samples (default 75 %% of bins)")
+    p.add_argument("--window", choices=["nuttall", "hann"], default="nuttall",
+                   help="nuttall = what the reference runs (src/FFTBackend.cpp:165-184); hann = BASELINE's C2 wording")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-parity", action="store_true")
@@ -229,6 +231,7 @@ def main():
     # N > 1: the STFT kernel of the large plans owns every register of the CUs it runs on, so the all-gather's
     # kernels (side stream) would only run between two of its launches; one CU per XCD is left to them
     st = ro.Stft(bins=BINS, overlap=OVERLAP, sample_rate=FS, device=local_rank, bands=bands, tile=tile,
+                 window=ro.RO_WINDOW_HANN if a.window == "hann" else ro.RO_WINDOW_NUTTALL,
                  spare_cus_per_xcd=1 if world > 1 else 0)
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
@@ -301,9 +304,10 @@ def main():
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: synthetic IQ 48 kHz, FFT bins=%d, overlap=%d (%d%%), "
-                                   "Nuttall window, waterfall magnitude rows + BolidRecorder scan"
-                                   % ("C3/C4" if (BINS, OVERLAP) == (32768, 24576) else "custom", BINS, OVERLAP,
-                                      round(100.0 * OVERLAP / BINS)),
+                                   "%s window, waterfall magnitude rows + BolidRecorder scan"
+                                   % ("C3/C4" if (BINS, OVERLAP) == (32768, 24576) else
+                                      "C2" if (BINS, OVERLAP) == (4096, 2048) else "custom", BINS, OVERLAP,
+                                      round(100.0 * OVERLAP / BINS), a.window.capitalize()),
                        "rows_per_step_per_gpu": R, "samples_per_step_per_gpu": samples,
                        "input": "float32 I/Q resident in HBM", "output": "float32 rows in HBM",
                        "parallelism": "time-chunk per GPU" + ("; all-gather of band tile [%d,+%d) + scan "
