@@ -143,6 +143,16 @@ int ro_stft_run_resident(ro_stft_t *h, const void *d_iq, int format, int64_t sam
                          float *d_rows, int64_t row_stride,
                          float *d_tile, ro_scan_record_t *d_records, void *stream);
 
+/* The complex spectra themselves instead of their magnitudes: what fftw_execute leaves in out_
+ * (src/FFTBackend.cpp:236) and hands to the protected hook FFTBackend::processFFT(const fftw_complex *data,
+ * int size, DataInfo, int rawMark) (src/FFTBackend.h:104) -- bin k of row r at d_spectra[r * stride + k] as
+ * {float re, float im}, unshifted (k = 0 is DC), unnormalised, after gain and window like the magnitude path.
+ * Same kernels with a different last step; rows x stride x 8 bytes are written.  bins <= 32768 only
+ * (RO_ERR_UNSUPPORTED above).  Asynchronous on `stream`. */
+int ro_stft_spectra_resident(ro_stft_t *h, const void *d_iq, int format, int64_t samples,
+                             int64_t first_row, int64_t rows,
+                             float *d_spectra /* rows x stride x {re, im} */, int64_t stride, void *stream);
+
 /* BolidRecorder::noise/peak/average over rows already in HBM
  * (src/BolidRecorder.cpp:121-132, :313-347). */
 int ro_stft_scan_resident(ro_stft_t *h, const float *d_rows, int64_t row_stride, int64_t rows,

@@ -70,6 +70,8 @@ _EXPORTS = {
     "ro_stft_set_bands": (C.c_int, [C.c_void_p, C.POINTER(Bands)]),
     "ro_stft_run_resident": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64,
                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ro_stft_spectra_resident": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64,
+                                           C.c_void_p, C.c_int64, C.c_void_p]),
     "ro_stft_scan_resident": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                         C.c_void_p]),
     "ro_stft_ln_tile_resident": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
@@ -246,6 +248,11 @@ class Stft:
         _check(library().ro_stft_run_resident(self._h, _ptr(d_iq), fmt, samples, first_row, rows,
                                               _ptr(d_rows), row_stride or self.bins, _ptr(d_tile),
                                               _ptr(d_records), _ptr(stream)))
+
+    def spectra_resident(self, d_iq, fmt, samples, first_row, rows, d_spectra, stride=None, stream=None):
+        """complex spectra (rows x stride x {re, im} float32, bin k at element k) instead of magnitudes"""
+        _check(library().ro_stft_spectra_resident(self._h, _ptr(d_iq), fmt, samples, first_row, rows,
+                                                  _ptr(d_spectra), stride or self.bins, _ptr(stream)))
 
     def scan_resident(self, d_rows, rows, d_records, row_stride=None, stream=None):
         _check(library().ro_stft_scan_resident(self._h, _ptr(d_rows), row_stride or self.bins, rows,

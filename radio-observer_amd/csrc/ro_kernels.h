@@ -18,7 +18,9 @@ struct StftArgs {
     const float  *window_k;    // the same coefficients in kernel order (stft_window_layout)
     const float2 *twiddles;    // per-stage tables (device), see build_twiddles
     const float4 *twiddles_k;  // radix-16/32 stages repacked for 16-byte loads (stft_pack_twiddles)
-    float        *rows_out;    // rows x row_stride
+    float        *rows_out;    // rows x row_stride (magnitude mode)
+    float2       *spec_out;    // non-null selects the complex-spectrum mode: rows x spec_stride float2, bin k at [k]
+    int64_t       spec_stride;
     int64_t       first_row;
     int64_t       rows;
     int64_t       row_stride;

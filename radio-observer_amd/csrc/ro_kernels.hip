@@ -529,7 +529,10 @@ template <> struct Sample<RO_FMT_I16> {
 // rows, the row stores drain while the next row is being loaded, and the next row's
 // samples are requested from inside the epilogue, each into the register whose
 // magnitude has just been stored.
-template <class PL, int FMT>
+// MODE 0: magnitude rows (the waterfall).  MODE 1: the complex spectrum itself, bin k at element k of the row
+// (what fftw_execute leaves in out_ and FFTBackend::processFFT receives, src/FFTBackend.h:104): same transform, the
+// epilogue stores v[] as it is -- no magnitude, no shift, no LDS staging.
+template <class PL, int FMT, int MODE>
 __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
 {
     constexpr int N = PL::N, T = PL::T, P = PL::P;
@@ -792,6 +795,27 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         // lane and stored -- 1 KiB per wave-instruction, the stores being the LAST thing in the
         // VMEM queue.
         if constexpr (RO_PREFETCH_NEXT) asm volatile("" ::"v"(touched0), "v"(touched1));   // keeps the touches alive
+        if constexpr (MODE == 1) {
+            // slot r of butterfly b is bin (tid + T b) + r N/RL: 8 bytes per lane, 512 contiguous bytes per wave
+            const __amdgpu_buffer_rsrc_t rs_spec =
+                make_rsrc(a.spec_out + row * a.spec_stride, (unsigned)N * 8u);
+#pragma unroll
+            for (int b = 0; b < P / RL; ++b) {
+#pragma unroll
+                for (int r = 0; r < RL; ++r) {
+                    const v2f x = v[b * RL + bitrev<RL>(r)];
+                    const u32x2 t = {__float_as_uint(x.x), __float_as_uint(x.y)};
+                    __builtin_amdgcn_raw_buffer_store_b64(t, rs_spec, (tid + T * b) * 8, r * (N / RL) * 8, RO_STORE_AUX);
+                }
+            }
+            load_row(make_rsrc(iq + (a.first_row + (has_next ? next : row)) * (int64_t)a.hop * S::BYTES,
+                               has_next ? N * S::BYTES : 0));
+            if constexpr (!RESW) load_window(make_rsrc(win_tab, has_next ? N * 4 : 0), cE{}, cN{});
+            st_acc[9] += 1;
+            if (!has_next) break;
+            row = next;
+            continue;
+        }
         if constexpr (ADDTID) {
             // slot q of thread `tid` is column tid + 1024 q: byte 4096 q + 4 tid of the LDS image, i.e. the row in
             // natural order, written lane-linearly (ds_write_addtid_b32); the fft-shift moves into the store offsets
@@ -1157,12 +1181,12 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void scan_kernel(ScanArgs a)
 // ---------------------------------------------------------------------------
 // Persistent launch: as many workgroups as the device can hold at once (rounded down to a
 // multiple of 8 so every XCD gets the same share), never more than there are rows.
-template <class PL, int FMT> static hipError_t launch_plan(const StftArgs &a, hipStream_t s)
+template <class PL, int FMT, int MODE> static hipError_t launch_plan(const StftArgs &a, hipStream_t s)
 {
     static int resident = 0;            // workgroups resident on the device (all CUs)
     static int per_cu_static = 1;       // ... per CU
     if (resident == 0) {
-        const void *fn = reinterpret_cast<const void *>(&stft_kernel<PL, FMT>);
+        const void *fn = reinterpret_cast<const void *>(&stft_kernel<PL, FMT, MODE>);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PL::LDS_BYTES);
         if (e != hipSuccess) return e;
         int dev = 0, cus = 0, per_cu = 0;
@@ -1209,7 +1233,7 @@ template <class PL, int FMT> static hipError_t launch_plan(const StftArgs &a, hi
         }
         b.stagger = stagger;
     }
-    hipLaunchKernelGGL((stft_kernel<PL, FMT>), dim3(grid), dim3(PL::T), PL::LDS_BYTES, s, b);
+    hipLaunchKernelGGL((stft_kernel<PL, FMT, MODE>), dim3(grid), dim3(PL::T), PL::LDS_BYTES, s, b);
     return hipGetLastError();
 }
 
@@ -1225,8 +1249,9 @@ using Plan256   = Plan<  256,   64,  4,  4,  4, 4, false>;
 
 template <class PL> static hipError_t launch_fmt(const StftArgs &a, int fmt, hipStream_t s)
 {
-    if (fmt == RO_FMT_F32) return launch_plan<PL, RO_FMT_F32>(a, s);
-    if (fmt == RO_FMT_I16) return launch_plan<PL, RO_FMT_I16>(a, s);
+    const bool spec = a.spec_out != nullptr;
+    if (fmt == RO_FMT_F32) return spec ? launch_plan<PL, RO_FMT_F32, 1>(a, s) : launch_plan<PL, RO_FMT_F32, 0>(a, s);
+    if (fmt == RO_FMT_I16) return spec ? launch_plan<PL, RO_FMT_I16, 1>(a, s) : launch_plan<PL, RO_FMT_I16, 0>(a, s);
     return hipErrorInvalidValue;
 }
 

@@ -677,6 +677,22 @@ extern "C" int ro_stft_run_resident(ro_stft_t *h, const void *d_iq, int format, 
     return RO_OK;
 }
 
+extern "C" int ro_stft_spectra_resident(ro_stft_t *h, const void *d_iq, int format, int64_t samples,
+                                        int64_t first_row, int64_t rows, float *d_spectra, int64_t stride,
+                                        void *stream)
+{
+    // same argument checks as the magnitude path (d_spectra in the place of d_rows)
+    int rc = validate_resident(h, d_iq, format, samples, first_row, rows, d_spectra, stride, nullptr, nullptr);
+    if (rc != RO_OK) return rc;
+    if (h->big) return fail(RO_ERR_UNSUPPORTED, "complex spectra are available for bins <= 32768");
+    HIP_TRY(hipSetDevice(h->device));
+    ro::StftArgs a = make_stft_args(h, d_iq, first_row, rows, nullptr, 0);
+    a.spec_out = reinterpret_cast<float2 *>(d_spectra);
+    a.spec_stride = stride;
+    HIP_TRY(ro::launch_stft(h->bins, format, a, (hipStream_t)stream));
+    return RO_OK;
+}
+
 extern "C" int ro_stft_scan_resident(ro_stft_t *h, const float *d_rows, int64_t row_stride, int64_t rows,
                                      ro_scan_record_t *d_records, void *stream)
 {
