@@ -95,4 +95,59 @@ private:
     DataInfo   dataInfo_;
 };
 
+// src/Frontend.h:24-60, src/Frontend.cpp:16-60: a sample source.  run() reads its input and feeds the backend
+// through startStream() / process() / endStream(); stop() asks a running frontend to finish.
+class Frontend {
+public:
+    Frontend() {}
+    virtual ~Frontend() {}
+    void setBackend(Backend *backend) { backend_ = backend; }
+    Backend *getBackend() const { return backend_; }
+    virtual void run() = 0;
+    virtual void stop() { stopping_ = true; }                       // src/Frontend.cpp:55-58
+
+protected:
+    void startStream()                                              // src/Frontend.cpp:16-27
+    {
+        if (!backend_) return;
+        backend_->startStream(streamInfo_);
+        dataInfo_.offset = 0;
+        dataInfo_.timeOffset = streamInfo_.timeOffset;
+    }
+    void endStream() { if (backend_) backend_->endStream(); }       // :30-38
+    void process(const std::vector<Complex> &data)                  // :41-52
+    {
+        if (!backend_) return;
+        backend_->process(data, dataInfo_);
+        dataInfo_.offset += data.size();
+        dataInfo_.timeOffset = streamInfo_.timeOffset.addSamples(dataInfo_.offset, streamInfo_.sampleRate);
+    }
+
+    Backend   *backend_ = nullptr;
+    StreamInfo streamInfo_;
+    DataInfo   dataInfo_;
+    bool       stopping_ = false;
+};
+
+// src/Pipeline.h:24-58, src/Pipeline.cpp:11-36: binds a frontend to a backend and runs it.  (The reference's
+// agents -- MetadataAgent and friends -- have empty bodies and are not mirrored; ownership is the caller's.)
+class Pipeline {
+public:
+    Frontend *getFrontend() const { return frontend_; }
+    void setFrontend(Frontend *frontend) { frontend_ = frontend; }
+    Backend *getBackend() const { return backend_; }
+    void setBackend(Backend *backend) { backend_ = backend; }
+    void run()                                                      // src/Pipeline.cpp:11-19
+    {
+        if (!frontend_) return;
+        frontend_->setBackend(backend_);
+        frontend_->run();
+    }
+    void stop() { if (frontend_) frontend_->stop(); }               // :22-36
+
+private:
+    Frontend *frontend_ = nullptr;
+    Backend  *backend_ = nullptr;
+};
+
 }  // namespace ro

@@ -15,12 +15,12 @@ std::string WAVStream::readString(int length)
 }
 
 // src/WAVStream.cpp:198-245 (run) and :158-183 (readSubchunk)
-bool WAVStream::run()
+void WAVStream::run()
 {
     streamInfo_ = StreamInfo();
-    if (readString(4) != "RIFF") { error_ = "Invalid chunk ID. Stream may not be in WAV format."; return false; }
+    if (readString(4) != "RIFF") { error_ = "Invalid chunk ID. Stream may not be in WAV format."; return; }
     int64_t chunkSize = (int64_t)readScalar<uint32_t>();
-    if (readString(4) != "WAVE") { error_ = "Invalid chunk format. Stream may not be in WAV format."; return false; }
+    if (readString(4) != "WAVE") { error_ = "Invalid chunk format. Stream may not be in WAV format."; return; }
     chunkSize -= 4;
     dataRead_ = false;
     while (chunkSize > 0 && in_.good()) {
@@ -42,7 +42,7 @@ bool WAVStream::run()
             inf1_ = readString((int)size);
         } else if (id == "data") {                                        // :169-176
             if (!dataRead_) {
-                driver_.startStream(streamInfo_);
+                startStream();
                 dataRead_ = true;
             }
             if (!readDataSubchunk(size)) break;
@@ -53,8 +53,7 @@ bool WAVStream::run()
         // (Appendix B-1); the correct accounting is used here
         chunkSize -= size + 8;
     }
-    if (dataRead_) driver_.endStream();                                   // :243-244
-    return error_.empty();
+    if (dataRead_) endStream();                                           // :243-244
 }
 
 // src/WAVStream.cpp:101-143
@@ -73,7 +72,7 @@ bool WAVStream::readDataSubchunk(int64_t size)
     std::vector<int16_t> raw((size_t)kBlockFrames * 2);
     std::vector<Complex> out;
     int64_t remaining = size;
-    while (remaining >= format_.blockAlign && in_.good()) {
+    while (remaining >= format_.blockAlign && in_.good() && !stopping_) {
         const int64_t want = std::min<int64_t>(remaining, (int64_t)kBlockFrames * format_.blockAlign);
         in_.read(reinterpret_cast<char *>(raw.data()), want);
         const int64_t got = in_.gcount();
@@ -86,7 +85,7 @@ bool WAVStream::readDataSubchunk(int64_t size)
             out[(size_t)s].real = (double)raw[(size_t)s * 2];             // :119  un-normalised int16
             out[(size_t)s].imag = (double)raw[(size_t)s * 2 + 1];         // :120
         }
-        driver_.process(out);
+        process(out);
         frames_ += frames;
         remaining -= got;
         if (got < want) break;
@@ -100,11 +99,11 @@ void RawStream::run()
 {
     std::vector<float> raw((size_t)kBlockFrames * 2);
     std::vector<Complex> out;
-    StreamInfo info;
-    info.sampleRate = sampleRate_;
-    info.timeOffset = start_;                 // the reference stamps WFTime::now() (:40); injectable here
-    driver_.startStream(info);
-    for (;;) {
+    streamInfo_ = StreamInfo();
+    streamInfo_.sampleRate = sampleRate_;
+    streamInfo_.timeOffset = start_;          // the reference stamps WFTime::now() (:40); injectable here
+    startStream();
+    while (!stopping_) {                                                  // :44
         in_.read(reinterpret_cast<char *>(raw.data()), (std::streamsize)(raw.size() * sizeof(float)));
         const int64_t frames = in_.gcount() / (int64_t)(sizeof(float) * 2);   // :58
         if (frames <= 0) break;
@@ -113,11 +112,11 @@ void RawStream::run()
             out[(size_t)i].real = raw[(size_t)i * 2];                     // :61
             out[(size_t)i].imag = raw[(size_t)i * 2 + 1];                 // :62
         }
-        driver_.process(out);
+        process(out);
         frames_ += frames;
         if (!in_.good()) break;
     }
-    driver_.endStream();
+    endStream();
 }
 
 }  // namespace ro

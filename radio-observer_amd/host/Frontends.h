@@ -18,11 +18,12 @@ struct WAVFormat {                       // src/WAVStream.h:33-49
     int audioFormat = 0, channelCount = 0, sampleRate = 0, byteRate = 0, blockAlign = 0, bitsPerSample = 0;
 };
 
-class WAVStream {
+class WAVStream : public Frontend {
 public:
-    WAVStream(std::istream &in, Backend *backend) : in_(in), driver_(backend) {}
-    // Returns false (after logging to lastError()) where the reference logs an error and returns.
-    bool run();
+    explicit WAVStream(std::istream &in, Backend *backend = nullptr) : in_(in) { setBackend(backend); }
+    // src/WAVStream.cpp:198-245.  Where the reference logs an error and returns, lastError() holds the text.
+    void run() override;
+    bool ok() const { return error_.empty(); }
     const WAVFormat &format() const { return format_; }
     const std::string &inf1() const { return inf1_; }
     const std::string &lastError() const { return error_; }
@@ -39,25 +40,22 @@ private:
     std::string readString(int length);
 
     std::istream  &in_;
-    FrontendDriver driver_;
     WAVFormat      format_;
     std::string    inf1_, error_;
-    StreamInfo     streamInfo_;
     bool           dataRead_ = false;
     int64_t        frames_ = 0;
     static const int kBlockFrames = 1024;            // dataBufferSize_, src/WAVStream.cpp:190
 };
 
-class RawStream {
+class RawStream : public Frontend {
 public:
     RawStream(std::istream &in, Backend *backend, int sampleRate, WFTime start = WFTime())
-        : in_(in), driver_(backend), sampleRate_(sampleRate), start_(start) {}
-    void run();                                       // src/RawStream.cpp:30-69
+        : in_(in), sampleRate_(sampleRate), start_(start) { setBackend(backend); }
+    void run() override;                              // src/RawStream.cpp:30-69
     int64_t framesDelivered() const { return frames_; }
 
 private:
     std::istream  &in_;
-    FrontendDriver driver_;
     int            sampleRate_;
     WFTime         start_;
     int64_t        frames_ = 0;

@@ -36,12 +36,12 @@ int ro_host_ring_free_reservation(void *r, int h) { return RING(r)->freeReservat
 int ro_host_ring_is_dirty(void *r, int h) { return RING(r)->isDirty(h) ? 1 : 0; }
 
 // ---- Frontend -> HipWaterfallBackend -> {SnapshotRecorder, BolidRecorder}
-struct Pipeline {
+struct Rig {
     HipWaterfallBackend backend;
     SnapshotRecorder snap;
     BolidRecorder bolid;
     FrontendDriver frontend;
-    Pipeline(const WaterfallConfig &w, const BolidConfig &b, const SnapshotConfig &sc, bool with_snapshot)
+    Rig(const WaterfallConfig &w, const BolidConfig &b, const SnapshotConfig &sc, bool with_snapshot)
         : backend(w), snap(&backend, sc), bolid(&backend, b), frontend(&backend)
     {
         if (with_snapshot) backend.addRecorder(&snap);       // same order as radio-observer.json:52-88
@@ -69,7 +69,7 @@ void *ro_host_pipeline_create(int bins, int overlap, int sample_rate, int64_t st
     b.jitter_time = jitter_time;
     b.avg_freq_range = avg_range;
     b.write_files = false;
-    Pipeline *p = new Pipeline(w, b, SnapshotConfig(), false);
+    Rig *p = new Rig(w, b, SnapshotConfig(), false);
     StreamInfo si;
     si.sampleRate = sample_rate;
     si.timeOffset = WFTime(start_sec, start_usec);
@@ -97,7 +97,7 @@ void *ro_host_pipeline_create_snap(int bins, int overlap, int sample_rate, int64
     b.snapshot_length = snapshot_length;
     b.low_detect_freq = 10300; b.hi_detect_freq = 10900; b.low_noise_freq = 9000; b.hi_noise_freq = 9600;
     b.advance_time = 2; b.jitter_time = 5;
-    Pipeline *p = new Pipeline(w, b, sc, true);
+    Rig *p = new Rig(w, b, sc, true);
     StreamInfo si;
     si.sampleRate = sample_rate;
     si.timeOffset = WFTime(start_sec, start_usec);
@@ -107,9 +107,9 @@ void *ro_host_pipeline_create_snap(int bins, int overlap, int sample_rate, int64
 int ro_host_pipeline_files(void *p, char *buf, int len)
 {
     std::string all;
-    for (const auto &f : static_cast<Pipeline *>(p)->snap.filesWritten()) all += f + "\n";
+    for (const auto &f : static_cast<Rig *>(p)->snap.filesWritten()) all += f + "\n";
     std::snprintf(buf, (size_t)len, "%s", all.c_str());
-    return (int)static_cast<Pipeline *>(p)->snap.filesWritten().size();
+    return (int)static_cast<Rig *>(p)->snap.filesWritten().size();
 }
 static int joinNames(const std::vector<std::string> &v, char *buf, int len)
 {
@@ -121,22 +121,22 @@ static int joinNames(const std::vector<std::string> &v, char *buf, int len)
 // files of the detector: raw = 0 the band snapshots ("blid"), raw = 1 the raw I/Q captures ("raws")
 int ro_host_pipeline_bolid_files(void *p, int raw, char *buf, int len)
 {
-    const BolidRecorder &b = static_cast<Pipeline *>(p)->bolid;
+    const BolidRecorder &b = static_cast<Rig *>(p)->bolid;
     return joinNames(raw ? b.rawFilesWritten() : b.filesWritten(), buf, len);
 }
 // pin WFTime::now() for the event lines; the metadata CSV's current file name ("" before the first entry)
 void ro_host_pipeline_set_clock(void *p, int64_t sec, int64_t usec)
 {
-    static_cast<Pipeline *>(p)->backend.setClock(WFTime(sec, usec));
+    static_cast<Rig *>(p)->backend.setClock(WFTime(sec, usec));
 }
 int ro_host_pipeline_metadata_file(void *p, char *buf, int len)
 {
-    CsvLog *log = static_cast<Pipeline *>(p)->backend.getMetadataFile();
+    CsvLog *log = static_cast<Rig *>(p)->backend.getMetadataFile();
     std::snprintf(buf, (size_t)len, "%s", log ? log->currentFile().c_str() : "");
     return log ? 1 : 0;
 }
-void ro_host_pipeline_destroy(void *p) { delete static_cast<Pipeline *>(p); }
-#define PIPE(p) static_cast<Pipeline *>(p)
+void ro_host_pipeline_destroy(void *p) { delete static_cast<Rig *>(p); }
+#define PIPE(p) static_cast<Rig *>(p)
 
 // one Frontend::process() call: n complex doubles
 void ro_host_pipeline_process(void *p, const double *iq, int n)
@@ -218,15 +218,21 @@ void *ro_host_frontend_run(int kind, const char *bytes, int64_t n, int sample_ra
 {
     FrontendRun *r = new FrontendRun();
     std::istringstream in(std::string(bytes, (size_t)n));
+    // through Pipeline, the way the reference's main() wires them (src/Pipeline.cpp:11-19)
+    ro::Pipeline pipe;
+    pipe.setBackend(&r->backend);
     if (kind == 0) {
-        WAVStream w(in, &r->backend);
-        r->ok = w.run();
+        WAVStream w(in);
+        pipe.setFrontend(&w);
+        pipe.run();
+        r->ok = w.ok();
         r->format = w.format();
         r->error = w.lastError();
         r->inf1 = w.inf1();
     } else {
-        RawStream w(in, &r->backend, sample_rate, WFTime(start_sec, start_usec));
-        w.run();
+        RawStream w(in, nullptr, sample_rate, WFTime(start_sec, start_usec));
+        pipe.setFrontend(&w);
+        pipe.run();
         r->ok = true;
     }
     return r;
@@ -280,8 +286,12 @@ int64_t ro_host_wav_to_fits(const char *bytes, int64_t n, int bins, int overlap,
     SnapshotRecorder snap(&backend, sc);
     backend.addRecorder(&snap);
     std::istringstream in(std::string(bytes, (size_t)n));
-    WAVStream wav(in, &backend);
-    const bool ok = wav.run();
+    WAVStream wav(in);
+    ro::Pipeline pipe;                                   // Frontend -> Pipeline -> Backend, as in the reference's main()
+    pipe.setFrontend(&wav);
+    pipe.setBackend(&backend);
+    pipe.run();
+    const bool ok = wav.ok();
     std::string all;
     for (const auto &f : snap.filesWritten()) all += f + "\n";
     std::snprintf(files, (size_t)files_len, "%s", all.c_str());
