@@ -131,3 +131,29 @@ def test_full_size_scan_records_and_detection(ro, oracle, torch_cuda):
         assert detect[r0:r0 + 4].any(), (i, t0)
         assert not detect[max(0, r0 - 40):r0 - 4].any(), (i, t0)
     assert 0 < detect.sum() < R // 10
+
+
+@pytest.mark.parametrize("bins,overlap,R", [(32768, 24576, 6000), (4096, 2048, 40000), (1024, 512, 100000)])
+def test_int16_samples_under_load(ro, oracle, torch_cuda, bins, overlap, R):
+    """The int16 (WAV) sample format has its own kernel instantiations: same shard-invariance check with every CU
+    busy, plus oracle rows at three places."""
+    torch = torch_cuda
+    hop = bins - overlap
+    samples = bins + hop * (R - 1)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(bins)
+    i16 = torch.randint(-20000, 20000, (samples, 2), generator=g, device="cuda", dtype=torch.int16)
+    rows = torch.empty((R, bins), dtype=torch.float32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    with ro.Stft(bins=bins, overlap=overlap) as st:
+        st.run_resident(i16, ro.RO_IQ_I16, samples, 0, R, rows, stream=s)
+        part = torch.empty((R // 3 + 1, bins), dtype=torch.float32, device="cuda")
+        for first in (0, R // 3 + 1, 2 * (R // 3 + 1)):
+            n = min(R // 3 + 1, R - first)
+            st.run_resident(i16, ro.RO_IQ_I16, samples, first, n, part, stream=s)
+            torch.cuda.synchronize()
+            assert torch.equal(part[:n].view(torch.int32), rows[first:first + n].view(torch.int32)), first
+    host = i16.cpu().numpy().astype(np.float64)
+    for r in (0, R // 2, R - 1):
+        want = oracle.stft(host[r * hop:r * hop + bins], bins, overlap)[0]
+        assert rel_to_row_max(rows[r].cpu().numpy()[None], want[None]) <= 1e-5
