@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libro_oracle.so")
+_LIB_PATH = os.environ.get("RO_ORACLE_LIB") or os.path.join(_HERE, "libro_oracle.so")   # override: sanitizer builds
 
 
 def build(force=False):

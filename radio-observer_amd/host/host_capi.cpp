@@ -262,7 +262,7 @@ int64_t ro_host_frontend_samples(void *r, double *out, int64_t max)
 {
     const auto &s = FR(r)->backend.samples;
     const int64_t n = std::min<int64_t>((int64_t)s.size(), max);
-    if (out) std::memcpy(out, s.data(), sizeof(Complex) * (size_t)n);
+    if (out && n > 0) std::memcpy(out, s.data(), sizeof(Complex) * (size_t)n);
     return (int64_t)s.size();
 }
 

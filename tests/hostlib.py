@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PATH = os.path.join(ROOT, "radio-observer_amd", "host", "libro_host.so")
+PATH = os.environ.get("RO_HOST_LIB") or os.path.join(ROOT, "radio-observer_amd", "host", "libro_host.so")
 _lib = False
 
 
