@@ -48,6 +48,9 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=30)
+    p.add_argument("--prewarm", type=int, default=25,
+                   help="untimed launches before the W warm-up steps: the device needs ~20 launches after idle to "
+                        "settle its clocks (first launches run 1.06, 1.24, 1.45, 1.35 ... ms), whatever W is")
     p.add_argument("--rows", type=int, default=16384, help="rows per step per GPU")
     p.add_argument("--bins", type=int, default=32768, help="FFT size (default = the headline C3/C4 workload)")
     p.add_argument("--overlap", type=int, default=None, help="overlap in samples (default 75 %% of bins)")
@@ -271,7 +274,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for i in range(a.warmup):
+    for i in range(a.prewarm + a.warmup):
         step(i)
     fence()
     ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-parity"      # the default run: 30 warm-up + 50 timed steps
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-parity"      # the default run: 25 pre-warm + 30 warm-up + 50 timed steps
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.log
 echo "trace done"
 SHORT="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity"

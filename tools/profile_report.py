@@ -27,7 +27,7 @@ for f in glob.glob(os.path.join(d, "trace", "*", "*_kernel_trace.csv")):
            if "stft_kernel" in r["Kernel_Name"]]
     if dur:
         n = len(dur)
-        k = (n - 30) // 2 if n > 40 else n // 2
+        k = (n - 55) // 2 if n > 70 else n // 2
         print("  stft_kernel launches in issue order, us: first 12 = %s" % [round(x) for x in dur[:12]])
         print("  mean of the last %d launches (the ones bench.py's HIP events time): %.1f us; of the %d before them "
               "(the timed steps): %.1f us" % (k, sum(dur[-k:]) / k, k, sum(dur[-2 * k:-k]) / k))
