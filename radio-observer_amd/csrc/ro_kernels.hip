@@ -1037,6 +1037,20 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(LnArgs a)
     }
 }
 
+// inclusive prefix sum over the 64 lanes with DPP moves (VALU only; a __shfl_up ladder is six dependent LDS round
+// trips): shifts by 1, 2, 4, 8 inside each row of 16 lanes, then the row totals are passed on with row_bcast
+__device__ __forceinline__ unsigned wave_inclusive_sum(unsigned x)
+{
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);     // row_shr:1, out-of-row lanes read 0
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);     // row_bcast:15 -> rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);     // row_bcast:31 -> rows 2 and 3
+    return (unsigned)v;
+}
+
 constexpr int SCAN_E = 16;            // noise-band elements cached per lane (band <= 1024)
 constexpr int SCAN_WAVES = 4;         // rows per workgroup
 
@@ -1092,12 +1106,7 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void scan_kernel(ScanArgs a)
             }
             const uint4 b = reinterpret_cast<const uint4 *>(h)[lane];          // bins 4 lane .. 4 lane + 3
             const unsigned s = b.x + b.y + b.z + b.w;
-            unsigned inc = s;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const unsigned t = __shfl_up(inc, d);
-                if (lane >= d) inc += t;
-            }
+            const unsigned inc = wave_inclusive_sum(s);
             const unsigned exc = inc - s;
             const bool mine = exc <= (unsigned)k && (unsigned)k < inc;         // exactly one lane: total > k
             unsigned below = exc, bin = 0;
@@ -1108,9 +1117,9 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void scan_kernel(ScanArgs a)
                     if ((unsigned)k >= below + b.z) { below += b.z; bin = 3; }
                 }
             }
-            const int owner = __ffsll((long long)__ballot(mine)) - 1;
-            const unsigned digit = (unsigned)__shfl((int)(4 * lane + bin), owner);
-            k -= __shfl((int)below, owner);
+            const int owner = __ffsll((long long)__ballot(mine)) - 1;                  // wave-uniform
+            const unsigned digit = (unsigned)__builtin_amdgcn_readlane((int)(4 * lane + bin), owner);
+            k -= __builtin_amdgcn_readlane((int)below, owner);
             prefix = (prefix << 8) | digit;
         }
         result = prefix;
