@@ -853,6 +853,9 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         // old coefficients alive next to the new ones
         if constexpr (!RESW) load_window(make_rsrc(win_tab, has_next ? N * 4 : 0), cE{}, cN{});
         stamp(7);                                   // next-row loads issued
+        // the add-TID writes sit inside inline asm: hipcc does not count them, so the barrier's own lgkmcnt wait
+        // is missing unless it is spelled out (the image is read by OTHER waves right behind the barrier)
+        if constexpr (ADDTID) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wg_sync();
         stamp(11);                                  // barrier 1
         {

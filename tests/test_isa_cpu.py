@@ -65,3 +65,21 @@ def test_lds_traffic_between_consecutive_barriers(isa):
                 seen, lds = True, False
             elif re.search(r"\bds_(read|write|add)|buffer_load.*\blds\b", line):
                 lds = True
+
+
+def test_addtid_writes_are_waited_for_before_the_barrier(isa):
+    """ds_write_addtid_b32 sits in inline asm, which hipcc's waitcnt insertion does not see: every s_barrier that
+    follows such writes needs an explicit s_waitcnt lgkmcnt(0) in between, or other waves read the image too early."""
+    ks = kernels(isa)
+    checked = 0
+    for name, body in ks.items():
+        pending = False
+        for i, line in enumerate(body):
+            if "ds_write_addtid_b32" in line:
+                pending = True
+                checked += 1
+            elif pending and re.search(r"s_waitcnt\b.*lgkmcnt\(0\)", line):
+                pending = False
+            elif "s_barrier" in line:
+                assert not pending, "s_barrier after un-waited ds_write_addtid_b32 in %s at +%d" % (name, i)
+    assert checked > 0
