@@ -110,6 +110,22 @@ int     ro_time_to_fft_samples(double seconds, float fft_sample_rate);
 int64_t ro_row_count(int64_t samples, int bins, int overlap);
 /* window table as FFTBackend::startStream builds it, :156-186 */
 int     ro_window_table(int kind, int bins, float *out);
+/* ---- time-chunk sharding of one stream over `world` GPUs ------------------------
+ * Rows are independent (row r needs samples [r*hop, r*hop+bins) only,
+ * src/FFTBackend.cpp:211-257), so shard g takes the contiguous rows
+ * [floor(g*R/world), floor((g+1)*R/world)) and the samples under them; neighbouring
+ * shards overlap by the bins-hop samples of halo.  Pure host arithmetic, no device. */
+int     ro_shard_rows(int64_t total_rows, int world, int rank, int64_t *first_row, int64_t *rows);
+/* first sample and sample count shard [first_row, +rows) must hold (halo included; 0 samples for an empty shard) */
+int     ro_shard_samples(int64_t first_row, int64_t rows, int bins, int overlap,
+                         int64_t *first_sample, int64_t *samples);
+/* rows every rank contributes to an equal-block all-gather: the largest shard */
+int64_t ro_shard_max_rows(int64_t total_rows, int world);
+/* Stitch the result of an equal-block all-gather (world blocks of ro_shard_max_rows rows of
+ * row_bytes each, short shards zero-padded at their end) into total_rows consecutive rows --
+ * the row order the FITS writer (src/WaterfallBackend.cpp:141-211) and BolidRecorder's state
+ * machine (src/BolidRecorder.cpp:171-273) consume.  Host memory; `out` may not alias `gathered`. */
+int     ro_stitch_rows(const void *gathered, int64_t total_rows, int world, size_t row_bytes, void *out);
 /* 1 if `bins` has a kernel in this build: powers of two 256 .. 1048576 (single pass up to
  * 32768, multi-pass through HBM scratch above) */
 int     ro_bins_supported(int bins);

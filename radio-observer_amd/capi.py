@@ -61,6 +61,11 @@ _EXPORTS = {
     "ro_row_count": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "ro_window_table": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "ro_bins_supported": (C.c_int, [C.c_int]),
+    "ro_shard_rows": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "ro_shard_samples": (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int64)]),
+    "ro_shard_max_rows": (C.c_int64, [C.c_int64, C.c_int]),
+    "ro_stitch_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_void_p]),
     "ro_stft_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
     "ro_stft_destroy": (C.c_int, [C.c_void_p]),
     "ro_stft_get_window": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
@@ -152,6 +157,37 @@ def window_table(kind, bins):
     w = np.empty(bins, dtype=np.float32)
     _check(library().ro_window_table(kind, bins, w.ctypes.data_as(C.POINTER(C.c_float))))
     return w
+
+
+def shard_rows(total_rows, world, rank):
+    """(first_row, rows) of `rank` -- ro_shard_rows"""
+    first, rows = C.c_int64(), C.c_int64()
+    _check(library().ro_shard_rows(int(total_rows), world, rank, C.byref(first), C.byref(rows)))
+    return first.value, rows.value
+
+
+def shard_samples(first_row, rows, bins, overlap):
+    """(first_sample, samples) a shard must hold, halo included -- ro_shard_samples"""
+    s0, ns = C.c_int64(), C.c_int64()
+    _check(library().ro_shard_samples(int(first_row), int(rows), bins, overlap, C.byref(s0), C.byref(ns)))
+    return s0.value, ns.value
+
+
+def shard_max_rows(total_rows, world):
+    n = library().ro_shard_max_rows(int(total_rows), world)
+    if n < 0:
+        _check(int(n))
+    return int(n)
+
+
+def stitch_rows(gathered, total_rows, world):
+    """numpy [world * max_rows, ...] (equal-block all-gather result) -> [total_rows, ...] in row order"""
+    g = np.ascontiguousarray(gathered)
+    row_bytes = g.strides[0]
+    out = np.empty((int(total_rows),) + g.shape[1:], dtype=g.dtype)
+    _check(library().ro_stitch_rows(C.c_void_p(g.ctypes.data), int(total_rows), world, row_bytes,
+                                    C.c_void_p(out.ctypes.data)))
+    return out
 
 
 def bins_supported(bins):

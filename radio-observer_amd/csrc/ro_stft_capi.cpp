@@ -456,6 +456,54 @@ extern "C" int ro_window_table(int kind, int bins, float *out)
     return RO_OK;
 }
 
+// ---------------------------------------------------------------------------
+// time-chunk sharding (host arithmetic; the Python side, timeshard.py, calls these)
+// ---------------------------------------------------------------------------
+extern "C" int ro_shard_rows(int64_t total_rows, int world, int rank, int64_t *first_row, int64_t *rows)
+{
+    if (total_rows < 0 || world < 1 || rank < 0 || rank >= world || !first_row || !rows)
+        return fail(RO_ERR_INVALID, "ro_shard_rows: bad arguments");
+    // 128-bit products: rank * total_rows overflows int64 only for absurd sizes, but costs nothing to rule out
+    const int64_t lo = (int64_t)(((__int128)rank * total_rows) / world);
+    const int64_t hi = (int64_t)(((__int128)(rank + 1) * total_rows) / world);
+    *first_row = lo;
+    *rows = hi - lo;
+    return RO_OK;
+}
+
+extern "C" int ro_shard_samples(int64_t first_row, int64_t rows, int bins, int overlap, int64_t *first_sample,
+                                int64_t *samples)
+{
+    if (first_row < 0 || rows < 0 || bins < 2 || !first_sample || !samples)
+        return fail(RO_ERR_INVALID, "ro_shard_samples: bad arguments");
+    const int64_t hop = bins - ro_clamp_overlap(bins, overlap);
+    *first_sample = first_row * hop;
+    *samples = rows > 0 ? (rows - 1) * hop + bins : 0;
+    return RO_OK;
+}
+
+extern "C" int64_t ro_shard_max_rows(int64_t total_rows, int world)
+{
+    if (total_rows < 0 || world < 1) return fail(RO_ERR_INVALID, "ro_shard_max_rows: bad arguments");
+    return (total_rows + world - 1) / world;       // sizes differ by at most one: the largest is the ceiling
+}
+
+extern "C" int ro_stitch_rows(const void *gathered, int64_t total_rows, int world, size_t row_bytes, void *out)
+{
+    if (total_rows < 0 || world < 1 || (total_rows > 0 && (!gathered || !out)))
+        return fail(RO_ERR_INVALID, "ro_stitch_rows: bad arguments");
+    const int64_t block = ro_shard_max_rows(total_rows, world);
+    const char *src = static_cast<const char *>(gathered);
+    char *dst = static_cast<char *>(out);
+    for (int g = 0; g < world; ++g) {
+        int64_t first = 0, rows = 0;
+        ro_shard_rows(total_rows, world, g, &first, &rows);
+        std::memcpy(dst + (size_t)first * row_bytes, src + (size_t)g * (size_t)block * row_bytes,
+                    (size_t)rows * row_bytes);
+    }
+    return RO_OK;
+}
+
 extern "C" int ro_bins_supported(int bins) { return (ro::stft_supported(bins) || ro::big_supported(bins)) ? 1 : 0; }
 
 // ---------------------------------------------------------------------------

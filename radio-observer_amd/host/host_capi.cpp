@@ -402,4 +402,40 @@ int ro_host_manual_events(void *m, BolidEvent *out, int max)
     return (int)ev.size();
 }
 
+
+// ---- the product's BolidRecorder driven by a stream of scan records (the stitched (n, p, a) stream of a
+// multi-GPU run: tests/test_gpu_c5.py): no files, zero rows in the ring, events out
+int64_t ro_host_bolid_replay(int bins, int overlap, int sample_rate, float lo_det, float hi_det, float lo_noise,
+                             float hi_noise, double advance_time, double jitter_time, float avg_range,
+                             const ro_scan_record_t *recs, int64_t n, BolidEvent *out, int max)
+{
+    WaterfallConfig w;
+    w.bins = bins;
+    w.overlap = overlap;
+    w.metadata_path = "";
+    w.keep_raw = false;
+    BolidConfig b;
+    b.write_files = false;
+    b.low_detect_freq = lo_det; b.hi_detect_freq = hi_det; b.low_noise_freq = lo_noise; b.hi_noise_freq = hi_noise;
+    b.advance_time = advance_time; b.jitter_time = jitter_time; b.avg_freq_range = avg_range;
+    ManualWaterfall source(w);
+    BolidRecorder bolid(&source, b);
+    source.addRecorder(&bolid);
+    StreamInfo si;
+    si.sampleRate = sample_rate;
+    source.startStream(si);
+    const std::vector<float> row((size_t)bins, 0.f);
+    const int hop = bins - ro_clamp_overlap(bins, overlap);
+    WFTime t(0, 0);
+    for (int64_t r = 0; r < n; ++r) {
+        source.pushRow(row.data(), &recs[r], t, (int)((r + 1) * hop + 1));
+        t = t.addSamples(hop, sample_rate);
+    }
+    source.endStream();
+    const auto &ev = bolid.events();
+    const int64_t m = std::min<int64_t>((int64_t)ev.size(), max);
+    for (int64_t i = 0; i < m; ++i) out[i] = ev[(size_t)i];
+    return (int64_t)ev.size();
+}
+
 }  // extern "C"

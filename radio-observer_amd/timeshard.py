@@ -9,54 +9,81 @@ each rank's band tile [rows_g x tile_cols] and scan records [rows_g x 3 words], 
 every rank holds the waterfall band and the (n, p, a) stream in row order -- what the
 reference's FITS writer (src/WaterfallBackend.cpp:141-211) and BolidRecorder's state machine
 (src/BolidRecorder.cpp:171-273) consume.
+
+The shard arithmetic itself lives behind the C ABI (ro_shard_rows / ro_shard_samples /
+ro_shard_max_rows / ro_stitch_rows, include/ro_stft.h) so that a C++ host needs no Python;
+this module is the torch.distributed plumbing around it.
 """
 import torch
 import torch.distributed as dist
 
+from . import capi
+
 
 def shard_rows(total_rows, world, rank):
     """(first_row, rows) of `rank`: contiguous, sizes differ by at most one."""
-    lo = (rank * total_rows) // world
-    hi = ((rank + 1) * total_rows) // world
-    return lo, hi - lo
+    return capi.shard_rows(total_rows, world, rank)
 
 
 def shard_samples(first_row, rows, bins, hop):
     """(first_sample, samples) a shard must hold, halo included; (x, 0) for an empty shard."""
-    if rows <= 0:
-        return first_row * hop, 0
-    return first_row * hop, (rows - 1) * hop + bins
+    return capi.shard_samples(first_row, rows, bins, bins - hop)
 
 
 def all_shards(total_rows, world):
     return [shard_rows(total_rows, world, g) for g in range(world)]
 
 
-def gather_rows(local, total_rows, group=None, async_op=False):
+def pad_block(local, total_rows, world):
+    """This rank's rows as the equal-sized block an all-gather needs: ro_shard_max_rows rows, zero-padded."""
+    max_rows = capi.shard_max_rows(total_rows, world)
+    if local.shape[0] == max_rows:
+        return local.contiguous()
+    send = torch.zeros((max_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    send[:local.shape[0]] = local
+    return send
+
+
+def stitch(recv, total_rows, world):
+    """[world * max_rows, C] as an equal-block all-gather leaves it -> [total_rows, C] in row order
+    (the device-tensor form of ro_stitch_rows: the padding of the short shards is cut)."""
+    shards = all_shards(total_rows, world)
+    max_rows = capi.shard_max_rows(total_rows, world)
+    if all(r == max_rows for _, r in shards):
+        return recv
+    return torch.cat([recv[g * max_rows:g * max_rows + r] for g, (_, r) in enumerate(shards)], dim=0)
+
+
+def gather_rows(local, total_rows, group=None, async_op=False, root=None):
     """All-gather per-rank row blocks [rows_g, C] into [total_rows, C] in row order.
 
     Shards may differ by one row, all_gather_into_tensor needs equal blocks: every rank
     contributes max_rows rows (its own, zero-padded) and the padding is cut on arrival.
-    Returns (stitched, work) -- `work` is None unless async_op."""
+    root = r gathers to rank r only (the other ranks get None): 1/world of the inbound traffic
+    per non-root rank, for when only one rank writes the FITS files.
+    Returns (stitched, work) -- `work` is None unless async_op, and `stitched` is then a
+    callable to be invoked after work.wait()."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     shards = all_shards(total_rows, world)
-    max_rows = max(r for _, r in shards)
-    cols = local.shape[1]
     assert local.shape[0] == shards[rank][1], (local.shape, shards[rank])
-    if local.shape[0] == max_rows:
-        send = local.contiguous()
+    send = pad_block(local, total_rows, world)
+    max_rows = send.shape[0]
+    if root is None:
+        recv = torch.empty((world * max_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        work = dist.all_gather_into_tensor(recv, send, group=group, async_op=async_op)
     else:
-        send = torch.zeros((max_rows, cols), dtype=local.dtype, device=local.device)
-        send[:local.shape[0]] = local
-    recv = torch.empty((world * max_rows, cols), dtype=local.dtype, device=local.device)
-    work = dist.all_gather_into_tensor(recv, send, group=group, async_op=async_op)
+        recv = None
+        parts = None
+        if rank == root:
+            recv = torch.empty((world * max_rows,) + tuple(local.shape[1:]), dtype=local.dtype,
+                               device=local.device)
+            parts = list(recv.view((world, max_rows) + tuple(local.shape[1:])).unbind(0))
+        work = dist.gather(send, parts, dst=root, group=group, async_op=async_op)
 
-    def stitch():
-        if all(r == max_rows for _, r in shards):
-            return recv
-        return torch.cat([recv[g * max_rows:g * max_rows + r] for g, (_, r) in enumerate(shards)], dim=0)
+    def finish():
+        return None if recv is None else stitch(recv, total_rows, world)
 
     if async_op:
-        return stitch, work
-    return stitch(), None
+        return finish, work
+    return finish(), None

@@ -104,3 +104,28 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile")):
                 text = open(os.path.join(d, f), errors="replace").read()
                 assert "ro_oracle" not in text and "oracle/" not in text, os.path.join(d, f)
+
+
+def test_shard_helpers_of_the_c_abi(ro):
+    """ro_shard_rows / ro_shard_samples / ro_shard_max_rows / ro_stitch_rows: contiguous cover, sizes within one,
+    halo = bins - hop, and the stitch undoes the equal-block padding of an all-gather."""
+    for total in (0, 1, 7, 8, 41, 168747):
+        for world in (1, 2, 3, 8):
+            shards = [ro.shard_rows(total, world, g) for g in range(world)]
+            assert shards[0][0] == 0 and sum(r for _, r in shards) == total
+            for g in range(1, world):
+                assert shards[g][0] == shards[g - 1][0] + shards[g - 1][1]
+            assert ro.shard_max_rows(total, world) == max(r for _, r in shards)
+            # an all-gather of zero-padded blocks, stitched back
+            full = np.arange(total * 3, dtype=np.float32).reshape(total, 3)
+            m = ro.shard_max_rows(total, world)
+            gathered = np.zeros((world * m, 3), np.float32)
+            for g, (first, rows) in enumerate(shards):
+                gathered[g * m:g * m + rows] = full[first:first + rows]
+            assert np.array_equal(ro.stitch_rows(gathered, total, world), full)
+    first, rows = ro.shard_rows(168747, 8, 3)
+    s0, ns = ro.shard_samples(first, rows, 32768, 24576)
+    assert s0 == first * 8192 and ns == (rows - 1) * 8192 + 32768
+    assert ro.shard_samples(5, 0, 4096, 2048) == (5 * 2048, 0)
+    with pytest.raises(ro.StftError):
+        ro.shard_rows(10, 4, 4)

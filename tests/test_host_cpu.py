@@ -371,3 +371,44 @@ def test_bolid_event_writes_band_snapshot_and_raw_iq(H, oracle, tmp_path):
     assert n_snap >= 1 and [l.split(";")[0] for l in lines] == snap_names
     assert all(l.split(";")[1:] == ["1", g(pf), "1.5", "0"] or l.split(";")[3] == "3" for l in lines)
     H.ro_host_manual_destroy(m)
+
+
+def test_bolid_replay_of_a_record_stream_matches_oracle_fsm(oracle):
+    """ro_host_bolid_replay (the product's BolidRecorder fed a stitched (n, p, a) stream, as after a multi-GPU
+    gather) fires the oracle FSM's events on a scripted detect / no-detect sequence with short gaps and re-triggers."""
+    from hostlib import BolidEvent, host_library
+    L = host_library()
+    if L is None:
+        pytest.skip("host library not built")
+    L.ro_host_bolid_replay.restype = C.c_int64
+    L.ro_host_bolid_replay.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       C.c_double, C.c_double, C.c_float, C.c_void_p, C.c_int64,
+                                       C.POINTER(BolidEvent), C.c_int]
+    bins, overlap, fs = 4096, 3072, 48000
+    rng = np.random.default_rng(5)
+    R = 6000
+    dt = np.dtype([("noise", np.float32), ("peak", np.int32), ("average", np.float32)])
+    recs = np.zeros(R, dt)
+    recs["noise"] = 1.0 + 0.01 * rng.standard_normal(R).astype(np.float32)
+    recs["peak"] = rng.integers(0, 50, R)
+    recs["average"] = 1.0
+    pos = 50
+    while pos < R - 400:                                       # bursts of 1..40 rows, some separated by < jitter rows
+        n = int(rng.integers(1, 40))
+        recs["average"][pos:pos + n] = 5.0
+        pos += n + int(rng.integers(1, 300))
+    b = oracle.bolid_bands(bins, fs, overlap, 10300, 10900, 9000, 9600, 0.5, 1.5, 400)
+    rate = oracle.lib().ro_oracle_fft_sample_rate(fs, bins, overlap)
+    buf = (BolidEvent * 512)()
+    n_ev = L.ro_host_bolid_replay(bins, overlap, fs, 10300.0, 10900.0, 9000.0, 9600.0, 0.5, 1.5, 400.0,
+                                  C.c_void_p(recs.ctypes.data), R, buf, 512)
+    cap = int(np.ceil(60 * rate)) * 8
+    f = oracle.BolidFsm(b.advance, b.jitter, rate, fs, 10300.0, 10900.0)
+    want = []
+    for i in range(R):
+        fq = oracle.lib().ro_oracle_bin_to_frequency(bins, fs, b.low_detect + int(recs["peak"][i]))
+        ev = f.update(recs["noise"][i], recs["average"][i], fq, (i + 1) % cap)
+        if ev.fired:
+            want.append((i, ev.snap_start, ev.snap_length, ev.peak_freq))
+    got = [(buf[i].row, buf[i].start, buf[i].length, buf[i].peakFreq) for i in range(n_ev)]
+    assert len(want) > 5 and got == want
