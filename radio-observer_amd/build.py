@@ -17,7 +17,7 @@ HEADERS = ["ro_kernels.h", "ro_fft_device.h", os.path.join("..", "..", "include"
 # constant operands must sit in VGPR pairs; that costs ~28 VGPRs and makes the 1024-thread
 # N=32768 kernel spill (see DESIGN.md "register budget").
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared",
-               "-Wall", "-Wno-unused-function"]
+               "-Wall", "-Wno-unused-function", "-Wno-inline-asm"]
 
 
 def _stale():

@@ -271,6 +271,81 @@ __device__ __forceinline__ void fdit32(v2f *x, v2f g16, v2f g8, v2f g4, v2f g2, 
     fdit_level<4>(x, g1, tok);
 }
 
+// fdit32 with a hook into its last level: that level's 16 butterflies (x[2U], x[2U+1]) run in the order
+// U = 0, 8, 1, 9, ... and done(j) is called after the pair (j, 8 + j): x[2j], x[2j+1], x[16+2j], x[17+2j] are final
+// then (bins bitrev32 of those positions) and their registers free for whatever the caller loads into them next.
+__device__ __forceinline__ void tie(v2f &x, float dep) { asm volatile("" : "+v"(x) : "v"(dep)); }
+
+// one last-level butterfly (a, b) <- (a + W32^E g1 b, a - W32^E g1 b), the product w = W32^(E & 7) g1 given
+template <int E> __device__ __forceinline__ void fdit_last_bfly(v2f &a, v2f &b, v2f w)
+{
+    const v2f s = (E >= 8) ? cmadd_mi(b, w, a) : cmadd(b, w, a);
+    b = __builtin_elementwise_fma(a, (v2f){2.0f, 2.0f}, -s);
+    a = s;
+}
+
+// Blocks J and 8 + J of the last level have exponents E = bitrev4(J) and E + 1, and J, J + 1 (J even) use the same two
+// products W32^(E & 7) g1 (E and E + 8 differ by -i, a modifier): the products are made two at a time, right where
+// they are first used -- 4 registers live instead of the 16 that all eight of them held through the level.
+// done(J) returns a float the next pair is chained behind (the scheduling leash of tie(); it cannot be one of the
+// x[] just finished: the caller has already started to reload those registers).
+template <int J, typename F>
+__device__ __forceinline__ void fdit_last_pair(v2f *x, v2f g1, v2f (&w)[2], float &chain, F &done)
+{
+    constexpr int E0 = bitrev_bits<4>(J), E1 = bitrev_bits<4>(8 + J);
+    static_assert(E1 == E0 + 1, "blocks J and 8 + J use neighbouring exponents");
+    if constexpr (J % 2 == 0) {
+        w[0] = mul_w32<E0 & 7>(g1);
+        w[1] = mul_w32<E1 & 7>(g1);
+    }
+    tie(x[2 * J], chain);
+    fdit_last_bfly<E0>(x[2 * J], x[2 * J + 1], w[0]);
+    tie(x[16 + 2 * J], x[2 * J + 1]);
+    fdit_last_bfly<E1>(x[16 + 2 * J], x[17 + 2 * J], w[1]);
+    chain = done(std::integral_constant<int, J>{});
+}
+
+template <typename F, int... Js>
+__device__ __forceinline__ void fdit_last_level(v2f *x, v2f g1, F &done, std::integer_sequence<int, Js...>)
+{
+    v2f w[2];
+    float chain = x[31].x;
+    (fdit_last_pair<Js>(x, g1, w, chain, done), ...);
+}
+
+// fdit32 in two parts: levels 0..3, then the last level with the hook (the caller may branch between them)
+__device__ __forceinline__ void fdit32_head(v2f *x, v2f g16, v2f g8, v2f g4, v2f g2)
+{
+    const v2f *tok = &x[31];
+    fdit_level<0>(x, g16, tok);
+    fdit_level<1>(x, g8, tok);
+    fdit_level<2>(x, g4, tok);
+    fdit_level<3>(x, g2, tok);
+}
+
+template <typename F> __device__ __forceinline__ void fdit32_last(v2f *x, v2f g1, F done)
+{
+    fdit_last_level(x, g1, done, std::make_integer_sequence<int, 8>{});
+}
+
+// dit<32> with hooks: hook(0) after the first level, hook(1..3) after the first three quarter sub-transforms --
+// four evenly spaced places for the caller to slip other work (row stores) between the butterflies
+template <typename F> __device__ __forceinline__ void dit32_hooked(v2f *v, F hook)
+{
+    const v2f *tok = &v[31];
+    dit_level<32, 0>(v, tok, std::make_integer_sequence<int, 16>{});
+    hook(std::integral_constant<int, 0>{});
+    dit_level<16, 0>(v, tok, std::make_integer_sequence<int, 8>{});
+    dit_rec<8, 0>(v, tok);
+    hook(std::integral_constant<int, 1>{});
+    dit_rec<8, 8>(v + 8, tok);
+    hook(std::integral_constant<int, 2>{});
+    dit_level<16, 8>(v + 16, tok, std::make_integer_sequence<int, 8>{});
+    dit_rec<8, 4>(v + 16, tok);
+    hook(std::integral_constant<int, 3>{});
+    dit_rec<8, 12>(v + 24, tok);
+}
+
 template <int R> __host__ __device__ constexpr int bitrev(int k)
 {
     int r = 0;

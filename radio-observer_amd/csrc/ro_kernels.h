@@ -30,6 +30,13 @@ struct StftArgs {
     int           stagger;     // start delay per workgroup slot, shader cycles (0 = none)
     int           prefetch;    // set by the launcher: touch the next row's new samples ahead of time
     int           spare_cus;   // CUs per XCD the persistent grid leaves to other kernels (ro_stft_config_t)
+    // fused per-row band scan (BolidRecorder::noise/peak/average on the row while it is still in LDS): plans that
+    // support it (stft_fuses_scan) fill records[row] themselves, the others leave it to launch_scan
+    ro_scan_record_t *records; // rows records, or nullptr
+    int           low_noise, noise_width, low_detect, detect_width, avg_bins;
+    // fused band tile: columns [tile_first, +tile_cols) of every row, compact (rows x tile_cols), or nullptr
+    float        *tile_out;
+    int           tile_first, tile_cols;
 };
 
 struct TileArgs {
@@ -84,6 +91,7 @@ int        big_radices(int bins, int radices[8]); // number of passes
 hipError_t launch_big_pass(int radix, bool first, bool last, int fmt, const BigArgs &a, hipStream_t s);
 
 bool       stft_supported(int bins);
+bool       stft_fuses_scan(int bins);             // the plan writes StftArgs::records / tile_out from its epilogue
 int        stft_twiddle_count(int bins);          // float2 entries, <0 if unsupported
 bool       stft_radices(int bins, int radices[4]);
 int        stft_packed_twiddle_count(int bins);   // float4 units of StftArgs::twiddles_k, <0 if unsupported

@@ -69,6 +69,28 @@
 #ifndef RO_USE_ADDTID
 #define RO_USE_ADDTID 1
 #endif
+// N = 32768 plan, software-pipelined row loop (1): the next row's sample / window loads are issued from inside the
+// LAST butterfly level of the current row, each into the registers whose magnitudes have just gone to the LDS image,
+// and the image leaves for HBM (LDS read-back + 16-byte stores) from inside the NEXT row's window stage and first
+// butterflies.  The memory pipe (about 9k cycles per row for 448 KiB at ~56 B/clk/CU) then runs beside the VALU
+// instead of in an epilogue of its own where all 16 waves sat in its queue.  0 = the round-1 epilogue.
+#ifndef RO_PIPE
+#define RO_PIPE 1
+#endif
+// fused band scan (BolidRecorder::noise/peak/average on the LDS image, two waves) and band tile in the PIPE epilogue
+// how many of the last level's eight butterfly pairs request next-row samples (two 16-byte loads each); the rest
+// of the samples is requested behind the barrier / the fused scan
+// 1: four of the eight image chunks leave from the window stage, four from the first butterflies; 0: all eight from
+// the first butterflies (the window stage is the register peak of the row: samples + all coefficients)
+#ifndef RO_PIPE_WSTORES
+#define RO_PIPE_WSTORES 0
+#endif
+#ifndef RO_PIPE_J
+#define RO_PIPE_J 6
+#endif
+#ifndef RO_FUSE_SCAN
+#define RO_FUSE_SCAN 1
+#endif
 // threads per workgroup of the N = 32768 plan: 1024 (32 points per thread) or 512 (64 points: every thread runs two
 // of the scheme's 1024 "logical threads"; same bits, 5 % slower -- 2 waves per SIMD -- and its 256 VGPRs still do not
 // hold window + twiddles resident, which was the point of trying it)
@@ -120,6 +142,11 @@ template <class PL> constexpr bool plan_addtid()
            PL::R0 == 32 && PL::R1 == 32 && PL::R2 == 32 && PL::R3 == 1 && PL::SPLIT;
 }
 template <class PL> constexpr bool plan_swap32() { return plan_addtid<PL>() && RO_SWAP32 && RO_PAIRED_LOADS; }
+// the pipelined row loop (RO_PIPE) with the fused scan: 1024-thread add-TID plan, magnitude mode
+template <class PL> constexpr bool plan_pipe() { return plan_addtid<PL>() && RO_PIPE && PL::T == 1024 && !RO_ABLATE; }
+// dynamic LDS of a plan: the exchange image; behind it, for the pipelined add-TID plan, 1 KiB of histogram for the
+// fused scan's radix select
+template <class PL> constexpr int plan_lds_bytes() { return PL::LDS_BYTES + (plan_pipe<PL>() ? 1024 : 0); }
 
 // Paired sample loads: which stage-0 column a thread transforms, and the first sample it fetches.
 // Lanes l, l^1 (default) or l, l+32 (swap32) fetch the SAME two adjacent columns with 16-byte loads, one lane
@@ -176,6 +203,13 @@ __device__ __forceinline__ void buf_store_f4(float x0, float x1, float x2, float
 {
     u32x4 t = {__float_as_uint(x0), __float_as_uint(x1), __float_as_uint(x2), __float_as_uint(x3)};
     __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, RO_STORE_AUX);
+    // A 16-byte store goes on reading its data registers after it has issued: a VALU write to them in the next two
+    // wait states changes what the last lanes store.  hipcc pads that hazard only for stores without an SGPR soffset
+    // (and counts the empty asm statements of the scheduling leash as wait states); with the soffset form used here
+    // and the registers recycled at once by the butterflies around the pipelined stores, one row in ten left with
+    // lanes 12..15 of every 16 carrying the NEXT values of those registers.  The asm keeps the four registers alive
+    // across two real wait states.
+    asm volatile("s_nop 1" ::"v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w));
 }
 
 // value of lane (quad_perm) of the same register, DPP: no LDS, full-rate VALU
@@ -411,7 +445,24 @@ __device__ __forceinline__ void addtid_write8(unsigned m0, float a0, float a1, f
                  :
                  : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7), "s"(m0), "n"(O0), "n"(O1),
                    "n"(O2), "n"(O3), "n"(O4), "n"(O5), "n"(O6), "n"(O7)
-                 : "memory");
+                 : "memory", "m0");      // M0 is hipcc's too (LDS-DMA): it must know the asm leaves another value there
+}
+
+// four add-TID writes with two M0 values: a0, a1 at offsets OA0, OA1 from M0 = ma, then b0, b1 at OB0, OB1 from mb
+template <int OA0, int OA1, int OB0, int OB1>
+__device__ __forceinline__ void addtid_write4(unsigned ma, unsigned mb, float a0, float a1, float b0, float b1)
+{
+    asm volatile("s_mov_b32 m0, %4\n\t"
+                 "s_nop 0\n\t"
+                 "ds_write_addtid_b32 %0 offset:%6\n\t"
+                 "ds_write_addtid_b32 %1 offset:%7\n\t"
+                 "s_mov_b32 m0, %5\n\t"
+                 "s_nop 0\n\t"
+                 "ds_write_addtid_b32 %2 offset:%8\n\t"
+                 "ds_write_addtid_b32 %3 offset:%9"
+                 :
+                 : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "s"(ma), "s"(mb), "n"(OA0), "n"(OA1), "n"(OB0), "n"(OB1)
+                 : "memory", "m0");
 }
 
 // scatter 32 floats per lane, slot q (value f(q), q a literal after inlining) to byte q*ROWB + 4*tid
@@ -487,6 +538,215 @@ __device__ __forceinline__ void exchange_addtid(void *smem, v2f (&v)[32 * NB], i
     sub(2);
     wg_sync();
     sub(3);
+}
+
+// ---------------------------------------------------------------------------
+// per-row band scan: BolidRecorder::noise / peak / average (src/BolidRecorder.cpp:313-347), one wavefront per row.
+// Shared by scan_kernel (rows in HBM) and the fused epilogue of the N = 32768 plan (row still in LDS).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned order_key(float x)
+{
+    unsigned u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_float(unsigned k)
+{
+    unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+// inclusive prefix sum over the 64 lanes with DPP moves (VALU only; a __shfl_up ladder is six dependent LDS round
+// trips): shifts by 1, 2, 4, 8 inside each row of 16 lanes, then the row totals are passed on with row_bcast
+__device__ __forceinline__ unsigned wave_inclusive_sum(unsigned x)
+{
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);     // row_shr:1, out-of-row lanes read 0
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);     // row_bcast:15 -> rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);     // row_bcast:31 -> rows 2 and 3
+    return (unsigned)v;
+}
+
+
+// row accessors: column c of the fft-shifted row
+struct GlobalRow {
+    const float *p;
+    __device__ __forceinline__ float operator()(int c) const { return p[c]; }
+};
+// the natural-order LDS image of the N = 32768 epilogue: bin k at element k, shifted column c is bin (c + N/2) mod N
+template <int N> struct ImageRow {
+    const float *img;
+    __device__ __forceinline__ float operator()(int c) const { return img[(c + N / 2) & (N - 1)]; }
+};
+
+constexpr int SCAN_E = 16;            // noise-band elements cached per lane by the CACHED form (band <= 1024)
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned x)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x = min(x, (unsigned)__shfl_xor((int)x, d));
+    return x;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned x)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x = max(x, (unsigned)__shfl_xor((int)x, d));
+    return x;
+}
+
+// noise(): element floor(W/4) of the ascending noise band, times two (src/BolidRecorder.cpp:313-317).
+// Order statistic by radix select on the order-preserving integer image of the floats, exact (the result is an
+// element of the band, bit for bit).  The bits on which ALL keys agree (wave min ^ max) are skipped -- a noise band
+// shares its sign and most of its exponent, and histogramming those bits first put every key on the same LDS word
+// (64-way ds_add_u32 collisions: 55 % of the old kernel's LDS cycles).  Below them, 8 bits per pass: every pass
+// histograms the digit of the keys that still match the prefix (256 bins in LDS, `h`), a wave scan over the bins
+// finds the bin holding rank k, k drops by the count below it; a bin holding ONE key ends the search early (that
+// key is looked up), which is the usual exit after two passes.
+// CACHED: keys live in registers (W <= 64 * SCAN_E); otherwise every pass re-reads the row (cheap from LDS).
+template <bool CACHED, class Row>
+__device__ __forceinline__ float scan_noise(Row row, int low_noise, int W, unsigned *h, int lane)
+{
+    if (W <= 0) return key_to_float(0xffffffffu) * 2.0f;        // the reference indexes an empty array (undefined)
+    unsigned keys[CACHED ? SCAN_E : 1];
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int e = 0; e < SCAN_E; ++e) {
+            const int i = lane + 64 * e;
+            // clamped index instead of a guarded load: no divergent branch, never outside the band
+            keys[e] = order_key(row(low_noise + (i < W ? i : W - 1)));
+        }
+    }
+    // f(key, valid) for every element slot of this lane (slots past the band: valid = false)
+    auto for_keys = [&](auto f) {
+        if constexpr (CACHED) {
+#pragma unroll
+            for (int e = 0; e < SCAN_E; ++e)
+                if (64 * e < W) f(keys[e], lane + 64 * e < W);
+        } else {
+            for (int i0 = 0; i0 < W; i0 += 64) {
+                const int i = i0 + lane;
+                f(order_key(row(low_noise + (i < W ? i : W - 1))), i < W);
+            }
+        }
+    };
+    unsigned kmin = 0xffffffffu, kmax = 0u;
+    for_keys([&](unsigned key, bool valid) {
+        kmin = min(kmin, valid ? key : 0xffffffffu);
+        kmax = max(kmax, valid ? key : 0u);
+    });
+    kmin = wave_min_u32(kmin);
+    kmax = wave_max_u32(kmax);
+    unsigned result = kmin;                              // all keys equal: that value
+    if (kmin != kmax) {
+        int top = 31 - __clz((int)(kmin ^ kmax));        // highest bit on which two keys differ (wave-uniform)
+        unsigned prefix = kmin;                          // bits above `top` are common to every key
+        int k = W / 4;
+        for (;;) {
+            const int shift = top >= 7 ? top - 7 : 0;
+            const unsigned mask = (2u << (top - shift)) - 1u;
+            {
+                // (a zero hipcc cannot hoist: as a loop invariant of the fused epilogue it went to scratch)
+                unsigned z = 0u;
+                asm volatile("" : "+v"(z));
+                reinterpret_cast<uint4 *>(h)[lane] = make_uint4(z, z, z, z);
+            }
+            for_keys([&](unsigned key, bool valid) {
+                // keys whose higher bits equal the prefix (shifting by 32 is not defined: top == 31 matches all);
+                // the others add 0 -- no divergent branch around the atomic
+                const bool match = top == 31 || ((key ^ prefix) >> (top + 1)) == 0u;
+                atomicAdd(&h[(key >> shift) & mask], (valid && match) ? 1u : 0u);
+            });
+            const uint4 b = reinterpret_cast<const uint4 *>(h)[lane];          // bins 4 lane .. 4 lane + 3
+            const unsigned s = b.x + b.y + b.z + b.w;
+            const unsigned inc = wave_inclusive_sum(s);
+            const unsigned exc = inc - s;
+            const bool mine = exc <= (unsigned)k && (unsigned)k < inc;         // exactly one lane: total > k
+            unsigned below = exc, bin = 0, count = b.x;
+            if ((unsigned)k >= below + b.x) {
+                below += b.x; bin = 1; count = b.y;
+                if ((unsigned)k >= below + b.y) {
+                    below += b.y; bin = 2; count = b.z;
+                    if ((unsigned)k >= below + b.z) { below += b.z; bin = 3; count = b.w; }
+                }
+            }
+            const int owner = __ffsll((long long)__ballot(mine)) - 1;                  // wave-uniform
+            const unsigned digit = (unsigned)__builtin_amdgcn_readlane((int)(4 * lane + bin), owner);
+            const unsigned in_bin = (unsigned)__builtin_amdgcn_readlane((int)count, owner);
+            k -= __builtin_amdgcn_readlane((int)below, owner);
+            prefix = (prefix & ~(mask << shift)) | (digit << shift);
+            if (shift == 0) { result = prefix; break; }
+            if (in_bin == 1u) {
+                // one key carries this prefix: it is the answer, whatever its lower bits are
+                unsigned found = 0u;
+                for_keys([&](unsigned key, bool valid) {
+                    if (valid && ((key ^ prefix) >> shift) == 0u) found = key;
+                });
+                result = wave_max_u32(found);            // every other lane holds 0
+                break;
+            }
+            top = shift - 1;
+        }
+    }
+    return (float)((double)key_to_float(result) * 2.0);
+}
+
+// peak(): last index of the maximum of the detect band (src/BolidRecorder.cpp:323-335: `>=`, so ties go to the
+// highest index).  Per-lane arg-max-last in index order, then a cross-lane reduction with "larger index wins".
+template <bool CACHED, class Row>
+__device__ __forceinline__ int scan_peak(Row row, int low_detect, int DW, int lane)
+{
+    float best = 0.f;
+    int best_i = -1;
+    if (CACHED && DW <= 64 * SCAN_E) {
+        // all loads first (one miss latency, not one per 64 columns)
+        float xs[SCAN_E];
+#pragma unroll
+        for (int e = 0; e < SCAN_E; ++e) {
+            const int i = lane + 64 * e;
+            xs[e] = row(low_detect + (i < DW ? i : (DW > 0 ? DW - 1 : 0)));
+        }
+#pragma unroll
+        for (int e = 0; e < SCAN_E; ++e) {
+            const int i = lane + 64 * e;
+            if (i < DW && (best_i < 0 || xs[e] >= best)) { best = xs[e]; best_i = i; }
+        }
+    } else {
+        for (int i = lane; i < DW; i += 64) {
+            const float x = row(low_detect + i);
+            if (best_i < 0 || x >= best) { best = x; best_i = i; }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ob = __shfl_xor(best, off);
+        const int oi = __shfl_xor(best_i, off);
+        const bool take = (oi >= 0) && (best_i < 0 || ob > best || (ob == best && oi > best_i));
+        if (take) { best = ob; best_i = oi; }
+    }
+    return best_i < 0 ? 0 : best_i;
+}
+
+// average(): sequential double sum in index order, like the reference (src/BolidRecorder.cpp:338-347; window start
+// :126-132).  64 columns are fetched at a time (one load per lane), then every lane adds them up in the same order
+// from the other lanes' registers.  The reference reads outside the row when the window leaves it (UB); columns
+// outside [0, bins) contribute nothing here.
+template <class Row>
+__device__ __forceinline__ float scan_average(Row row, int start, int avg_bins, int bins, int lane)
+{
+    double acc = 0.0;
+    for (int base = 0; base < avg_bins; base += 64) {
+        const int c = start + base + lane;
+        const float x = (base + lane < avg_bins && c >= 0 && c < bins) ? row(c) : 0.f;
+        const int n = avg_bins - base < 64 ? avg_bins - base : 64;
+        for (int i = 0; i < n; ++i) {
+            const int ci = start + base + i;
+            const float xi = __shfl(x, i);
+            if (ci >= 0 && ci < bins) acc += (double)xi;
+        }
+    }
+    return (float)(acc / (double)avg_bins);
 }
 
 // ---------------------------------------------------------------------------
@@ -667,7 +927,8 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
     // (their registers are free for the whole transform, so these loads cost nothing); the
     // rest follows in the epilogue.  (Keeping all of them resident instead -- they are the same for every row --
     // makes hipcc spill 31 registers; prefetching 100 % fits but leaves no VGPR to spare and gains 1 %.)
-    constexpr int NW_EARLY = ((NW * RO_WIN_EARLY_PCT) / 100) & ~1;
+    // (the int16 form of the pipelined plan converts while it windows and has fewer registers to spare: a quarter)
+    constexpr int NW_EARLY = ((NW * (plan_pipe<PL>() && FMT == RO_FMT_I16 ? 25 : RO_WIN_EARLY_PCT)) / 100) & ~1;
     using c0 = std::integral_constant<int, 0>;
     using cE = std::integral_constant<int, NW_EARLY>;
     using cN = std::integral_constant<int, NW>;
@@ -686,7 +947,26 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         if constexpr (PL::R3 > 1) tw_prefetch<P, T, PL::R3, PL::NS3, PL::TW3, PL::PK3>(tw3, rs_tw, rs_twk, tid);
     }
 
+    // PIPE: the image of the row before this one (LDS, natural order) and where it goes; 0 bytes = nothing to store
+    constexpr bool PIPE = plan_pipe<PL>() && MODE == 0;
+    constexpr bool FUSE = PIPE && RO_FUSE_SCAN;
+    constexpr int PIPE_J = RO_PIPE_J;      // butterfly pairs of the last level that request next-row samples (of 8)
+    const float *prev_out = a.rows_out;
+    unsigned prev_bytes = 0;
+    unsigned touch = 0;                    // destination of the next-row prefetch touches (touch_next)
+    // chunk q of the image: 16 bytes per lane from LDS, out as 1 KiB per wave-instruction; column k leaves for
+    // (k + N/2) mod N (src/WaterfallBackend.cpp:492-505)
+    auto store_chunk = [&](int q, const __amdgpu_buffer_rsrc_t &rs) {
+        // (chunks 4..7 lie past the 64 KiB an LDS offset field reaches: without the empty asm hipcc keeps four more
+        // loop-invariant address registers alive through the whole row instead of one add per chunk)
+        int lt = tid;
+        asm volatile("" : "+v"(lt));
+        const float4 x = reinterpret_cast<const float4 *>(smem)[lt + T * q];
+        buf_store_f4(x.x, x.y, x.z, x.w, rs, tid * 16, ((q * T * 4 + N / 2) & (N - 1)) * 4);
+    };
+
     for (;;) {
+        const __amdgpu_buffer_rsrc_t rs_prev = make_rsrc(prev_out, prev_bytes);
         // ---- stage 0: window.  Coefficients arrive in chunks of WIN_CHUNK, two chunks in
         // flight, so the stage peaks at 2P + 2*WIN_CHUNK VGPRs (+P while a row waits to be stored).
         // ---- stage 0: window (coefficients and samples were requested a whole epilogue ago)
@@ -721,6 +1001,8 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
                         const auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(e.y), __float_as_uint(o.y), false, false);
                         lo = (v2f){__uint_as_float(rx[0]), __uint_as_float(ry[0])};
                         hi = (v2f){__uint_as_float(rx[1]), __uint_as_float(ry[1])};
+                        // PIPE: chunks 0..3 of the previous row's image leave from here (the rest from stage 0)
+                        if constexpr (PIPE && RO_PIPE_WSTORES) { if ((k & 3) == 3) store_chunk(k >> 2, rs_prev); }
                         continue;
                     }
                     // even lane keeps e in slot k and takes the partner's e (leg H+k) into slot H+k;
@@ -739,24 +1021,40 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         // The coefficients for the NEXT row are requested right away: their registers are free
         // from here on and the loads overlap the whole transform instead of the epilogue's
         // memory burst.  (Unconditional: the same table every row.)
+        if constexpr (ADDTID) asm volatile("" ::"v"(touch));     // see touch_next
         if constexpr (!RESW) load_window(make_rsrc(win_tab, N * 4), c0{}, cE{});
         const int64_t next = row + stride;
         const bool has_next = next < xcd_end;
-        unsigned touched0 = 0, touched1 = 0;
         auto touch_next = [&]() {
-            // samples [next*hop + N - hop, next*hop + N) = hop * BYTES bytes: one dword per 128-byte line, two per
-            // thread (reaches hop = N; whatever lies past the descriptor's end costs nothing)
+            if constexpr (!ADDTID) return;          // only the add-TID plan is launched with a.prefetch
+            // samples [next*hop + N - hop, next*hop + N) = hop * BYTES bytes: one dword per 128-byte line and thread
+            // (reaches 128 KiB: hop <= N/2 for float samples; whatever lies past the descriptor's end costs nothing).
+            // The dword is not wanted, only its line in L2.  It is a load hipcc can see, into a register that is
+            // "used" only after the next window stage (younger loads have been waited for by then, so that use never
+            // waits): two attempts to do without the register failed -- LDS-DMA into a scrap line (M0 reaches only
+            // the first 64 KiB of LDS: the DMA landed on byte 0xFFFC of the magnitude image) and loads issued from
+            // inline asm (hipcc copied the "finished" value elsewhere and reused the register while the data was
+            // still on its way: stray samples in lanes of whatever lived there next).
             const int64_t s0 = (a.first_row + (has_next ? next : row)) * (int64_t)a.hop + (N - a.hop);
             // switched off (a.prefetch == 0, last row) by a zero-sized descriptor, not by a branch
             const __amdgpu_buffer_rsrc_t rs_new =
                 make_rsrc(iq + s0 * S::BYTES, (has_next && a.prefetch) ? a.hop * S::BYTES : 0);
-            touched0 = __builtin_amdgcn_raw_buffer_load_b32(rs_new, tid * 128, 0, 0);
-            touched1 = __builtin_amdgcn_raw_buffer_load_b32(rs_new, tid * 128, T * 128, 0);
+            touch = __builtin_amdgcn_raw_buffer_load_b32(rs_new, tid * 128, 0, 0);
         };
         if constexpr (RO_PREFETCH_NEXT == 1) touch_next();
         stamp(0);                                   // window multiply (+ wait for samples)
 
-        butterflies<P, R0>(v);
+        if constexpr (PIPE) {
+            dit32_hooked(v, [&](auto hc) {
+                constexpr int h = decltype(hc)::value;
+                if constexpr (RO_PIPE_WSTORES) store_chunk(4 + h, rs_prev);
+                else { store_chunk(2 * h, rs_prev); store_chunk(2 * h + 1, rs_prev); }
+            });
+            // every wave has read its part of the image back: LDS belongs to the exchanges again
+            wg_sync();
+        } else {
+            butterflies<P, R0>(v);
+        }
         if constexpr (PL::R1 > 1 && !RES) tw_prefetch<P, T, PL::R1, PL::NS1, PL::TW1, PL::PK1>(tw1, rs_tw, rs_twk, tid);
         stamp(2);                                   // butterflies 0
 
@@ -765,8 +1063,10 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             if constexpr (ADDTID) exchange_addtid<1, SWAP32, P / 32, T>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             else exchange<PL, PL::R0, 1, PL::R1>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             stamp(3);                               // exchange 1
-            if constexpr (RO_PREFETCH_NEXT == 2) touch_next();
             tw_butterflies<P, PL::R1>(v, tw1);
+            // behind the butterflies: in front of them hipcc's wait for this pass's twiddles (which it believes to be
+            // the youngest loads in flight) would sit through the touches' HBM misses as well
+            if constexpr (RO_PREFETCH_NEXT == 2) touch_next();
             stamp(4);                               // twiddles + butterflies 1
         }
         // ---- stage 2
@@ -776,7 +1076,103 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             else exchange<PL, PL::R1, PL::NS1, PL::R2>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             stamp(5);                               // exchange 2
             if constexpr (RO_PREFETCH_NEXT == 3) touch_next();
-            tw_butterflies<P, PL::R2>(v, tw2);
+            if constexpr (PIPE) {
+                // Last pass with the epilogue folded into its last level.  After butterflies (j, 8 + j) of that level
+                // x[2j], x[2j+1], x[16+2j], x[17+2j] are final = bins (tid + 1024 q) for q = qj, qj+16, qj+1, qj+17
+                // (qj = bitrev32(2j)): their magnitudes go to the natural-order LDS image (byte 4096 q + 4 tid,
+                // add-TID), and the four freed registers receive legs 2j, 2j+1 of the NEXT row's samples -- for
+                // j < PIPE_J; the last legs are requested behind the scan (they are also the last ones the window
+                // stage asks for), whose two waves would not fit the 128 VGPRs with all 64 of them in flight.
+                const __amdgpu_buffer_rsrc_t rs_next =
+                    make_rsrc(iq + (a.first_row + (has_next ? next : row)) * (int64_t)a.hop * S::BYTES,
+                              has_next ? N * S::BYTES : 0);     // zero-sized after the last row: the loads are no-ops
+                const unsigned wave_bytes = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6) * 256u;
+                constexpr int HB = 61444;                        // see addtid_scatter32<4096>: M0 for slots 16..31
+                const int po = pair_off(0) * S::BYTES;
+                // The image writes of pair j are issued one pair late (from done(j + 1), the last ones behind the level):
+                // v_sqrt_f32 runs in the transcendental pipe, and a ds_write_addtid_b32 that follows it within a few
+                // instructions reads its data register before the last lanes of the result have been written -- the
+                // hardware does not interlock the two and hipcc inserts no wait states in front of inline asm (seen:
+                // lanes 51, 55, 59, 63 of one row in ten carried the register's previous contents).
+                float pm0 = 0.f, pm1 = 0.f, pm16 = 0.f, pm17 = 0.f;
+                auto write_pair = [&](auto jc) {
+                    constexpr int q = bitrev<32>(2 * decltype(jc)::value);
+                    static_assert(q % 2 == 0 && q < 16, "slot algebra");
+                    addtid_write4<4096 * q, 4096 * (q + 1), 4096 * (q + 16) - HB, 4096 * (q + 17) - HB>(
+                        wave_bytes, wave_bytes + HB, pm0, pm1, pm16, pm17);
+                };
+                auto done = [&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    static_assert(bitrev<32>(2 * j + 1) == bitrev<32>(2 * j) + 16 && bitrev<32>(16 + 2 * j) == bitrev<32>(2 * j) + 1 &&
+                                  bitrev<32>(17 + 2 * j) == bitrev<32>(2 * j) + 17, "slot algebra");
+                    auto mag = [](v2f x) { const v2f sq = x * x; return __builtin_amdgcn_sqrtf(sq.x + sq.y); };
+                    const float m0 = mag(v[2 * j]), m16 = mag(v[2 * j + 1]);
+                    const float m1 = mag(v[16 + 2 * j]), m17 = mag(v[17 + 2 * j]);
+                    if constexpr (j > 0) write_pair(std::integral_constant<int, j - 1>{});
+                    pm0 = m0; pm1 = m1; pm16 = m16; pm17 = m17;
+                    if constexpr (j < PIPE_J) {
+                        // the loads may not start before these magnitudes exist (fake dependence; no instruction)
+                        const int pj = after(po, m17);
+                        S::load_pair(rs_next, pj, (2 * j) * (N / R0) * S::BYTES, v[2 * j], v[H + 2 * j]);
+                        S::load_pair(rs_next, pj, (2 * j + 1) * (N / R0) * S::BYTES, v[2 * j + 1], v[H + 2 * j + 1]);
+                    }
+                    return m17;                                  // the next pair of butterflies is chained behind this
+                };
+                static_assert(P == 32 && NB == 1, "one radix-32 butterfly per thread");
+                fdit32_head(v, tw2[0][4], tw2[0][3], tw2[0][2], tw2[0][1]);
+                fdit32_last(v, tw2[0][0], done);
+                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // the last square roots: see above
+                write_pair(std::integral_constant<int, 7>{});
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the add-TID image writes (hipcc does not count them)
+                wg_sync();                                            // the image of this row is complete
+                stamp(11);
+                if constexpr (FUSE) {
+                    // BolidRecorder's per-row scan on the image (src/BolidRecorder.cpp:121-132, :313-347), two waves on
+                    // different SIMDs (waves are dealt to SIMDs cyclically) while the others go on to the next row's
+                    // window stage; the image stays until the barrier in front of the next exchange.  Two more waves
+                    // cut the band tile.
+                    // Everything derived from the lane number and the band limits is laundered through empty asm:
+                    // otherwise hipcc hoists those loop invariants in front of the row loop, where they sit in VGPRs
+                    // of all 16 waves for the whole row.
+                    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+                    int lane = tid & 63;
+                    asm volatile("" : "+v"(lane));
+                    const ImageRow<N> img{reinterpret_cast<const float *>(smem)};
+                    if (a.records != nullptr && (wave == 3 || wave == 6)) {
+                        int low_noise = a.low_noise, noise_width = a.noise_width, low_detect = a.low_detect;
+                        int detect_width = a.detect_width, avg_bins = a.avg_bins;
+                        asm volatile("" : "+s"(low_noise), "+s"(noise_width), "+s"(low_detect), "+s"(detect_width),
+                                     "+s"(avg_bins));
+                        if (wave == 3) {
+                            unsigned *hist = reinterpret_cast<unsigned *>(smem + PL::LDS_BYTES);
+                            const float nz = scan_noise<false>(img, low_noise, noise_width, hist, lane);
+                            if (lane == 0) a.records[row].noise = nz;
+                        } else {
+                            const int pk = scan_peak<false>(img, low_detect, detect_width, lane);
+                            const float av = scan_average(img, low_detect + pk - avg_bins / 2, avg_bins, N, lane);
+                            if (lane == 0) {
+                                a.records[row].peak = pk;
+                                a.records[row].average = av;
+                            }
+                        }
+                    }
+                    if (a.tile_out != nullptr && (wave == 9 || wave == 12)) {
+                        int tile_cols = a.tile_cols, tile_first = a.tile_first;
+                        asm volatile("" : "+s"(tile_cols), "+s"(tile_first));
+                        const int half = ((tile_cols + 127) >> 7) << 6;            // first wave's share, whole 64s
+                        const int c0 = wave == 9 ? 0 : half;
+                        const int c1 = wave == 9 ? (half < tile_cols ? half : tile_cols) : tile_cols;
+                        float *dst = a.tile_out + row * (int64_t)tile_cols;
+                        for (int c = c0 + lane; c < c1; c += 64) dst[c] = img(tile_first + c);
+                    }
+                }
+                // the legs the last level did not request
+#pragma unroll
+                for (int k = 2 * PIPE_J; k < H; ++k)
+                    S::load_pair(rs_next, po, k * (N / R0) * S::BYTES, v[k], v[H + k]);
+            } else {
+                tw_butterflies<P, PL::R2>(v, tw2);
+            }
             stamp(6);                               // twiddles + butterflies 2
         }
         // ---- stage 3
@@ -794,7 +1190,6 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         // requested into the freed registers, and only then the row is read back 16 bytes per
         // lane and stored -- 1 KiB per wave-instruction, the stores being the LAST thing in the
         // VMEM queue.
-        if constexpr (RO_PREFETCH_NEXT) asm volatile("" ::"v"(touched0), "v"(touched1));   // keeps the touches alive
         if constexpr (MODE == 1) {
             // slot r of butterfly b is bin (tid + T b) + r N/RL: 8 bytes per lane, 512 contiguous bytes per wave
             const __amdgpu_buffer_rsrc_t rs_spec =
@@ -811,6 +1206,19 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             load_row(make_rsrc(iq + (a.first_row + (has_next ? next : row)) * (int64_t)a.hop * S::BYTES,
                                has_next ? N * S::BYTES : 0));
             if constexpr (!RESW) load_window(make_rsrc(win_tab, has_next ? N * 4 : 0), cE{}, cN{});
+            st_acc[9] += 1;
+            if (!has_next) break;
+            row = next;
+            continue;
+        }
+        if constexpr (PIPE) {
+            stamp(8);
+            // The rest of the next row's window coefficients: behind the scan, whose two waves need the registers
+            // (inside the last butterfly level they do not fit the 128 VGPRs either); they have half a window stage
+            // to land.  Zero-sized descriptor after the last row.
+            if constexpr (!RESW) load_window(make_rsrc(win_tab, has_next ? N * 4 : 0), cE{}, cN{});
+            prev_out = a.rows_out + row * a.row_stride;
+            prev_bytes = N * 4;
             st_acc[9] += 1;
             if (!has_next) break;
             row = next;
@@ -879,6 +1287,15 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         st_acc[9] += 1;
         if (!has_next) break;
         row = next;
+    }
+    if constexpr (PIPE) {
+        // the last row's image (complete: the loop ends behind its barrier); nothing overwrites LDS any more
+        const __amdgpu_buffer_rsrc_t rs_last = make_rsrc(prev_out, prev_bytes);
+#pragma unroll
+        for (int q = 0; q < P / 4; ++q) {
+            store_chunk(q, rs_last);
+            if (q & 1) asm volatile("" ::: "memory");
+        }
     }
     if constexpr (RO_STAMPS) {
         if (a.stamps && tid == 0)
@@ -967,17 +1384,6 @@ __global__ __launch_bounds__(256) void tile_kernel(TileArgs a)
 // ---------------------------------------------------------------------------
 // per-row band scan (one wavefront per row)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ unsigned order_key(float x)
-{
-    unsigned u = __float_as_uint(x);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float key_to_float(unsigned k)
-{
-    unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-    return __uint_as_float(u);
-}
-
 // ---------------------------------------------------------------------------
 // ln tile: the viewer's FN_LOG (fits2png:46: numpy.log of the non-zero float32 pixels) over the band
 // columns, its min / max (fits2png:476-477), and the grey level (v - min) / (max - min) * 255 cut to
@@ -1040,21 +1446,6 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(LnArgs a)
     }
 }
 
-// inclusive prefix sum over the 64 lanes with DPP moves (VALU only; a __shfl_up ladder is six dependent LDS round
-// trips): shifts by 1, 2, 4, 8 inside each row of 16 lanes, then the row totals are passed on with row_bcast
-__device__ __forceinline__ unsigned wave_inclusive_sum(unsigned x)
-{
-    int v = (int)x;
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);     // row_shr:1, out-of-row lanes read 0
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);     // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);     // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);     // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);     // row_bcast:15 -> rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);     // row_bcast:31 -> rows 2 and 3
-    return (unsigned)v;
-}
-
-constexpr int SCAN_E = 16;            // noise-band elements cached per lane (band <= 1024)
 constexpr int SCAN_WAVES = 4;         // rows per workgroup
 
 __global__ __launch_bounds__(64 * SCAN_WAVES) void scan_kernel(ScanArgs a)
@@ -1062,128 +1453,19 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void scan_kernel(ScanArgs a)
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * SCAN_WAVES + (threadIdx.x >> 6);
     if (row >= a.rows) return;
-    const float *__restrict__ src = a.rows_in + row * a.row_stride;
-
-    // ---- noise(): element floor(W/4) of the ascending noise band, times two.
-    // Order statistic by a 4-pass radix select (8 bits per pass, most significant first) on the order-preserving
-    // integer image of the floats: every pass histograms the digit of the keys that still match the prefix found so
-    // far (256 bins per wave in LDS, ds_add_u32), a wave scan over the bins finds the bin holding rank k, and k is
-    // reduced by the count below it.  Exact: the result is an element of the band, bit for bit.
-    const float *nb = src + a.low_noise;
-    const int W = a.noise_width;
+    const GlobalRow src{a.rows_in + row * a.row_stride};
     __shared__ __attribute__((aligned(16))) unsigned hist[SCAN_WAVES][256];
     unsigned *h = hist[threadIdx.x >> 6];
-    unsigned keys[SCAN_E];
-    const bool cached = W <= 64 * SCAN_E;
-    if (cached) {
-#pragma unroll
-        for (int e = 0; e < SCAN_E; ++e) {
-            const int i = lane + 64 * e;
-            // clamped index instead of a guarded load: no divergent branch, never outside the band
-            const unsigned key = order_key(nb[i < W ? i : (W > 0 ? W - 1 : 0)]);
-            keys[e] = i < W ? key : 0xffffffffu;
-        }
-    }
-    unsigned result = 0xffffffffu;                 // W == 0: the reference indexes an empty array (undefined)
-    if (W > 0) {
-        unsigned prefix = 0;
-        int k = W / 4;
-        for (int pass = 0; pass < 4; ++pass) {
-            const int shift = 24 - 8 * pass;
-            reinterpret_cast<uint4 *>(h)[lane] = make_uint4(0u, 0u, 0u, 0u);
-            auto count = [&](unsigned key, bool valid) {
-                // keys whose higher digits equal the prefix (all of them in pass 0: shifting by 32 is not defined);
-                // the others add 0 -- no divergent branch around the atomic
-                const bool match = pass == 0 || (key >> (shift + 8)) == prefix;
-                atomicAdd(&h[(key >> shift) & 255u], (valid && match) ? 1u : 0u);
-            };
-            if (cached) {
-#pragma unroll
-                for (int e = 0; e < SCAN_E; ++e)
-                    if (64 * e < W) count(keys[e], lane + 64 * e < W);
-            } else {
-                for (int i0 = 0; i0 < W; i0 += 64) {
-                    const int i = i0 + lane;
-                    count(i < W ? order_key(nb[i]) : 0u, i < W);
-                }
-            }
-            const uint4 b = reinterpret_cast<const uint4 *>(h)[lane];          // bins 4 lane .. 4 lane + 3
-            const unsigned s = b.x + b.y + b.z + b.w;
-            const unsigned inc = wave_inclusive_sum(s);
-            const unsigned exc = inc - s;
-            const bool mine = exc <= (unsigned)k && (unsigned)k < inc;         // exactly one lane: total > k
-            unsigned below = exc, bin = 0;
-            if ((unsigned)k >= below + b.x) {
-                below += b.x; bin = 1;
-                if ((unsigned)k >= below + b.y) {
-                    below += b.y; bin = 2;
-                    if ((unsigned)k >= below + b.z) { below += b.z; bin = 3; }
-                }
-            }
-            const int owner = __ffsll((long long)__ballot(mine)) - 1;                  // wave-uniform
-            const unsigned digit = (unsigned)__builtin_amdgcn_readlane((int)(4 * lane + bin), owner);
-            k -= __builtin_amdgcn_readlane((int)below, owner);
-            prefix = (prefix << 8) | digit;
-        }
-        result = prefix;
-    }
-    const float q = key_to_float(result);
-    const float noise = (float)((double)q * 2.0);
-
-    // ---- peak(): last index of the maximum of the detect band.  All loads first (one miss latency, not one per
-    // 64 columns), then the per-lane arg-max-last in index order and the cross-lane reduction.
-    const float *db = src + a.low_detect;
-    const int DW = a.detect_width;
-    float best = 0.f;
-    int best_i = -1;
-    if (DW <= 64 * SCAN_E) {
-        float xs[SCAN_E];
-#pragma unroll
-        for (int e = 0; e < SCAN_E; ++e) {
-            const int i = lane + 64 * e;
-            xs[e] = db[i < DW ? i : (DW > 0 ? DW - 1 : 0)];
-        }
-#pragma unroll
-        for (int e = 0; e < SCAN_E; ++e) {
-            const int i = lane + 64 * e;
-            if (i < DW && (best_i < 0 || xs[e] >= best)) { best = xs[e]; best_i = i; }
-        }
-    } else {
-        for (int i = lane; i < DW; i += 64) {
-            const float x = db[i];
-            if (best_i < 0 || x >= best) { best = x; best_i = i; }
-        }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const float ob = __shfl_xor(best, off);
-        const int oi = __shfl_xor(best_i, off);
-        const bool take = (oi >= 0) && (best_i < 0 || ob > best || (ob == best && oi > best_i));
-        if (take) { best = ob; best_i = oi; }
-    }
-    const int peak = best_i < 0 ? 0 : best_i;
-
-    // ---- average(): sequential double sum in index order, like the reference.  64 columns are fetched at a time
-    // (one load per lane), then every lane adds them up in the same order from the other lanes' registers.
-    const int start = a.low_detect + peak - a.avg_bins / 2;
-    double acc = 0.0;
-    for (int base = 0; base < a.avg_bins; base += 64) {
-        const int c = start + base + lane;
-        // the reference reads outside the row here when the window leaves it (UB);
-        // columns outside [0, bins) contribute nothing in this implementation.
-        const float x = (base + lane < a.avg_bins && c >= 0 && c < a.bins) ? src[c] : 0.f;
-        const int n = a.avg_bins - base < 64 ? a.avg_bins - base : 64;
-        for (int i = 0; i < n; ++i) {
-            const int ci = start + base + i;
-            const float xi = __shfl(x, i);
-            if (ci >= 0 && ci < a.bins) acc += (double)xi;
-        }
-    }
+    const bool cached = a.noise_width <= 64 * SCAN_E;
+    const float noise = cached ? scan_noise<true>(src, a.low_noise, a.noise_width, h, lane)
+                               : scan_noise<false>(src, a.low_noise, a.noise_width, h, lane);
+    const int peak = scan_peak<true>(src, a.low_detect, a.detect_width, lane);
+    const float avg = scan_average(src, a.low_detect + peak - a.avg_bins / 2, a.avg_bins, a.bins, lane);
     if (lane == 0) {
         ro_scan_record_t rec;
         rec.noise = noise;
         rec.peak = peak;
-        rec.average = (float)(acc / (double)a.avg_bins);
+        rec.average = avg;
         a.records[row] = rec;
     }
 }
@@ -1199,12 +1481,12 @@ template <class PL, int FMT, int MODE> static hipError_t launch_plan(const StftA
     static int per_cu_static = 1;       // ... per CU
     if (resident == 0) {
         const void *fn = reinterpret_cast<const void *>(&stft_kernel<PL, FMT, MODE>);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PL::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, plan_lds_bytes<PL>());
         if (e != hipSuccess) return e;
         int dev = 0, cus = 0, per_cu = 0;
         if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, PL::T, PL::LDS_BYTES)) != hipSuccess)
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, PL::T, plan_lds_bytes<PL>())) != hipSuccess)
             return e;
         if (per_cu < 1) per_cu = 1;
         per_cu_static = per_cu;
@@ -1245,7 +1527,7 @@ template <class PL, int FMT, int MODE> static hipError_t launch_plan(const StftA
         }
         b.stagger = stagger;
     }
-    hipLaunchKernelGGL((stft_kernel<PL, FMT, MODE>), dim3(grid), dim3(PL::T), PL::LDS_BYTES, s, b);
+    hipLaunchKernelGGL((stft_kernel<PL, FMT, MODE>), dim3(grid), dim3(PL::T), plan_lds_bytes<PL>(), s, b);
     return hipGetLastError();
 }
 
@@ -1265,6 +1547,11 @@ template <class PL> static hipError_t launch_fmt(const StftArgs &a, int fmt, hip
     if (fmt == RO_FMT_F32) return spec ? launch_plan<PL, RO_FMT_F32, 1>(a, s) : launch_plan<PL, RO_FMT_F32, 0>(a, s);
     if (fmt == RO_FMT_I16) return spec ? launch_plan<PL, RO_FMT_I16, 1>(a, s) : launch_plan<PL, RO_FMT_I16, 0>(a, s);
     return hipErrorInvalidValue;
+}
+
+bool stft_fuses_scan(int bins)
+{
+    return bins == 32768 && plan_pipe<Plan32768>() && RO_FUSE_SCAN;
 }
 
 bool stft_supported(int bins)

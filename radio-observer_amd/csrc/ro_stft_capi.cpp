@@ -194,7 +194,8 @@ int validate_resident(const ro_stft *h, const void *d_iq, int format, int64_t sa
 }
 
 ro::StftArgs make_stft_args(const ro_stft *h, const void *d_iq, int64_t first_row, int64_t rows,
-                            float *d_rows, int64_t row_stride)
+                            float *d_rows, int64_t row_stride, float *d_tile = nullptr,
+                            ro_scan_record_t *d_records = nullptr)
 {
     ro::StftArgs a{};
     a.iq = d_iq;
@@ -210,6 +211,18 @@ ro::StftArgs make_stft_args(const ro_stft *h, const void *d_iq, int64_t first_ro
     a.gain = (float)h->cfg.iq_gain;
     a.stamps = h->d_stamps;
     a.spare_cus = h->cfg.spare_cus_per_xcd;
+    // plans with a fused epilogue scan / tile take them here; for the others the caller launches the separate kernels
+    if (ro::stft_fuses_scan(h->bins)) {
+        a.records = d_records;
+        a.low_noise = h->cfg.bands.low_noise;
+        a.noise_width = h->cfg.bands.noise_width;
+        a.low_detect = h->cfg.bands.low_detect;
+        a.detect_width = h->cfg.bands.detect_width;
+        a.avg_bins = h->cfg.bands.avg_bins;
+        a.tile_out = d_tile;
+        a.tile_first = h->cfg.tile_first_col;
+        a.tile_cols = h->cfg.tile_cols;
+    }
     return a;
 }
 
@@ -245,11 +258,25 @@ ro::ScanArgs make_scan_args(const ro_stft *h, const float *d_rows, int64_t row_s
 
 // window -> FFT -> |X| for rows [first_row, +rows): the single-pass kernel, or for bins > 32768
 // the multi-pass path in chunks that fit the scratch blocks
+// d_tile / d_records (either may be null): produced here too, by the transform's own epilogue where the plan fuses them
+// (N = 32768), by tile_kernel / scan_kernel behind it otherwise
 int launch_transform(ro_stft *h, const void *d_iq, int format, int64_t first_row, int64_t rows, float *d_rows,
-                     int64_t row_stride, hipStream_t s)
+                     int64_t row_stride, hipStream_t s, float *d_tile = nullptr, ro_scan_record_t *d_records = nullptr);
+
+int launch_tile_and_scan(ro_stft *h, const float *d_rows, int64_t row_stride, int64_t rows, float *d_tile,
+                         ro_scan_record_t *d_records, hipStream_t s)
+{
+    if (ro::stft_fuses_scan(h->bins)) return RO_OK;                 // already written by the transform
+    if (d_tile) HIP_TRY(ro::launch_tile(make_tile_args(h, d_rows, row_stride, rows, d_tile), s));
+    if (d_records) HIP_TRY(ro::launch_scan(make_scan_args(h, d_rows, row_stride, rows, d_records), s));
+    return RO_OK;
+}
+
+int launch_transform(ro_stft *h, const void *d_iq, int format, int64_t first_row, int64_t rows, float *d_rows,
+                     int64_t row_stride, hipStream_t s, float *d_tile, ro_scan_record_t *d_records)
 {
     if (!h->big) {
-        ro::StftArgs a = make_stft_args(h, d_iq, first_row, rows, d_rows, row_stride);
+        ro::StftArgs a = make_stft_args(h, d_iq, first_row, rows, d_rows, row_stride, d_tile, d_records);
         HIP_TRY(ro::launch_stft(h->bins, format, a, s));
         return RO_OK;
     }
@@ -345,12 +372,10 @@ int run_stream_batch(ro_stft *h, int64_t rows)
     if (!b) return fail(RO_ERR_NOMEM, "out of pinned host memory for a row batch");
     HIP_TRY(hipEventRecord(b->k0, h->stream));
     {
-        int rc = launch_transform(h, h->d_iq, RO_IQ_F32, 0, rows, h->d_rows, h->bins, h->stream);
+        ro_scan_record_t *recs = h->cfg.enable_scan ? h->d_records : nullptr;
+        int rc = launch_transform(h, h->d_iq, RO_IQ_F32, 0, rows, h->d_rows, h->bins, h->stream, nullptr, recs);
+        if (rc == RO_OK) rc = launch_tile_and_scan(h, h->d_rows, h->bins, rows, nullptr, recs, h->stream);
         if (rc != RO_OK) { release_batch(h, b); return rc; }
-    }
-    if (h->cfg.enable_scan) {
-        ro::ScanArgs s = make_scan_args(h, h->d_rows, h->bins, rows, h->d_records);
-        HIP_TRY(ro::launch_scan(s, h->stream));
     }
     HIP_TRY(hipEventRecord(b->k1, h->stream));
     b->first_row = h->rows_emitted;
@@ -713,13 +738,10 @@ extern "C" int ro_stft_run_resident(ro_stft_t *h, const void *d_iq, int format, 
     if (rc != RO_OK || rows == 0) return rc;
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;      // NULL = the default (null) stream, like any HIP launch
-    rc = launch_transform(h, d_iq, format, first_row, rows, d_rows, row_stride, s);
+    rc = launch_transform(h, d_iq, format, first_row, rows, d_rows, row_stride, s, d_tile, d_records);
     if (rc != RO_OK) return rc;
-    if (d_tile) HIP_TRY(ro::launch_tile(make_tile_args(h, d_rows, row_stride, rows, d_tile), s));
-    if (d_records) {
-        ro::ScanArgs sc = make_scan_args(h, d_rows, row_stride, rows, d_records);
-        HIP_TRY(ro::launch_scan(sc, s));
-    }
+    rc = launch_tile_and_scan(h, d_rows, row_stride, rows, d_tile, d_records, s);
+    if (rc != RO_OK) return rc;
     h->stat_launches += 1;
     h->stat_rows += rows;
     return RO_OK;
@@ -789,28 +811,46 @@ extern "C" int ro_stft_time_resident(ro_stft_t *h, const void *d_iq, int format,
     if (iters <= 0 || !ms_out) return fail(RO_ERR_INVALID, "iters must be positive and ms_out non-null");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;      // NULL = the default (null) stream, like any HIP launch
-    std::vector<hipEvent_t> ev((size_t)iters * 3);
-    for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
-    ro::ScanArgs sc = make_scan_args(h, d_rows, row_stride, rows, d_records);
-    for (int i = 0; i < iters; ++i) {
-        HIP_TRY(hipEventRecord(ev[3 * i], s));
-        rc = launch_transform(h, d_iq, format, first_row, rows, d_rows, row_stride, s);
-        if (rc != RO_OK) return rc;
-        HIP_TRY(hipEventRecord(ev[3 * i + 1], s));
-        if (d_tile) HIP_TRY(ro::launch_tile(make_tile_args(h, d_rows, row_stride, rows, d_tile), s));
-        if (d_records) HIP_TRY(ro::launch_scan(sc, s));
-        HIP_TRY(hipEventRecord(ev[3 * i + 2], s));
+    std::vector<hipEvent_t> ev((size_t)iters * 3, nullptr);
+    for (auto &e : ev) {
+        if (hipEventCreate(&e) != hipSuccess) {
+            for (auto &d : ev) if (d) (void)hipEventDestroy(d);
+            return fail(RO_ERR_HIP, "hipEventCreate failed");
+        }
     }
-    HIP_TRY(hipStreamSynchronize(s));
+    for (int i = 0; i < iters && rc == RO_OK; ++i) {
+        hipError_t e = hipEventRecord(ev[3 * i], s);
+        if (e == hipSuccess) {
+            rc = launch_transform(h, d_iq, format, first_row, rows, d_rows, row_stride, s, d_tile, d_records);
+            if (rc != RO_OK) break;
+            e = hipEventRecord(ev[3 * i + 1], s);
+        }
+        if (e == hipSuccess) {
+            rc = launch_tile_and_scan(h, d_rows, row_stride, rows, d_tile, d_records, s);
+            if (rc != RO_OK) break;
+            e = hipEventRecord(ev[3 * i + 2], s);
+        }
+        if (e != hipSuccess) rc = fail(RO_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(e));
+    }
+    if (rc != RO_OK) {                                  // leave no event behind on the error paths
+        (void)hipStreamSynchronize(s);
+        for (auto &e : ev) (void)hipEventDestroy(e);
+        return rc;
+    }
+    hipError_t es = hipStreamSynchronize(s);
     double k0 = 0.0, k1 = 0.0;
-    for (int i = 0; i < iters; ++i) {
+    for (int i = 0; i < iters && es == hipSuccess; ++i) {
         float t = 0.f, t0 = 0.f, t1 = 0.f;
-        HIP_TRY(hipEventElapsedTime(&t, ev[3 * i], ev[3 * i + 2]));
-        HIP_TRY(hipEventElapsedTime(&t0, ev[3 * i], ev[3 * i + 1]));
-        HIP_TRY(hipEventElapsedTime(&t1, ev[3 * i + 1], ev[3 * i + 2]));
+        if ((es = hipEventElapsedTime(&t, ev[3 * i], ev[3 * i + 2])) != hipSuccess) break;
+        if ((es = hipEventElapsedTime(&t0, ev[3 * i], ev[3 * i + 1])) != hipSuccess) break;
+        if ((es = hipEventElapsedTime(&t1, ev[3 * i + 1], ev[3 * i + 2])) != hipSuccess) break;
         ms_out[i] = t;
         k0 += t0;
         k1 += t1;
+    }
+    if (es != hipSuccess) {
+        for (auto &e : ev) (void)hipEventDestroy(e);
+        return fail(RO_ERR_HIP, "timing the resident path failed: %s", hipGetErrorString(es));
     }
     if (kernel_ms_out) {
         kernel_ms_out[0] = (float)(k0 / iters);
