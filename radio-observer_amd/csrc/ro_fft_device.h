@@ -328,22 +328,50 @@ template <typename F> __device__ __forceinline__ void fdit32_last(v2f *x, v2f g1
     fdit_last_level(x, g1, done, std::make_integer_sequence<int, 8>{});
 }
 
-// dit<32> with hooks: hook(0) after the first level, hook(1..3) after the first three quarter sub-transforms --
-// four evenly spaced places for the caller to slip other work (row stores) between the butterflies
-template <typename F> __device__ __forceinline__ void dit32_hooked(v2f *v, F hook)
+// dit<32> in LEVEL order (dit_rec walks the same butterflies depth first), in two parts like fdit32: levels 0..3 with a
+// hook after each of them (four evenly spaced places for the caller to slip other work -- row stores -- between the
+// butterflies), then the last level with the pair hook of fdit_last_pair.  Block U of level L has exponent
+// bitrev_L(U) * (16 >> L), as in the recursion.
+template <int L, int... Us>
+__device__ __forceinline__ void dit_level_order(v2f *v, const v2f *&tok, std::integer_sequence<int, Us...>)
+{
+    constexpr int S = 32 >> L;
+    (dit_level<S, bitrev_bits<L>(Us) * (16 >> L)>(v + Us * S, tok, std::make_integer_sequence<int, S / 2>{}), ...);
+}
+
+template <typename F> __device__ __forceinline__ void dit32_head(v2f *v, F hook)
 {
     const v2f *tok = &v[31];
-    dit_level<32, 0>(v, tok, std::make_integer_sequence<int, 16>{});
+    dit_level_order<0>(v, tok, std::make_integer_sequence<int, 1>{});
     hook(std::integral_constant<int, 0>{});
-    dit_level<16, 0>(v, tok, std::make_integer_sequence<int, 8>{});
-    dit_rec<8, 0>(v, tok);
+    dit_level_order<1>(v, tok, std::make_integer_sequence<int, 2>{});
     hook(std::integral_constant<int, 1>{});
-    dit_rec<8, 8>(v + 8, tok);
+    dit_level_order<2>(v, tok, std::make_integer_sequence<int, 4>{});
     hook(std::integral_constant<int, 2>{});
-    dit_level<16, 8>(v + 16, tok, std::make_integer_sequence<int, 8>{});
-    dit_rec<8, 4>(v + 16, tok);
+    dit_level_order<3>(v, tok, std::make_integer_sequence<int, 8>{});
     hook(std::integral_constant<int, 3>{});
-    dit_rec<8, 12>(v + 24, tok);
+}
+
+template <int J, typename F> __device__ __forceinline__ void dit_last_pair(v2f *x, float &chain, F &done)
+{
+    tie(x[2 * J], chain);
+    dit_pair<bitrev_bits<4>(J)>(x[2 * J], x[2 * J + 1]);
+    tie(x[16 + 2 * J], x[2 * J + 1]);
+    dit_pair<bitrev_bits<4>(8 + J)>(x[16 + 2 * J], x[17 + 2 * J]);
+    chain = done(std::integral_constant<int, J>{});
+}
+
+template <typename F, int... Js>
+__device__ __forceinline__ void dit_last_level(v2f *x, F &done, std::integer_sequence<int, Js...>)
+{
+    float chain = x[31].x;
+    (dit_last_pair<Js>(x, chain, done), ...);
+}
+
+// last level of dit<32>: pairs (j, 8 + j) in the order j = 0..7, done(j) after each (see fdit_last_pair)
+template <typename F> __device__ __forceinline__ void dit32_last(v2f *x, F done)
+{
+    dit_last_level(x, done, std::make_integer_sequence<int, 8>{});
 }
 
 template <int R> __host__ __device__ constexpr int bitrev(int k)

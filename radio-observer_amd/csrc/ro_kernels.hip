@@ -88,6 +88,12 @@
 #ifndef RO_PIPE_J
 #define RO_PIPE_J 6
 #endif
+#ifndef RO_SCAN_W0
+#define RO_SCAN_W0 0
+#define RO_SCAN_W1 1
+#define RO_SCAN_W2 2
+#define RO_SCAN_W3 3
+#endif
 #ifndef RO_FUSE_SCAN
 #define RO_FUSE_SCAN 1
 #endif
@@ -100,6 +106,9 @@
 // share (percent) of the next row's window coefficients that is prefetched across the transform
 #ifndef RO_WIN_EARLY_PCT
 #define RO_WIN_EARLY_PCT 50
+#endif
+#ifndef RO_PIPE_WIN_EARLY_PCT
+#define RO_PIPE_WIN_EARLY_PCT 25
 #endif
 // window coefficients in flight per chunk (two chunks are outstanding)
 #ifndef RO_WIN_CHUNK
@@ -540,6 +549,57 @@ __device__ __forceinline__ void exchange_addtid(void *smem, v2f (&v)[32 * NB], i
     sub(3);
 }
 
+// The same exchange in pieces, for the pipelined row loop: the x-plane scatter is issued by the caller from inside the
+// last butterfly level of the finished stage (scatter_x_pair, four slots per pair of butterflies, so the LDS writes run
+// beside the VALU instead of behind it); exchange_tail does the rest and ends WITHOUT a barrier behind its y-plane
+// gather -- the caller places that barrier after levels 0..3 of the next stage, right in front of the next LDS writes,
+// and the gathers return in the order the first level consumes them (slot i, i + 16), so the butterflies start while
+// the gather is still coming in.
+template <int XCH> constexpr int addtid_row_bytes() { return (XCH == 1 ? 1025 : 1024) * 4; }
+// M0 for slots 16..31 (see addtid_scatter32): M0 and the offset field hold 16 bits each
+template <int ROWB> constexpr int addtid_hb() { return (31 * ROWB - 65532 + 3) / 4 * 4; }
+
+// slots of the four registers a last-level pair (j, 8 + j) finishes: 2j -> q, 16+2j -> q+1, 2j+1 -> q+16, 17+2j -> q+17
+template <int ROWB, int J>
+__device__ __forceinline__ void addtid_write_pair(unsigned wave_bytes, float s_q, float s_q1, float s_q16, float s_q17)
+{
+    constexpr int q = bitrev<32>(2 * J), HB = addtid_hb<ROWB>();
+    static_assert(q % 2 == 0 && q < 16 && bitrev<32>(2 * J + 1) == q + 16 && bitrev<32>(16 + 2 * J) == q + 1 &&
+                  bitrev<32>(17 + 2 * J) == q + 17, "slot algebra");
+    static_assert(HB + 3840 <= 65532 && 31 * ROWB - HB <= 65535 && 16 * ROWB - HB >= 0, "M0 / offset split");
+    addtid_write4<ROWB * q, ROWB * (q + 1), ROWB * (q + 16) - HB, ROWB * (q + 17) - HB>(wave_bytes, wave_bytes + HB, s_q,
+                                                                                        s_q1, s_q16, s_q17);
+}
+
+template <int XCH, bool SWAP32>
+__device__ __forceinline__ void exchange_tail(void *smem, v2f (&v)[32], int tid)
+{
+    constexpr int ROW = XCH == 1 ? 1025 : 1024;
+    constexpr bool PERM = XCH == 1 && SWAP32;
+    const float *lds = reinterpret_cast<const float *>(smem);
+    const unsigned wave_bytes = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6) * 256u;
+    const int q = tid >> 5;
+    const float *gb = lds + (XCH == 1 ? (tid & 31) * 1025 + (PERM ? 32 * (q & 1) + (q >> 1) : q) : (tid >> 5) * 1024 + (tid & 31));
+    auto goff = [](int r) constexpr { return PERM ? 64 * (r >> 1) + 16 * (r & 1) : 32 * r; };
+    typedef const volatile __attribute__((address_space(3))) float lds_vfloat;
+    lds_vfloat *gv = (lds_vfloat *)gb;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the caller's x-plane scatter
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 32; ++r) v[r].x = gv[goff(r)];
+    wg_sync();
+    addtid_scatter32<ROW * 4>(wave_bytes, [&](int s) { return v[bitrev<32>(s)].y; });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {                                // the order level 0 of the next stage pairs them
+        v[i].y = gv[goff(i)];
+        v[i + 16].y = gv[goff(i + 16)];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // per-row band scan: BolidRecorder::noise / peak / average (src/BolidRecorder.cpp:313-347), one wavefront per row.
 // Shared by scan_kernel (rows in HBM) and the fused epilogue of the N = 32768 plan (row still in LDS).
@@ -583,18 +643,23 @@ template <int N> struct ImageRow {
 
 constexpr int SCAN_E = 16;            // noise-band elements cached per lane by the CACHED form (band <= 1024)
 
-__device__ __forceinline__ unsigned wave_min_u32(unsigned x)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) x = min(x, (unsigned)__shfl_xor((int)x, d));
-    return x;
-}
+// maximum / minimum over the 64 lanes, VALU only (the same DPP ladder as wave_inclusive_sum with max in the place of
+// +: an inclusive prefix maximum whose last lane holds the total; 0 is the identity the out-of-row lanes read).  The
+// __shfl_xor form these replace is six DEPENDENT ds_bpermute round trips (~120 cycles each) per reduction -- the
+// fused scan's two waves spent most of their time in them.
 __device__ __forceinline__ unsigned wave_max_u32(unsigned x)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) x = max(x, (unsigned)__shfl_xor((int)x, d));
-    return x;
+    int v = (int)x;
+    auto mx = [](int a, int b) { return (int)max((unsigned)a, (unsigned)b); };
+    v = mx(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true));     // row_shr:1
+    v = mx(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true));     // row_shr:2
+    v = mx(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true));     // row_shr:4
+    v = mx(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true));     // row_shr:8
+    v = mx(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true));     // row_bcast:15 -> rows 1 and 3
+    v = mx(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true));     // row_bcast:31 -> rows 2 and 3
+    return (unsigned)__builtin_amdgcn_readlane(v, 63);
 }
+__device__ __forceinline__ unsigned wave_min_u32(unsigned x) { return ~wave_max_u32(~x); }
 
 // noise(): element floor(W/4) of the ascending noise band, times two (src/BolidRecorder.cpp:313-317).
 // Order statistic by radix select on the order-preserving integer image of the floats, exact (the result is an
@@ -605,14 +670,15 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned x)
 // finds the bin holding rank k, k drops by the count below it; a bin holding ONE key ends the search early (that
 // key is looked up), which is the usual exit after two passes.
 // CACHED: keys live in registers (W <= 64 * SCAN_E); otherwise every pass re-reads the row (cheap from LDS).
-template <bool CACHED, class Row>
+template <int E, class Row>      // E > 0: keys cached in E registers per lane (W <= 64 E); E = 0: re-read every pass
 __device__ __forceinline__ float scan_noise(Row row, int low_noise, int W, unsigned *h, int lane)
 {
+    constexpr bool CACHED = E > 0;
     if (W <= 0) return key_to_float(0xffffffffu) * 2.0f;        // the reference indexes an empty array (undefined)
-    unsigned keys[CACHED ? SCAN_E : 1];
+    unsigned keys[CACHED ? E : 1];
     if constexpr (CACHED) {
 #pragma unroll
-        for (int e = 0; e < SCAN_E; ++e) {
+        for (int e = 0; e < E; ++e) {
             const int i = lane + 64 * e;
             // clamped index instead of a guarded load: no divergent branch, never outside the band
             keys[e] = order_key(row(low_noise + (i < W ? i : W - 1)));
@@ -622,7 +688,7 @@ __device__ __forceinline__ float scan_noise(Row row, int low_noise, int W, unsig
     auto for_keys = [&](auto f) {
         if constexpr (CACHED) {
 #pragma unroll
-            for (int e = 0; e < SCAN_E; ++e)
+            for (int e = 0; e < E; ++e)
                 if (64 * e < W) f(keys[e], lane + 64 * e < W);
         } else {
             for (int i0 = 0; i0 < W; i0 += 64) {
@@ -683,7 +749,7 @@ __device__ __forceinline__ float scan_noise(Row row, int low_noise, int W, unsig
                 for_keys([&](unsigned key, bool valid) {
                     if (valid && ((key ^ prefix) >> shift) == 0u) found = key;
                 });
-                result = wave_max_u32(found);            // every other lane holds 0
+                result = wave_max_u32(found);            // every other lane holds 0 (and no key is 0: order_key)
                 break;
             }
             top = shift - 1;
@@ -694,21 +760,21 @@ __device__ __forceinline__ float scan_noise(Row row, int low_noise, int W, unsig
 
 // peak(): last index of the maximum of the detect band (src/BolidRecorder.cpp:323-335: `>=`, so ties go to the
 // highest index).  Per-lane arg-max-last in index order, then a cross-lane reduction with "larger index wins".
-template <bool CACHED, class Row>
+template <int E, class Row>      // E > 0 and DW <= 64 E: all loads first; else one load per step
 __device__ __forceinline__ int scan_peak(Row row, int low_detect, int DW, int lane)
 {
     float best = 0.f;
     int best_i = -1;
-    if (CACHED && DW <= 64 * SCAN_E) {
+    if (E > 0 && DW <= 64 * E) {
         // all loads first (one miss latency, not one per 64 columns)
-        float xs[SCAN_E];
+        float xs[E > 0 ? E : 1];
 #pragma unroll
-        for (int e = 0; e < SCAN_E; ++e) {
+        for (int e = 0; e < E; ++e) {
             const int i = lane + 64 * e;
             xs[e] = row(low_detect + (i < DW ? i : (DW > 0 ? DW - 1 : 0)));
         }
 #pragma unroll
-        for (int e = 0; e < SCAN_E; ++e) {
+        for (int e = 0; e < E; ++e) {
             const int i = lane + 64 * e;
             if (i < DW && (best_i < 0 || xs[e] >= best)) { best = xs[e]; best_i = i; }
         }
@@ -718,13 +784,11 @@ __device__ __forceinline__ int scan_peak(Row row, int low_detect, int DW, int la
             if (best_i < 0 || x >= best) { best = x; best_i = i; }
         }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const float ob = __shfl_xor(best, off);
-        const int oi = __shfl_xor(best_i, off);
-        const bool take = (oi >= 0) && (best_i < 0 || ob > best || (ob == best && oi > best_i));
-        if (take) { best = ob; best_i = oi; }
-    }
+    // cross-lane: the largest value, then the largest index among the lanes that hold it (two DPP reductions)
+    const unsigned bk = best_i < 0 ? 0u : order_key(best);             // order_key never gives 0 for a real value
+    const unsigned top = wave_max_u32(bk);
+    const unsigned cand = (best_i >= 0 && bk == top) ? (unsigned)best_i + 1u : 0u;
+    best_i = (int)wave_max_u32(cand) - 1;
     return best_i < 0 ? 0 : best_i;
 }
 
@@ -741,9 +805,9 @@ __device__ __forceinline__ float scan_average(Row row, int start, int avg_bins, 
         const float x = (base + lane < avg_bins && c >= 0 && c < bins) ? row(c) : 0.f;
         const int n = avg_bins - base < 64 ? avg_bins - base : 64;
         for (int i = 0; i < n; ++i) {
-            const int ci = start + base + i;
-            const float xi = __shfl(x, i);
-            if (ci >= 0 && ci < bins) acc += (double)xi;
+            // v_readlane with a uniform lane number: a few cycles, where __shfl was an LDS round trip per element of
+            // this dependent chain (out-of-row columns were loaded as 0 and add nothing, like before)
+            acc += (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), i));
         }
     }
     return (float)(acc / (double)avg_bins);
@@ -927,8 +991,10 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
     // (their registers are free for the whole transform, so these loads cost nothing); the
     // rest follows in the epilogue.  (Keeping all of them resident instead -- they are the same for every row --
     // makes hipcc spill 31 registers; prefetching 100 % fits but leaves no VGPR to spare and gains 1 %.)
-    // (the int16 form of the pipelined plan converts while it windows and has fewer registers to spare: a quarter)
-    constexpr int NW_EARLY = ((NW * (plan_pipe<PL>() && FMT == RO_FMT_I16 ? 25 : RO_WIN_EARLY_PCT)) / 100) & ~1;
+    // (the pipelined plan has fewer registers to spare -- the fused scan's two waves keep their band in registers
+    // while the next row's samples are already landing: a quarter; with half, hipcc parks one coefficient quad in
+    // scratch for the whole row)
+    constexpr int NW_EARLY = ((NW * (plan_pipe<PL>() ? RO_PIPE_WIN_EARLY_PCT : RO_WIN_EARLY_PCT)) / 100) & ~1;
     using c0 = std::integral_constant<int, 0>;
     using cE = std::integral_constant<int, NW_EARLY>;
     using cN = std::integral_constant<int, NW>;
@@ -950,6 +1016,11 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
     // PIPE: the image of the row before this one (LDS, natural order) and where it goes; 0 bytes = nothing to store
     constexpr bool PIPE = plan_pipe<PL>() && MODE == 0;
     constexpr bool FUSE = PIPE && RO_FUSE_SCAN;
+    // Who runs the fused scan and cuts the tile: waves 0..3, the OLDEST wave of each SIMD (waves are dealt to the SIMDs
+    // cyclically and the arbiter serves the oldest first).  In-kernel stamps show wave 0 reaching the barrier in front
+    // of the first exchange ~4.6k cycles before the last wave does: that slack pays for the scan.  (With waves 3, 6, 9,
+    // 12 -- one of them second-oldest on its SIMD -- the fused scan cost 12 % of the kernel.)
+    constexpr int SCAN_WAVE_NOISE = RO_SCAN_W0, SCAN_WAVE_PEAK = RO_SCAN_W1, TILE_WAVE_A = RO_SCAN_W2, TILE_WAVE_B = RO_SCAN_W3;
     constexpr int PIPE_J = RO_PIPE_J;      // butterfly pairs of the last level that request next-row samples (of 8)
     const float *prev_out = a.rows_out;
     unsigned prev_bytes = 0;
@@ -1029,12 +1100,10 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             if constexpr (!ADDTID) return;          // only the add-TID plan is launched with a.prefetch
             // samples [next*hop + N - hop, next*hop + N) = hop * BYTES bytes: one dword per 128-byte line and thread
             // (reaches 128 KiB: hop <= N/2 for float samples; whatever lies past the descriptor's end costs nothing).
-            // The dword is not wanted, only its line in L2.  It is a load hipcc can see, into a register that is
-            // "used" only after the next window stage (younger loads have been waited for by then, so that use never
-            // waits): two attempts to do without the register failed -- LDS-DMA into a scrap line (M0 reaches only
-            // the first 64 KiB of LDS: the DMA landed on byte 0xFFFC of the magnitude image) and loads issued from
-            // inline asm (hipcc copied the "finished" value elsewhere and reused the register while the data was
-            // still on its way: stray samples in lanes of whatever lived there next).
+            // The dword is not wanted, only its line in L2; its register is "used" only after the next window stage
+            // (younger loads have been waited for by then, so that use never waits).  One touch per thread, one VGPR:
+            // with two, hipcc ran out of registers in the pipelined loop and spilled them behind an s_waitcnt that sat
+            // through the HBM miss the touch exists to hide.
             const int64_t s0 = (a.first_row + (has_next ? next : row)) * (int64_t)a.hop + (N - a.hop);
             // switched off (a.prefetch == 0, last row) by a zero-sized descriptor, not by a branch
             const __amdgpu_buffer_rsrc_t rs_new =
@@ -1045,16 +1114,153 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         stamp(0);                                   // window multiply (+ wait for samples)
 
         if constexpr (PIPE) {
-            dit32_hooked(v, [&](auto hc) {
+            // =====================================================================================================
+            // The pipelined row (N = 32768, 1024 threads).  Every stage is cut in front of its last butterfly level:
+            //   levels 0..3 | barrier (everyone is done reading LDS) | last level, whose finished pairs go straight
+            //   to LDS (x plane of the next exchange, or the magnitude image) while the other pairs are still being
+            //   computed | rest of the exchange.
+            // Around the row boundary: the next row's samples are requested from inside the last level of the last
+            // pass, each into the registers whose magnitudes have just gone to the image; the image leaves for HBM
+            // (LDS read-back + 16-byte stores) from inside the next row's first butterflies.
+            // =====================================================================================================
+            static_assert(P == 32 && NB == 1 && SWAP32, "one radix-32 butterfly per thread");
+            const unsigned wave_bytes = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6) * 256u;
+            // ---- pass 0, levels 0..3; the previous row's image goes out between them
+            dit32_head(v, [&](auto hc) {
                 constexpr int h = decltype(hc)::value;
                 if constexpr (RO_PIPE_WSTORES) store_chunk(4 + h, rs_prev);
                 else { store_chunk(2 * h, rs_prev); store_chunk(2 * h + 1, rs_prev); }
             });
-            // every wave has read its part of the image back: LDS belongs to the exchanges again
-            wg_sync();
-        } else {
-            butterflies<P, R0>(v);
+            tw_prefetch<P, T, 32, PL::NS1, PL::TW1, PL::PK1>(tw1, rs_tw, rs_twk, tid);
+            stamp(2);                               // butterflies 0, levels 0..3 (+ the previous row's read-back and stores)
+            wg_sync();                              // every wave has read its part of the image back: LDS is free
+            stamp(7);
+            // ---- pass 0, last level: x plane of exchange 1 as the pairs finish
+            dit32_last(v, [&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                addtid_write_pair<addtid_row_bytes<1>(), j>(wave_bytes, v[2 * j].x, v[16 + 2 * j].x, v[2 * j + 1].x,
+                                                            v[17 + 2 * j].x);
+                return v[17 + 2 * j].y;
+            });
+            stamp(10);
+            exchange_tail<1, SWAP32>(smem, v, tid);
+            stamp(3);                               // exchange 1
+            // ---- pass 1
+            fdit32_head(v, tw1[0][4], tw1[0][3], tw1[0][2], tw1[0][1]);
+            // the touch sits behind the butterflies: in front of them hipcc's wait for this pass's twiddles would sit
+            // through the touch's HBM miss as well
+            touch_next();
+            tw_prefetch<P, T, 32, PL::NS2, PL::TW2, PL::PK2>(tw2, rs_tw, rs_twk, tid);
+            stamp(4);
+            wg_sync();                              // exchange 1's y plane has been gathered by everyone
+            stamp(11);
+            fdit32_last(v, tw1[0][0], [&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                addtid_write_pair<addtid_row_bytes<2>(), j>(wave_bytes, v[2 * j].x, v[16 + 2 * j].x, v[2 * j + 1].x,
+                                                            v[17 + 2 * j].x);
+                return v[17 + 2 * j].y;
+            });
+            stamp(12);
+            exchange_tail<2, SWAP32>(smem, v, tid);
+            stamp(5);                               // exchange 2
+            // ---- pass 2
+            fdit32_head(v, tw2[0][4], tw2[0][3], tw2[0][2], tw2[0][1]);
+            stamp(6);
+            wg_sync();                              // exchange 2's y plane has been gathered by everyone
+            stamp(13);
+            {
+                // Last level with the epilogue folded in.  After butterflies (j, 8 + j) x[2j], x[2j+1], x[16+2j],
+                // x[17+2j] are final = bins tid + 1024 q for q = qj, qj+16, qj+1, qj+17 (qj = bitrev32(2j)): their
+                // magnitudes go to the natural-order LDS image (byte 4096 q + 4 tid, add-TID), and the four freed
+                // registers receive legs 2j, 2j+1 of the NEXT row's samples -- for j < PIPE_J; the last legs are
+                // requested behind the scan (they are also the last ones the window stage asks for), whose two waves
+                // would not fit the 128 VGPRs with all 64 of them in flight.
+                const __amdgpu_buffer_rsrc_t rs_next =
+                    make_rsrc(iq + (a.first_row + (has_next ? next : row)) * (int64_t)a.hop * S::BYTES,
+                              has_next ? N * S::BYTES : 0);     // zero-sized after the last row: the loads are no-ops
+                const int po = pair_off(0) * S::BYTES;
+                // The image writes of pair j are issued one pair late (from done(j + 1), the last ones behind the
+                // level): v_sqrt_f32 runs in the transcendental pipe and hipcc pads no hazards in front of inline asm.
+                float pm0 = 0.f, pm1 = 0.f, pm16 = 0.f, pm17 = 0.f;
+                fdit32_last(v, tw2[0][0], [&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    auto mag = [](v2f x) { const v2f sq = x * x; return __builtin_amdgcn_sqrtf(sq.x + sq.y); };
+                    const float m0 = mag(v[2 * j]), m16 = mag(v[2 * j + 1]);
+                    const float m1 = mag(v[16 + 2 * j]), m17 = mag(v[17 + 2 * j]);
+                    if constexpr (j > 0) addtid_write_pair<4096, (j > 0 ? j - 1 : 0)>(wave_bytes, pm0, pm1, pm16, pm17);
+                    pm0 = m0; pm1 = m1; pm16 = m16; pm17 = m17;
+                    if constexpr (j < PIPE_J) {
+                        // the loads may not start before these magnitudes exist (fake dependence; no instruction)
+                        const int pj = after(po, m17);
+                        S::load_pair(rs_next, pj, (2 * j) * (N / R0) * S::BYTES, v[2 * j], v[H + 2 * j]);
+                        S::load_pair(rs_next, pj, (2 * j + 1) * (N / R0) * S::BYTES, v[2 * j + 1], v[H + 2 * j + 1]);
+                    }
+                    return m17;                                  // the next pair of butterflies is chained behind this
+                });
+                stamp(14);
+                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // the last square roots: see above
+                addtid_write_pair<4096, 7>(wave_bytes, pm0, pm1, pm16, pm17);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the add-TID image writes (hipcc does not count them)
+                wg_sync();                                            // the image of this row is complete
+                stamp(15);
+                if constexpr (FUSE) {
+                    // BolidRecorder's per-row scan on the image (src/BolidRecorder.cpp:121-132, :313-347) by waves 0
+                    // and 1 while the others go on to the next row's window stage; the image stays until the barrier
+                    // in front of the next LDS writes.  Waves 2 and 3 cut the band tile.
+                    // Everything derived from the lane number and the band limits is laundered through empty asm:
+                    // otherwise hipcc hoists those loop invariants in front of the row loop, where they sit in VGPRs
+                    // of all 16 waves for the whole row.
+                    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+                    int lane = tid & 63;
+                    asm volatile("" : "+v"(lane));
+                    const ImageRow<N> img{reinterpret_cast<const float *>(smem)};
+                    if (a.records != nullptr && (wave == SCAN_WAVE_NOISE || wave == SCAN_WAVE_PEAK)) {
+                        int low_noise = a.low_noise, noise_width = a.noise_width, low_detect = a.low_detect;
+                        int detect_width = a.detect_width, avg_bins = a.avg_bins;
+                        asm volatile("" : "+s"(low_noise), "+s"(noise_width), "+s"(low_detect), "+s"(detect_width),
+                                     "+s"(avg_bins));
+                        if (wave == SCAN_WAVE_NOISE) {
+                            unsigned *hist = reinterpret_cast<unsigned *>(smem + PL::LDS_BYTES);
+                            // bands up to 512 columns (the shipped configs: 409 / 410) keep their keys in registers
+                            const float nz = noise_width <= 512 ? scan_noise<8>(img, low_noise, noise_width, hist, lane)
+                                                                : scan_noise<0>(img, low_noise, noise_width, hist, lane);
+                            if (lane == 0) a.records[row].noise = nz;
+                        } else {
+                            const int pk = scan_peak<8>(img, low_detect, detect_width, lane);
+                            const float av = scan_average(img, low_detect + pk - avg_bins / 2, avg_bins, N, lane);
+                            if (lane == 0) {
+                                a.records[row].peak = pk;
+                                a.records[row].average = av;
+                            }
+                        }
+                    }
+                    if (a.tile_out != nullptr && (wave == TILE_WAVE_A || wave == TILE_WAVE_B)) {
+                        int tile_cols = a.tile_cols, tile_first = a.tile_first;
+                        asm volatile("" : "+s"(tile_cols), "+s"(tile_first));
+                        const int half = ((tile_cols + 127) >> 7) << 6;            // first wave's share, whole 64s
+                        const int c0 = wave == TILE_WAVE_A ? 0 : half;
+                        const int c1 = wave == TILE_WAVE_A ? (half < tile_cols ? half : tile_cols) : tile_cols;
+                        float *dst = a.tile_out + row * (int64_t)tile_cols;
+                        for (int c = c0 + lane; c < c1; c += 64) dst[c] = img(tile_first + c);
+                    }
+                }
+                // the legs the last level did not request, then the rest of the window coefficients (behind the scan,
+                // whose waves need the registers; they have the window stage's first legs to land)
+#pragma unroll
+                for (int k = 2 * PIPE_J; k < H; ++k)
+                    S::load_pair(rs_next, po, k * (N / R0) * S::BYTES, v[k], v[H + k]);
+            }
+            if constexpr (!RESW) load_window(make_rsrc(win_tab, has_next ? N * 4 : 0), cE{}, cN{});
+            stamp(8);
+            prev_out = a.rows_out + row * a.row_stride;
+            prev_bytes = N * 4;
+            st_acc[9] += 1;
+            if (!has_next) break;
+            row = next;
+            continue;
         }
+
+        butterflies<P, R0>(v);
         if constexpr (PL::R1 > 1 && !RES) tw_prefetch<P, T, PL::R1, PL::NS1, PL::TW1, PL::PK1>(tw1, rs_tw, rs_twk, tid);
         stamp(2);                                   // butterflies 0
 
@@ -1076,104 +1282,9 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             else exchange<PL, PL::R1, PL::NS1, PL::R2>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             stamp(5);                               // exchange 2
             if constexpr (RO_PREFETCH_NEXT == 3) touch_next();
-            if constexpr (PIPE) {
-                // Last pass with the epilogue folded into its last level.  After butterflies (j, 8 + j) of that level
-                // x[2j], x[2j+1], x[16+2j], x[17+2j] are final = bins (tid + 1024 q) for q = qj, qj+16, qj+1, qj+17
-                // (qj = bitrev32(2j)): their magnitudes go to the natural-order LDS image (byte 4096 q + 4 tid,
-                // add-TID), and the four freed registers receive legs 2j, 2j+1 of the NEXT row's samples -- for
-                // j < PIPE_J; the last legs are requested behind the scan (they are also the last ones the window
-                // stage asks for), whose two waves would not fit the 128 VGPRs with all 64 of them in flight.
-                const __amdgpu_buffer_rsrc_t rs_next =
-                    make_rsrc(iq + (a.first_row + (has_next ? next : row)) * (int64_t)a.hop * S::BYTES,
-                              has_next ? N * S::BYTES : 0);     // zero-sized after the last row: the loads are no-ops
-                const unsigned wave_bytes = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6) * 256u;
-                constexpr int HB = 61444;                        // see addtid_scatter32<4096>: M0 for slots 16..31
-                const int po = pair_off(0) * S::BYTES;
-                // The image writes of pair j are issued one pair late (from done(j + 1), the last ones behind the level):
-                // v_sqrt_f32 runs in the transcendental pipe, and a ds_write_addtid_b32 that follows it within a few
-                // instructions reads its data register before the last lanes of the result have been written -- the
-                // hardware does not interlock the two and hipcc inserts no wait states in front of inline asm (seen:
-                // lanes 51, 55, 59, 63 of one row in ten carried the register's previous contents).
-                float pm0 = 0.f, pm1 = 0.f, pm16 = 0.f, pm17 = 0.f;
-                auto write_pair = [&](auto jc) {
-                    constexpr int q = bitrev<32>(2 * decltype(jc)::value);
-                    static_assert(q % 2 == 0 && q < 16, "slot algebra");
-                    addtid_write4<4096 * q, 4096 * (q + 1), 4096 * (q + 16) - HB, 4096 * (q + 17) - HB>(
-                        wave_bytes, wave_bytes + HB, pm0, pm1, pm16, pm17);
-                };
-                auto done = [&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    static_assert(bitrev<32>(2 * j + 1) == bitrev<32>(2 * j) + 16 && bitrev<32>(16 + 2 * j) == bitrev<32>(2 * j) + 1 &&
-                                  bitrev<32>(17 + 2 * j) == bitrev<32>(2 * j) + 17, "slot algebra");
-                    auto mag = [](v2f x) { const v2f sq = x * x; return __builtin_amdgcn_sqrtf(sq.x + sq.y); };
-                    const float m0 = mag(v[2 * j]), m16 = mag(v[2 * j + 1]);
-                    const float m1 = mag(v[16 + 2 * j]), m17 = mag(v[17 + 2 * j]);
-                    if constexpr (j > 0) write_pair(std::integral_constant<int, j - 1>{});
-                    pm0 = m0; pm1 = m1; pm16 = m16; pm17 = m17;
-                    if constexpr (j < PIPE_J) {
-                        // the loads may not start before these magnitudes exist (fake dependence; no instruction)
-                        const int pj = after(po, m17);
-                        S::load_pair(rs_next, pj, (2 * j) * (N / R0) * S::BYTES, v[2 * j], v[H + 2 * j]);
-                        S::load_pair(rs_next, pj, (2 * j + 1) * (N / R0) * S::BYTES, v[2 * j + 1], v[H + 2 * j + 1]);
-                    }
-                    return m17;                                  // the next pair of butterflies is chained behind this
-                };
-                static_assert(P == 32 && NB == 1, "one radix-32 butterfly per thread");
-                fdit32_head(v, tw2[0][4], tw2[0][3], tw2[0][2], tw2[0][1]);
-                fdit32_last(v, tw2[0][0], done);
-                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // the last square roots: see above
-                write_pair(std::integral_constant<int, 7>{});
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the add-TID image writes (hipcc does not count them)
-                wg_sync();                                            // the image of this row is complete
-                stamp(11);
-                if constexpr (FUSE) {
-                    // BolidRecorder's per-row scan on the image (src/BolidRecorder.cpp:121-132, :313-347), two waves on
-                    // different SIMDs (waves are dealt to SIMDs cyclically) while the others go on to the next row's
-                    // window stage; the image stays until the barrier in front of the next exchange.  Two more waves
-                    // cut the band tile.
-                    // Everything derived from the lane number and the band limits is laundered through empty asm:
-                    // otherwise hipcc hoists those loop invariants in front of the row loop, where they sit in VGPRs
-                    // of all 16 waves for the whole row.
-                    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-                    int lane = tid & 63;
-                    asm volatile("" : "+v"(lane));
-                    const ImageRow<N> img{reinterpret_cast<const float *>(smem)};
-                    if (a.records != nullptr && (wave == 3 || wave == 6)) {
-                        int low_noise = a.low_noise, noise_width = a.noise_width, low_detect = a.low_detect;
-                        int detect_width = a.detect_width, avg_bins = a.avg_bins;
-                        asm volatile("" : "+s"(low_noise), "+s"(noise_width), "+s"(low_detect), "+s"(detect_width),
-                                     "+s"(avg_bins));
-                        if (wave == 3) {
-                            unsigned *hist = reinterpret_cast<unsigned *>(smem + PL::LDS_BYTES);
-                            const float nz = scan_noise<false>(img, low_noise, noise_width, hist, lane);
-                            if (lane == 0) a.records[row].noise = nz;
-                        } else {
-                            const int pk = scan_peak<false>(img, low_detect, detect_width, lane);
-                            const float av = scan_average(img, low_detect + pk - avg_bins / 2, avg_bins, N, lane);
-                            if (lane == 0) {
-                                a.records[row].peak = pk;
-                                a.records[row].average = av;
-                            }
-                        }
-                    }
-                    if (a.tile_out != nullptr && (wave == 9 || wave == 12)) {
-                        int tile_cols = a.tile_cols, tile_first = a.tile_first;
-                        asm volatile("" : "+s"(tile_cols), "+s"(tile_first));
-                        const int half = ((tile_cols + 127) >> 7) << 6;            // first wave's share, whole 64s
-                        const int c0 = wave == 9 ? 0 : half;
-                        const int c1 = wave == 9 ? (half < tile_cols ? half : tile_cols) : tile_cols;
-                        float *dst = a.tile_out + row * (int64_t)tile_cols;
-                        for (int c = c0 + lane; c < c1; c += 64) dst[c] = img(tile_first + c);
-                    }
-                }
-                // the legs the last level did not request
-#pragma unroll
-                for (int k = 2 * PIPE_J; k < H; ++k)
-                    S::load_pair(rs_next, po, k * (N / R0) * S::BYTES, v[k], v[H + k]);
-            } else {
-                tw_butterflies<P, PL::R2>(v, tw2);
-            }
+            tw_butterflies<P, PL::R2>(v, tw2);
             stamp(6);                               // twiddles + butterflies 2
+
         }
         // ---- stage 3
         if constexpr (PL::R3 > 1) {
@@ -1206,19 +1317,6 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             load_row(make_rsrc(iq + (a.first_row + (has_next ? next : row)) * (int64_t)a.hop * S::BYTES,
                                has_next ? N * S::BYTES : 0));
             if constexpr (!RESW) load_window(make_rsrc(win_tab, has_next ? N * 4 : 0), cE{}, cN{});
-            st_acc[9] += 1;
-            if (!has_next) break;
-            row = next;
-            continue;
-        }
-        if constexpr (PIPE) {
-            stamp(8);
-            // The rest of the next row's window coefficients: behind the scan, whose two waves need the registers
-            // (inside the last butterfly level they do not fit the 128 VGPRs either); they have half a window stage
-            // to land.  Zero-sized descriptor after the last row.
-            if constexpr (!RESW) load_window(make_rsrc(win_tab, has_next ? N * 4 : 0), cE{}, cN{});
-            prev_out = a.rows_out + row * a.row_stride;
-            prev_bytes = N * 4;
             st_acc[9] += 1;
             if (!has_next) break;
             row = next;
@@ -1457,9 +1555,9 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void scan_kernel(ScanArgs a)
     __shared__ __attribute__((aligned(16))) unsigned hist[SCAN_WAVES][256];
     unsigned *h = hist[threadIdx.x >> 6];
     const bool cached = a.noise_width <= 64 * SCAN_E;
-    const float noise = cached ? scan_noise<true>(src, a.low_noise, a.noise_width, h, lane)
-                               : scan_noise<false>(src, a.low_noise, a.noise_width, h, lane);
-    const int peak = scan_peak<true>(src, a.low_detect, a.detect_width, lane);
+    const float noise = cached ? scan_noise<SCAN_E>(src, a.low_noise, a.noise_width, h, lane)
+                               : scan_noise<0>(src, a.low_noise, a.noise_width, h, lane);
+    const int peak = scan_peak<SCAN_E>(src, a.low_detect, a.detect_width, lane);
     const float avg = scan_average(src, a.low_detect + peak - a.avg_bins / 2, a.avg_bins, a.bins, lane);
     if (lane == 0) {
         ro_scan_record_t rec;
