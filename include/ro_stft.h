@@ -32,7 +32,7 @@ extern "C" {
 #define RO_ERR_NOMEM       (-4)
 #define RO_ERR_STATE       (-5)   /* call not valid in the handle's current state */
 
-#define RO_ABI_VERSION 1
+#define RO_ABI_VERSION 2
 
 /* window function; the reference hard-codes the 4-term Nuttall
  * (src/FFTBackend.cpp:165-184) and keeps Hann as dead code (:157-163). */
@@ -45,6 +45,15 @@ enum { RO_WINDOW_NUTTALL = 0, RO_WINDOW_HANN = 1, RO_WINDOW_CUSTOM = 2 };
  *       host-side only, narrowed to float32 while staging (lossless for every
  *       frontend the reference has: int16 WAV, float32 raw/JACK). */
 enum { RO_IQ_F32 = 0, RO_IQ_I16 = 1, RO_IQ_F64 = 2 };
+
+/* arithmetic of the transform.
+ *  F32: float32 butterflies on float32 samples -- the fast path; rows within 1e-5 of the ROW MAXIMUM of the
+ *       reference's double-precision rows (measured 1-3e-7), which is the norm-wise reading of "1e-5 relative".
+ *  F64: the reference's own arithmetic type -- double window multiply, double transform, double sqrt, one
+ *       narrowing to the float row (src/FFTBackend.cpp:117-120,229-236, src/WaterfallBackend.cpp:492-505) -- as a
+ *       multi-pass transform through HBM scratch.  Rows within 1e-5 of the reference PER BIN (measured ~1e-12 at
+ *       60 dB of dynamic range); several times slower.  Complex-spectra output is F32 only. */
+enum { RO_PRECISION_F32 = 0, RO_PRECISION_F64 = 1 };
 
 /* bin ranges of BolidRecorder::start (src/BolidRecorder.cpp:84-102), in
  * fft-shifted row columns. */
@@ -86,6 +95,9 @@ typedef struct ro_stft_config {
                                    /* CU's registers, so nothing else runs beside    */
                                    /* them; 1 lets a concurrent kernel on another    */
                                    /* stream (an RCCL collective) make progress.     */
+    int32_t      precision;        /* RO_PRECISION_* (ABI 2; a caller that passes the */
+                                   /* ABI-1 struct_size gets RO_PRECISION_F32)        */
+    int32_t      reserved0;        /* must be 0 (keeps the struct free of padding)   */
 } ro_stft_config_t;
 
 typedef struct ro_stft ro_stft_t;

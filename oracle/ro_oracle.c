@@ -10,6 +10,7 @@
  */
 #include "ro_oracle.h"
 
+#include <dlfcn.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -178,8 +179,109 @@ static const fft_plan_t *get_plan(int n)
     return p;
 }
 
+/* ---- optional engine: the reference's own FFT library, when the host has it.
+ * src/FFTBackend.cpp:117-120 plans fftw_plan_dft_1d(bins, in_, out_, FFTW_FORWARD, FFTW_ESTIMATE) on fftw_malloc'ed
+ * arrays and calls fftw_execute per row (:236).  libfftw3 is not vendored with the reference and not installed in
+ * this image; ro_oracle_use_fftw() dlopens libfftw3.so.3 if the box running the CPU baseline happens to have it and
+ * from then on ro_oracle_fft_f64 executes through it (new-array execute on buffers from ro_oracle_fft_alloc, which
+ * are fftw_malloc'ed like the plan's own).  Never required: without the library everything stays on the radix-2
+ * transform below, and the two agree to ~1e-15 |x| (tests/test_oracle.py checks that when the library is present). */
+typedef void *(*fftw_plan_fn)(int, void *, void *, int, unsigned);
+typedef void (*fftw_exec_fn)(void *, void *, void *);
+typedef void *(*fftw_malloc_fn)(size_t);
+typedef void (*fftw_free_fn)(void *);
+static struct {
+    void *handle;
+    fftw_plan_fn plan_dft_1d;
+    fftw_exec_fn execute_dft;
+    fftw_malloc_fn malloc_;
+    fftw_free_fn free_;
+    int on;
+    int engine;              /* 1 = libfftw3, 2 = MKL's FFTW3 interface */
+    int n[MAX_PLANS];
+    void *plan[MAX_PLANS];
+    int count;
+} g_fftw;
+
+int ro_oracle_use_fftw(int on)
+{
+    if (!on) { g_fftw.on = 0; return 0; }
+    if (!g_fftw.handle) {
+        void *h = dlopen("libfftw3.so.3", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libfftw3.so", RTLD_NOW | RTLD_LOCAL);
+        g_fftw.engine = 1;
+        if (!h) {
+            /* second choice: a vendor FFT behind the same fftw3 API (MKL's FFTW3 interface lives in libmkl_rt); not
+             * the reference's library, but the API and plan flags are the reference's call sites verbatim.  One
+             * thread per call: the baseline's threads are the bench's own. */
+            static const char *mkl[] = {"libmkl_rt.so.2", "libmkl_rt.so.1", "libmkl_rt.so", "/opt/conda/lib/libmkl_rt.so.2",
+                                        "/opt/conda/lib/libmkl_rt.so.1", "/opt/conda/lib/libmkl_rt.so"};
+            for (size_t i = 0; i < sizeof(mkl) / sizeof(mkl[0]) && !h; i++) h = dlopen(mkl[i], RTLD_NOW | RTLD_LOCAL);
+            g_fftw.engine = 2;
+            if (h) {
+                void (*set_threads)(int) = (void (*)(int))dlsym(h, "MKL_Set_Num_Threads");
+                if (set_threads) set_threads(1);
+            }
+        }
+        if (!h) { g_fftw.engine = 0; return 0; }
+        g_fftw.plan_dft_1d = (fftw_plan_fn)dlsym(h, "fftw_plan_dft_1d");
+        g_fftw.execute_dft = (fftw_exec_fn)dlsym(h, "fftw_execute_dft");
+        g_fftw.malloc_ = (fftw_malloc_fn)dlsym(h, "fftw_malloc");
+        g_fftw.free_ = (fftw_free_fn)dlsym(h, "fftw_free");
+        if (!g_fftw.plan_dft_1d || !g_fftw.execute_dft || !g_fftw.malloc_ || !g_fftw.free_) { dlclose(h); g_fftw.engine = 0; return 0; }
+        g_fftw.handle = h;
+    }
+    g_fftw.on = 1;
+    return 1;
+}
+
+int ro_oracle_fftw_active(void) { return g_fftw.on ? g_fftw.engine : 0; }
+
+/* plan for `bins` (FFTW_FORWARD = -1, FFTW_ESTIMATE = 1 << 6); call once per size before threads share it */
+int ro_oracle_fft_prepare(int bins)
+{
+    if (!g_fftw.on) return get_plan(bins) ? 0 : -1;
+    for (int i = 0; i < g_fftw.count; i++)
+        if (g_fftw.n[i] == bins) return 0;
+    if (g_fftw.count >= MAX_PLANS) return -1;
+    void *a = g_fftw.malloc_(sizeof(double) * 2 * (size_t)bins), *b = g_fftw.malloc_(sizeof(double) * 2 * (size_t)bins);
+    if (!a || !b) return -1;
+    void *pl = g_fftw.plan_dft_1d(bins, a, b, -1, 1u << 6);
+    g_fftw.free_(a);
+    g_fftw.free_(b);
+    if (!pl) return -1;
+    g_fftw.n[g_fftw.count] = bins;
+    g_fftw.plan[g_fftw.count] = pl;
+    g_fftw.count++;
+    return 0;
+}
+
+/* scratch for ro_oracle_fft_f64: aligned the way the active engine wants it */
+static void *fft_alloc(size_t bytes) { return g_fftw.on ? g_fftw.malloc_(bytes) : malloc(bytes); }
+static void fft_free(void *p) { if (g_fftw.on) g_fftw.free_(p); else free(p); }
+
 int ro_oracle_fft_f64(int bins, const double *in, double *out)
 {
+    if (g_fftw.on) {
+        if (ro_oracle_fft_prepare(bins) != 0) return -1;
+        for (int i = 0; i < g_fftw.count; i++)
+            if (g_fftw.n[i] == bins) {
+                /* fftw_execute_dft wants the alignment of the planning arrays: callers inside this file pass
+                 * fft_alloc'ed buffers; anything else is copied through aligned scratch */
+                if ((((uintptr_t)in | (uintptr_t)out) & 63) == 0) {
+                    g_fftw.execute_dft(g_fftw.plan[i], (void *)in, out);
+                } else {
+                    double *a = (double *)g_fftw.malloc_(sizeof(double) * 4 * (size_t)bins);
+                    if (!a) return -2;
+                    memcpy(a, in, sizeof(double) * 2 * (size_t)bins);
+                    g_fftw.execute_dft(g_fftw.plan[i], a, a + 2 * (size_t)bins);
+                    memcpy(out, a + 2 * (size_t)bins, sizeof(double) * 2 * (size_t)bins);
+                    g_fftw.free_(a);
+                }
+                return 0;
+            }
+        return -1;
+    }
     const fft_plan_t *p = get_plan(bins);
     if (!p) return -1;
     const int n = bins;
@@ -255,7 +357,7 @@ static int row_from_window(int bins, const double *win /* gain already applied *
 int ro_oracle_row(int bins, const double *iq, const float *w, double gain,
                   float *row, double *spectrum)
 {
-    double *buf = (double *)malloc(sizeof(double) * 6 * (size_t)bins);
+    double *buf = (double *)fft_alloc(sizeof(double) * 6 * (size_t)bins);
     if (!buf) return -2;
     double *win = buf, *in = buf + 2 * (size_t)bins, *out = buf + 4 * (size_t)bins;
     for (int i = 0; i < bins; i++) {
@@ -263,7 +365,7 @@ int ro_oracle_row(int bins, const double *iq, const float *w, double gain,
         win[2 * i + 1] = iq[2 * i + 1] + gain;
     }
     int rc = row_from_window(bins, win, w, row, spectrum, in, out);
-    free(buf);
+    fft_free(buf);
     return rc;
 }
 
@@ -278,7 +380,7 @@ int64_t ro_oracle_stft(const double *iq, int64_t samples, int bins, int overlap,
     int64_t count = total - first_row;
     if (count < 0) count = 0;
     if (count > max_rows) count = max_rows;
-    double *buf = (double *)malloc(sizeof(double) * 6 * (size_t)bins);
+    double *buf = (double *)fft_alloc(sizeof(double) * 6 * (size_t)bins);
     if (!buf) return -2;
     double *win = buf, *in = buf + 2 * (size_t)bins, *out = buf + 4 * (size_t)bins;
     for (int64_t r = 0; r < count; r++) {
@@ -288,11 +390,11 @@ int64_t ro_oracle_stft(const double *iq, int64_t samples, int bins, int overlap,
             win[2 * i + 1] = src[2 * i + 1] + gain;
         }
         if (row_from_window(bins, win, w, rows + r * (int64_t)bins, NULL, in, out) != 0) {
-            free(buf);
+            fft_free(buf);
             return -1;
         }
     }
-    free(buf);
+    fft_free(buf);
     return count;
 }
 
@@ -307,7 +409,7 @@ int64_t ro_oracle_stft_f32(const float *iq, int64_t samples, int bins, int overl
     int64_t count = total - first_row;
     if (count < 0) count = 0;
     if (count > max_rows) count = max_rows;
-    double *buf = (double *)malloc(sizeof(double) * 6 * (size_t)bins);
+    double *buf = (double *)fft_alloc(sizeof(double) * 6 * (size_t)bins);
     if (!buf) return -2;
     double *win = buf, *in = buf + 2 * (size_t)bins, *out = buf + 4 * (size_t)bins;
     for (int64_t r = 0; r < count; r++) {
@@ -318,11 +420,11 @@ int64_t ro_oracle_stft_f32(const float *iq, int64_t samples, int bins, int overl
             win[2 * i + 1] = (double)src[2 * i + 1] + gain;
         }
         if (row_from_window(bins, win, w, rows + r * (int64_t)bins, NULL, in, out) != 0) {
-            free(buf);
+            fft_free(buf);
             return -1;
         }
     }
-    free(buf);
+    fft_free(buf);
     return count;
 }
 

@@ -48,6 +48,14 @@ int64_t ro_oracle_row_count(int64_t samples, int bins, int overlap);
 /* ---- forward unnormalised FP64 DFT (stand-in for fftw_execute, src/FFTBackend.cpp:120,236).
  * in/out interleaved (re,im); bins must be a power of two. Returns 0 on success. */
 int ro_oracle_fft_f64(int bins, const double *in, double *out);
+/* Optional engine behind ro_oracle_fft_f64: libfftw3 itself (what src/FFTBackend.cpp:117-120,236 calls), dlopen'ed when
+ * the host has libfftw3.so.3; failing that, a vendor FFT that implements the same fftw3 API (MKL's FFTW3 interface).
+ * ro_oracle_use_fftw(1) returns 1 if such an engine is now active, 0 if none was found.
+ * ro_oracle_fftw_active(): 0 = the built-in radix-2 transform, 1 = libfftw3, 2 = MKL through its FFTW3 interface. */
+int ro_oracle_use_fftw(int on);
+int ro_oracle_fftw_active(void);
+/* build the plan / tables of one size up front (needed before several threads transform that size) */
+int ro_oracle_fft_prepare(int bins);
 /* O(N^2) direct DFT in long double, for checking the FFT on small sizes. */
 void ro_oracle_dft_direct(int bins, const double *in, double *out);
 

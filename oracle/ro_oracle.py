@@ -80,6 +80,9 @@ def lib():
         "ro_oracle_window_hann": (None, [C.c_int, f32p]),
         "ro_oracle_row_count": (i64, [i64, C.c_int, C.c_int]),
         "ro_oracle_fft_f64": (C.c_int, [C.c_int, f64p, f64p]),
+        "ro_oracle_use_fftw": (C.c_int, [C.c_int]),
+        "ro_oracle_fftw_active": (C.c_int, []),
+        "ro_oracle_fft_prepare": (C.c_int, [C.c_int]),
         "ro_oracle_dft_direct": (None, [C.c_int, f64p, f64p]),
         "ro_oracle_row": (C.c_int, [C.c_int, f64p, f32p, C.c_double, f32p, f64p]),
         "ro_oracle_stft": (i64, [f64p, i64, C.c_int, C.c_int, f32p, C.c_double, i64, i64, f32p]),
@@ -138,6 +141,20 @@ def _f64(a):
 
 
 # ---- numpy-level conveniences -------------------------------------------------
+
+def use_fftw(on=True):
+    """Route the FP64 transform through libfftw3 (the reference's FFT) if this host has it; returns whether it is active."""
+    return bool(lib().ro_oracle_use_fftw(1 if on else 0))
+
+
+def fft_engine():
+    """'port' (built-in radix-2), 'libfftw3' or 'mkl-fftw3-interface' -- what ro_oracle_fft_f64 runs on right now"""
+    return {0: "port", 1: "libfftw3", 2: "mkl-fftw3-interface"}[lib().ro_oracle_fftw_active()]
+
+
+def fft_prepare(bins):
+    return lib().ro_oracle_fft_prepare(bins)
+
 
 def window(bins, kind="nuttall"):
     w = np.empty(bins, dtype=np.float32)

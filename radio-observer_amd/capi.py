@@ -13,6 +13,7 @@ from . import build as _build
 
 RO_WINDOW_NUTTALL, RO_WINDOW_HANN, RO_WINDOW_CUSTOM = 0, 1, 2
 RO_IQ_F32, RO_IQ_I16, RO_IQ_F64 = 0, 1, 2
+RO_PRECISION_F32, RO_PRECISION_F64 = 0, 1
 
 RO_OK = 0
 _ERR_NAMES = {-1: "RO_ERR_INVALID", -2: "RO_ERR_UNSUPPORTED", -3: "RO_ERR_HIP", -4: "RO_ERR_NOMEM",
@@ -45,7 +46,8 @@ class Config(C.Structure):
                 ("window_table", C.POINTER(C.c_float)), ("iq_gain", C.c_double),
                 ("iq_phase_shift", C.c_int32), ("device", C.c_int32), ("max_batch_rows", C.c_int32),
                 ("enable_scan", C.c_int32), ("bands", Bands), ("tile_first_col", C.c_int32),
-                ("tile_cols", C.c_int32), ("spare_cus_per_xcd", C.c_int32)]
+                ("tile_cols", C.c_int32), ("spare_cus_per_xcd", C.c_int32), ("precision", C.c_int32),
+                ("reserved0", C.c_int32)]
 
 
 _EXPORTS = {
@@ -216,7 +218,7 @@ class Stft:
 
     def __init__(self, bins=32768, overlap=0, sample_rate=48000, window=RO_WINDOW_NUTTALL,
                  window_table=None, iq_gain=0.0, iq_phase_shift=0, device=0, max_batch_rows=0,
-                 bands=None, tile=None, spare_cus_per_xcd=0):
+                 bands=None, tile=None, spare_cus_per_xcd=0, precision=RO_PRECISION_F32):
         cfg = Config()
         cfg.struct_size = C.sizeof(Config)
         cfg.bins, cfg.overlap, cfg.sample_rate = bins, overlap, sample_rate
@@ -238,6 +240,7 @@ class Stft:
         if tile is not None:
             cfg.tile_first_col, cfg.tile_cols = tile
         cfg.spare_cus_per_xcd = spare_cus_per_xcd
+        cfg.precision = precision
         self._h = C.c_void_p()
         _check(library().ro_stft_create(C.byref(cfg), C.byref(self._h)))
         self.bins = bins

@@ -86,6 +86,25 @@ struct BigArgs {
     int           ns;          // product of the radices of earlier passes
     float         gain;
 };
+// ---- strict precision (RO_PRECISION_F64): the same multi-pass recurrence in double, any supported size
+struct BigArgsD {
+    const void    *iq;         // FIRST pass: sample 0 of the stream
+    const float   *window;     // FIRST pass (float32 coefficients, widened like src/FFTBackend.cpp:229-232)
+    const double2 *tw;         // exp(-2 pi i m / N), m in [0, N), correctly rounded doubles
+    const double2 *in;         // middle / last passes: [rows][N]
+    double2       *out;        // first / middle passes: [rows][N]
+    float         *rows_out;   // LAST pass: [rows][row_stride]
+    int64_t        first_row;
+    int64_t        rows;
+    int64_t        row_stride;
+    int            hop;
+    int            n;
+    int            ns;
+    double         gain;
+};
+int        f64_radices(int bins, int radices[8]); // passes of the FP64 path for a power of two 256 .. 2^20 (0 = unsupported)
+hipError_t launch_f64_pass(int radix, bool first, bool last, int fmt, const BigArgsD &a, hipStream_t s);
+
 bool       big_supported(int bins);               // power of two in (32768, 2^20]
 int        big_radices(int bins, int radices[8]); // number of passes
 hipError_t launch_big_pass(int radix, bool first, bool last, int fmt, const BigArgs &a, hipStream_t s);

@@ -1466,6 +1466,114 @@ __global__ __launch_bounds__(256) void big_pass_kernel(BigArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// Strict precision (ro_stft_config_t::precision = RO_PRECISION_F64): the reference's arithmetic type.  FFTBackend
+// multiplies double samples by the float window in double (src/FFTBackend.cpp:229-232), runs FFTW's double transform
+// (:117-120, :236) and takes sqrt(re^2 + im^2) in double before narrowing to the float row
+// (src/WaterfallBackend.cpp:492-505).  A row of doubles (512 KiB at N = 32768) does not fit a CU's registers, so this
+// mode runs the multi-pass recurrence of big_pass_kernel for EVERY size, in double: radix-16 passes (the last one 2..16)
+// over two complex-double scratch blocks in HBM, twiddles from one correctly rounded exp(-2 pi i m/N) table, the
+// butterflies' own constants in double.  Bound: HBM at 32 B per point and pass; never the benchmarked shape.  Its
+// rows agree with the oracle's FP64 radix-2 transform to a few 1e-16 of the row maximum, i.e. per bin to ~1e-12 at
+// 60 dB of dynamic range -- the per-bin reading of "1e-5 relative" that fp32 butterflies cannot meet.
+// ---------------------------------------------------------------------------
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2d cmul_d(v2d a, v2d w) { return (v2d){a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
+
+// exp(-2 pi i M / 16) for M = 0..7 (the rest by symmetry inside dif_d)
+template <int M> __device__ __forceinline__ v2d mul_w16_d(v2d d)
+{
+    constexpr double C1 = 0.92387953251128675613, C2 = 0.70710678118654752440, C3 = 0.38268343236508977173;
+    if constexpr (M == 0) return d;
+    else if constexpr (M == 4) return (v2d){d.y, -d.x};                       // * (-i)
+    else {
+        constexpr double c = (M == 1) ? C1 : (M == 2) ? C2 : (M == 3) ? C3 : (M == 5) ? -C3 : (M == 6) ? -C2 : -C1;
+        constexpr double sn = (M == 1) ? C3 : (M == 2) ? C2 : (M == 3) ? C1 : (M == 5) ? C1 : (M == 6) ? C2 : C3;
+        return (v2d){d.x * c + d.y * sn, d.y * c - d.x * sn};                 // d * (c - i sn)
+    }
+}
+
+// in-place decimation-in-frequency DFT of R points (R in {2,4,8,16}); result k sits at v[bitrev_R(k)]
+template <int R> __device__ __forceinline__ void dif_d(v2d *v)
+{
+    if constexpr (R >= 2) {
+#pragma unroll
+        for (int i = 0; i < R / 2; ++i) {
+            const v2d a = v[i], b = v[i + R / 2];
+            v[i] = a + b;
+            const v2d d = a - b;
+            // twiddle W_R^i = W_16^(i * 16 / R)
+            switch (i * (16 / R)) {
+            case 0: v[i + R / 2] = d; break;
+            case 1: v[i + R / 2] = mul_w16_d<1>(d); break;
+            case 2: v[i + R / 2] = mul_w16_d<2>(d); break;
+            case 3: v[i + R / 2] = mul_w16_d<3>(d); break;
+            case 4: v[i + R / 2] = mul_w16_d<4>(d); break;
+            case 5: v[i + R / 2] = mul_w16_d<5>(d); break;
+            case 6: v[i + R / 2] = mul_w16_d<6>(d); break;
+            default: v[i + R / 2] = mul_w16_d<7>(d); break;
+            }
+        }
+        dif_d<R / 2>(v);
+        dif_d<R / 2>(v + R / 2);
+    }
+}
+
+template <int R, bool FIRST, bool LAST, int FMT>
+__global__ __launch_bounds__(256) void f64_pass_kernel(BigArgsD a)
+{
+    const int per_row = a.n / R;                                  // butterflies per row
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = g / per_row;
+    if (row >= a.rows) return;
+    const int j = (int)(g - row * per_row);
+    v2d v[R];
+    if constexpr (FIRST) {
+        using S = Sample<FMT>;
+        const int64_t s0 = (a.first_row + row) * (int64_t)a.hop;
+        const __amdgpu_buffer_rsrc_t rs =
+            make_rsrc(reinterpret_cast<const char *>(a.iq) + s0 * S::BYTES, (unsigned)a.n * S::BYTES);
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int n = j + k * per_row;
+            const double w = (double)a.window[n];
+            const v2f x = S::load(rs, n * S::BYTES, 0);
+            v[k] = (v2d){(double)x.x * w, ((double)x.y + a.gain) * w};       // src/FFTBackend.cpp:78-79, :229-232
+        }
+    } else {
+        const double2 *in = a.in + row * (int64_t)a.n;
+        const int kk = j & (a.ns - 1);
+        const int step = a.n / (a.ns * R);
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const double2 x = in[j + k * per_row];
+            v[k] = (v2d){x.x, x.y};
+            if (k > 0) {
+                const double2 t = a.tw[(int64_t)k * kk * step];
+                v[k] = cmul_d(v[k], (v2d){t.x, t.y});
+            }
+        }
+    }
+    dif_d<R>(v);
+    const int j0 = (j / a.ns) * (a.ns * R) + (j & (a.ns - 1));
+    if constexpr (LAST) {
+        float *out = a.rows_out + row * a.row_stride;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const v2d x = v[bitrev<R>(k)];
+            out[(j0 + k * a.ns + a.n / 2) & (a.n - 1)] = (float)sqrt(x.x * x.x + x.y * x.y);   // WaterfallBackend.cpp:492-505
+        }
+    } else {
+        double2 *out = a.out + row * (int64_t)a.n;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const v2d x = v[bitrev<R>(k)];
+            out[j0 + k * a.ns] = make_double2(x.x, x.y);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // band tile: compact copy of columns [first, first+cols) of every row (what the FITS
 // writer keeps, src/WaterfallBackend.cpp:176,204) -- the unit the multi-GPU gather moves.
 // ---------------------------------------------------------------------------
@@ -1835,6 +1943,51 @@ hipError_t launch_big_pass(int radix, bool first, bool last, int fmt, const BigA
         case 4:  return launch_big<4, false, true, RO_FMT_F32>(a, s);
         case 8:  return launch_big<8, false, true, RO_FMT_F32>(a, s);
         case 16: return launch_big<16, false, true, RO_FMT_F32>(a, s);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+int f64_radices(int bins, int radices[8])
+{
+    if (bins < 256 || bins > (1 << 20) || (bins & (bins - 1)) != 0) return 0;
+    int l = 0;
+    while ((1 << l) < bins) ++l;
+    int n = 0;
+    while (l >= 8 || l == 4) {              // radix 16 while the remainder still leaves a last pass of >= 2 ... 16
+        radices[n++] = 16;
+        l -= 4;
+    }
+    if (l > 4) {                            // 5..7 bits left: 16 then 2, 4 or 8
+        radices[n++] = 16;
+        l -= 4;
+    }
+    if (l > 0) radices[n++] = 1 << l;
+    return n;
+}
+
+template <int R, bool FIRST, bool LAST, int FMT> static hipError_t launch_f64(const BigArgsD &a, hipStream_t s)
+{
+    const int64_t total = a.rows * (int64_t)(a.n / R);
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffff) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((f64_pass_kernel<R, FIRST, LAST, FMT>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_f64_pass(int radix, bool first, bool last, int fmt, const BigArgsD &a, hipStream_t s)
+{
+    if (a.rows <= 0) return hipSuccess;
+    if (first && !last && radix == 16)
+        return fmt == RO_FMT_I16 ? launch_f64<16, true, false, RO_FMT_I16>(a, s)
+                                 : launch_f64<16, true, false, RO_FMT_F32>(a, s);
+    if (!first && !last && radix == 16) return launch_f64<16, false, false, RO_FMT_F32>(a, s);
+    if (!first && last) {
+        switch (radix) {
+        case 2:  return launch_f64<2, false, true, RO_FMT_F32>(a, s);
+        case 4:  return launch_f64<4, false, true, RO_FMT_F32>(a, s);
+        case 8:  return launch_f64<8, false, true, RO_FMT_F32>(a, s);
+        case 16: return launch_f64<16, false, true, RO_FMT_F32>(a, s);
         }
     }
     return hipErrorInvalidValue;

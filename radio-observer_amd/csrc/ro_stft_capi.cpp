@@ -96,6 +96,18 @@ std::vector<float2> build_full_twiddles(int bins)
     return tw;
 }
 
+// the same table in double, correctly rounded from long double (strict-precision path)
+std::vector<double2> build_full_twiddles_f64(int bins)
+{
+    std::vector<double2> tw((size_t)bins);
+    const long double two_pi = 8.0L * atanl(1.0L);
+    for (int m = 0; m < bins; ++m) {
+        const long double ang = -two_pi * (long double)m / (long double)bins;
+        tw[(size_t)m] = make_double2((double)cosl(ang), (double)sinl(ang));
+    }
+    return tw;
+}
+
 // One launch worth of finished rows on their way to the caller.  The buffers are pinned host
 // memory (hipHostMalloc) recycled through a free list; `done` fires when the device-to-host
 // copies have landed, so ro_stft_push never waits for the GPU -- only ro_stft_fetch does.
@@ -151,6 +163,12 @@ struct ro_stft {
     unsigned *d_ln_keys = nullptr;     // min / max keys of ro_stft_ln_tile_resident
     float2 *d_scratch[2] = {nullptr, nullptr};
     int64_t scratch_rows = 0;
+
+    // strict precision (RO_PRECISION_F64): double twiddle table + two complex-double scratch blocks
+    bool     f64 = false;
+    double2 *d_tw_f64 = nullptr;
+    double2 *d_scratch_d[2] = {nullptr, nullptr};
+    int64_t  scratch_rows_d = 0;
 };
 
 namespace {
@@ -212,7 +230,7 @@ ro::StftArgs make_stft_args(const ro_stft *h, const void *d_iq, int64_t first_ro
     a.stamps = h->d_stamps;
     a.spare_cus = h->cfg.spare_cus_per_xcd;
     // plans with a fused epilogue scan / tile take them here; for the others the caller launches the separate kernels
-    if (ro::stft_fuses_scan(h->bins)) {
+    if (!h->f64 && ro::stft_fuses_scan(h->bins)) {
         a.records = d_records;
         a.low_noise = h->cfg.bands.low_noise;
         a.noise_width = h->cfg.bands.noise_width;
@@ -266,15 +284,53 @@ int launch_transform(ro_stft *h, const void *d_iq, int format, int64_t first_row
 int launch_tile_and_scan(ro_stft *h, const float *d_rows, int64_t row_stride, int64_t rows, float *d_tile,
                          ro_scan_record_t *d_records, hipStream_t s)
 {
-    if (ro::stft_fuses_scan(h->bins)) return RO_OK;                 // already written by the transform
+    if (!h->f64 && ro::stft_fuses_scan(h->bins)) return RO_OK;      // already written by the transform
     if (d_tile) HIP_TRY(ro::launch_tile(make_tile_args(h, d_rows, row_stride, rows, d_tile), s));
     if (d_records) HIP_TRY(ro::launch_scan(make_scan_args(h, d_rows, row_stride, rows, d_records), s));
+    return RO_OK;
+}
+
+// RO_PRECISION_F64: every size as radix-16 passes in double through HBM scratch, in chunks that fit it
+int launch_transform_f64(ro_stft *h, const void *d_iq, int format, int64_t first_row, int64_t rows, float *d_rows,
+                         int64_t row_stride, hipStream_t s)
+{
+    if (!h->d_scratch_d[0]) {
+        h->scratch_rows_d = std::max<int64_t>(1, ((int64_t)512 << 20) / ((int64_t)h->bins * 16));
+        for (int i = 0; i < 2; ++i)
+            HIP_TRY(hipMalloc(&h->d_scratch_d[i], (size_t)h->scratch_rows_d * h->bins * sizeof(double2)));
+    }
+    int radix[8];
+    const int passes = ro::f64_radices(h->bins, radix);
+    if (passes < 2) return fail(RO_ERR_UNSUPPORTED, "no FP64 pass plan for bins = %d", h->bins);
+    for (int64_t done = 0; done < rows; done += h->scratch_rows_d) {
+        const int64_t n = std::min(h->scratch_rows_d, rows - done);
+        ro::BigArgsD b{};
+        b.iq = d_iq;
+        b.window = h->d_window;
+        b.tw = h->d_tw_f64;
+        b.first_row = first_row + done;
+        b.rows = n;
+        b.row_stride = row_stride;
+        b.hop = h->hop;
+        b.n = h->bins;
+        b.gain = h->cfg.iq_gain;
+        int ns = 1;
+        for (int p = 0; p < passes; ++p) {
+            b.ns = ns;
+            b.in = h->d_scratch_d[(p + 1) & 1];
+            b.out = h->d_scratch_d[p & 1];
+            b.rows_out = d_rows + done * row_stride;
+            HIP_TRY(ro::launch_f64_pass(radix[p], p == 0, p == passes - 1, format, b, s));
+            ns *= radix[p];
+        }
+    }
     return RO_OK;
 }
 
 int launch_transform(ro_stft *h, const void *d_iq, int format, int64_t first_row, int64_t rows, float *d_rows,
                      int64_t row_stride, hipStream_t s, float *d_tile, ro_scan_record_t *d_records)
 {
+    if (h->f64) return launch_transform_f64(h, d_iq, format, first_row, rows, d_rows, row_stride, s);
     if (!h->big) {
         ro::StftArgs a = make_stft_args(h, d_iq, first_row, rows, d_rows, row_stride, d_tile, d_records);
         HIP_TRY(ro::launch_stft(h->bins, format, a, s));
@@ -534,13 +590,24 @@ extern "C" int ro_bins_supported(int bins) { return (ro::stft_supported(bins) ||
 // ---------------------------------------------------------------------------
 // handle
 // ---------------------------------------------------------------------------
-extern "C" int ro_stft_create(const ro_stft_config_t *cfg, ro_stft_t **out)
+extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
 {
-    if (!cfg || !out) return fail(RO_ERR_INVALID, "ro_stft_create: null argument");
+    if (!cfg_in || !out) return fail(RO_ERR_INVALID, "ro_stft_create: null argument");
     *out = nullptr;
-    if (cfg->struct_size != sizeof(ro_stft_config_t))
-        return fail(RO_ERR_INVALID, "ro_stft_create: struct_size %u != %zu", cfg->struct_size,
-                    sizeof(ro_stft_config_t));
+    const ro_stft_config_t *cfg = cfg_in;          // re-pointed at a full-size copy once struct_size is known
+    // ABI growth: fields are only ever appended; a caller built against ABI 1 passes the shorter struct and gets the
+    // defaults (0) for what it does not know
+    const size_t abi1_size = offsetof(ro_stft_config_t, precision);
+    if (cfg->struct_size != sizeof(ro_stft_config_t) && cfg->struct_size != abi1_size)
+        return fail(RO_ERR_INVALID, "ro_stft_create: struct_size %u is neither %zu (ABI 2) nor %zu (ABI 1)",
+                    cfg->struct_size, sizeof(ro_stft_config_t), abi1_size);
+    ro_stft_config_t cfg_full{};
+    std::memcpy(&cfg_full, cfg_in, cfg_in->struct_size);
+    cfg_full.struct_size = sizeof(ro_stft_config_t);
+    cfg = &cfg_full;
+    if (cfg->precision != RO_PRECISION_F32 && cfg->precision != RO_PRECISION_F64)
+        return fail(RO_ERR_INVALID, "unknown precision %d", cfg->precision);
+    if (cfg->reserved0 != 0) return fail(RO_ERR_INVALID, "reserved0 must be 0");
     if (!ro::stft_supported(cfg->bins) && !ro::big_supported(cfg->bins))
         return fail(RO_ERR_UNSUPPORTED, "bins = %d has no kernel (powers of two 256..1048576)", cfg->bins);
     if (cfg->iq_phase_shift != 0)
@@ -592,6 +659,7 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg, ro_stft_t **out)
     else
         build_window(cfg->window_kind, h->bins, h->window.data());
     h->big = ro::big_supported(h->bins);
+    h->f64 = cfg->precision == RO_PRECISION_F64;
     std::vector<float2> tw = h->big ? std::vector<float2>() : build_twiddles(h->bins);
     if (!h->big && (int)tw.size() != ro::stft_twiddle_count(h->bins)) {
         delete h;
@@ -632,6 +700,11 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg, ro_stft_t **out)
         CREATE_TRY(hipMalloc(&h->d_twiddles_k, sizeof(float4) * pk.size()));
         CREATE_TRY(hipMemcpy(h->d_twiddles_k, pk.data(), sizeof(float4) * pk.size(), hipMemcpyHostToDevice));
     }
+    if (h->f64) {
+        std::vector<double2> full = build_full_twiddles_f64(h->bins);
+        CREATE_TRY(hipMalloc(&h->d_tw_f64, sizeof(double2) * full.size()));
+        CREATE_TRY(hipMemcpy(h->d_tw_f64, full.data(), sizeof(double2) * full.size(), hipMemcpyHostToDevice));
+    }
     if (h->big) {
         std::vector<float2> full = build_full_twiddles(h->bins);
         CREATE_TRY(hipMalloc(&h->d_tw_big, sizeof(float2) * full.size()));
@@ -670,6 +743,9 @@ extern "C" int ro_stft_destroy(ro_stft_t *h)
         if (h->h_in_free[i]) (void)hipEventDestroy(h->h_in_free[i]);
     }
     if (h->d_tw_big) (void)hipFree(h->d_tw_big);
+    if (h->d_tw_f64) (void)hipFree(h->d_tw_f64);
+    for (int i = 0; i < 2; ++i)
+        if (h->d_scratch_d[i]) (void)hipFree(h->d_scratch_d[i]);
     for (int i = 0; i < 2; ++i)
         if (h->d_scratch[i]) (void)hipFree(h->d_scratch[i]);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -755,6 +831,7 @@ extern "C" int ro_stft_spectra_resident(ro_stft_t *h, const void *d_iq, int form
     int rc = validate_resident(h, d_iq, format, samples, first_row, rows, d_spectra, stride, nullptr, nullptr);
     if (rc != RO_OK) return rc;
     if (h->big) return fail(RO_ERR_UNSUPPORTED, "complex spectra are available for bins <= 32768");
+    if (h->f64) return fail(RO_ERR_UNSUPPORTED, "complex spectra are float32 only (RO_PRECISION_F32)");
     HIP_TRY(hipSetDevice(h->device));
     ro::StftArgs a = make_stft_args(h, d_iq, first_row, rows, nullptr, 0);
     a.spec_out = reinterpret_cast<float2 *>(d_spectra);

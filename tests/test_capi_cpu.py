@@ -25,7 +25,7 @@ def test_header_symbols_are_exported(ro):
         assert hasattr(lib, n), "libro_stft.so does not export %s" % n
     # and the binding covers exactly the header
     assert sorted(ro.capi.exported_symbols()) == names
-    assert lib.ro_abi_version() == 1
+    assert lib.ro_abi_version() == 2
 
 
 def test_struct_layouts(ro):
@@ -73,7 +73,7 @@ def test_config_is_validated_before_any_device_work(ro):
     """Argument errors come back as RO_ERR_INVALID / RO_ERR_UNSUPPORTED with or without a GPU."""
     for kw, code in ((dict(bins=1000), -2), (dict(bins=1024, iq_phase_shift=1), -2),
                      (dict(bins=1024, sample_rate=0), -1), (dict(bins=1024, spare_cus_per_xcd=17), -1),
-                     (dict(bins=1024, spare_cus_per_xcd=-1), -1)):
+                     (dict(bins=1024, spare_cus_per_xcd=-1), -1), (dict(bins=1024, precision=2), -1)):
         with pytest.raises(ro.StftError) as e:
             ro.Stft(**kw)
         assert e.value.code == code, (kw, str(e.value))
@@ -83,6 +83,13 @@ def test_config_is_validated_before_any_device_work(ro):
     cfg.bins = 1024
     h = C.c_void_p()
     assert ro.library().ro_stft_create(C.byref(cfg), C.byref(h)) == -1
+    # an ABI-1 caller (struct without `precision`) is accepted up to the point where a device is needed
+    cfg.struct_size = ro.capi.Config.precision.offset
+    cfg.sample_rate = 48000
+    rc = ro.library().ro_stft_create(C.byref(cfg), C.byref(h))
+    assert rc in (0, -3), rc                                 # RO_OK on a GPU box, RO_ERR_HIP here
+    if rc == 0:
+        ro.library().ro_stft_destroy(h)
 
 
 def test_no_cpu_fallback(ro):
