@@ -25,6 +25,7 @@ import ctypes
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -62,6 +63,11 @@ def parse():
     p.add_argument("--comm", choices=["nccl", "gloo-host"], default="nccl",
                    help="gloo-host: rehearsal mode for 1-GPU boxes -- every rank uses cuda:0 and the gather is "
                         "staged through host memory over gloo (exercises the N>1 control flow, not xGMI)")
+    p.add_argument("--gather", choices=["all", "root", "none"], default="all",
+                   help="N > 1: what ends a step.  all = all-gather of band tile + scan records (every rank stitches); "
+                        "root = gather to rank 0 only (the rank that writes the FITS files); none = compute only -- so a "
+                        "scaling run can report compute and exchange separately")
+    p.add_argument("--no-strict", action="store_true", help="skip the RO_PRECISION_F64 side measurement")
     p.add_argument("--pmc-traffic", type=float, default=None,
                    help="HBM bytes per launch from a separate rocprofv3 --pmc run (default: profiles/*_traffic.json)")
     return p.parse_args()
@@ -91,13 +97,32 @@ def synth_iq(torch, samples, seed, device):
     return iq
 
 
-def cpu_baseline(iq_host, w, bands, budget_s):
-    """Oracle (oracle/ro_oracle.c, -O2, one thread) on a bounded prefix of the same input."""
+def oracle_module(lib_path=None):
+    """the oracle's ctypes loader; lib_path selects another build of the same source (the -O0 twin)"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import ro_oracle as O
-    O.lib()
+    if lib_path is None:
+        import ro_oracle as O
+        O.lib()
+        return O
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ro_oracle_alt", os.path.join(ROOT, "oracle", "ro_oracle.py"))
+    O = importlib.util.module_from_spec(spec)
+    os.environ["RO_ORACLE_LIB"] = lib_path
+    try:
+        spec.loader.exec_module(O)
+        O.lib()
+    finally:
+        os.environ.pop("RO_ORACLE_LIB", None)
+    return O
+
+
+def cpu_baseline(iq_host, w, bands, budget_s, O=None):
+    """Oracle (oracle/ro_oracle.c, one thread) on a bounded prefix of the same input; the FP64 transform runs on
+    whatever engine the oracle has been switched to (O.fft_engine())."""
+    O = O or oracle_module()
     max_rows = O.row_count(iq_host.shape[0], BINS, OVERLAP)
-    done, chunk = 0, 256
+    O.fft_prepare(BINS)
+    done, chunk = 0, 64
     t0 = time.perf_counter()
     while done < max_rows and time.perf_counter() - t0 < budget_s:
         n = min(chunk, max_rows - done)
@@ -113,9 +138,8 @@ def cpu_baseline_threads(iq_host, w, bands, budget_s, threads):
     """The same oracle on `threads` host threads at once (the C calls release the GIL), every thread walking its own
     interleaved set of 64-row chunks of the same input until the budget is spent."""
     import threading
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import ro_oracle as O
-    O.lib()
+    O = oracle_module()
+    O.fft_prepare(BINS)                                      # plans / tables before the threads share them
     max_rows = O.row_count(iq_host.shape[0], BINS, OVERLAP)
     chunk = 64
     done = [0] * threads
@@ -211,13 +235,22 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def all_gather(out, inp):
-        """RCCL all-gather over xGMI; in rehearsal mode the same exchange through host memory."""
+        """RCCL all-gather over xGMI (or, --gather root, a gather to rank 0); in rehearsal mode the same exchange
+        through host memory."""
         if a.comm == "nccl":
-            dist.all_gather_into_tensor(out, inp)
+            if a.gather == "root":
+                parts = list(out.view((world,) + tuple(inp.shape)).unbind(0)) if rank == 0 else None
+                dist.gather(inp, parts, dst=0)
+            else:
+                dist.all_gather_into_tensor(out, inp)
         else:
             h_in = inp.cpu()
             h_out = torch.empty(out.shape, dtype=out.dtype)
-            dist.all_gather_into_tensor(h_out, h_in)
+            if a.gather == "root":
+                parts = list(h_out.view((world,) + tuple(h_in.shape)).unbind(0)) if rank == 0 else None
+                dist.gather(h_in, parts, dst=0)
+            else:
+                dist.all_gather_into_tensor(h_out, h_in)
             out.copy_(h_out)
 
     ro = importlib.import_module("radio-observer_amd")
@@ -256,6 +289,8 @@ def main():
                 stream.wait_event(comm_done[b])            # tile buffer b is free again
             st.run_resident(iq, ro.RO_IQ_F32, samples, 0, R, rows, d_tile=tiles[b], d_records=recs[b],
                             stream=sptr)
+            if a.gather == "none":
+                return
             ready = torch.cuda.Event()
             ready.record(stream)
             with torch.cuda.stream(comm_stream):
@@ -313,11 +348,17 @@ def main():
                                       round(100.0 * OVERLAP / BINS), a.window.capitalize()),
                        "rows_per_step_per_gpu": R, "samples_per_step_per_gpu": samples,
                        "input": "float32 I/Q resident in HBM", "output": "float32 rows in HBM",
-                       "parallelism": "time-chunk per GPU" + ("; all-gather of band tile [%d,+%d) + scan "
-                                                              "records per step, overlapped" % tile if tile else "")},
+                       "parallelism": "time-chunk per GPU" + (("; %s of band tile [%d,+%d) + scan records per step, "
+                                                               "overlapped with the next step"
+                                                               % (({"all": "all-gather", "root": "gather to rank 0"}[a.gather],)
+                                                                  + tile)) if tile and a.gather != "none" else
+                                                              ("; compute only (--gather none)" if tile else ""))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": a.pmc_traffic if a.pmc_traffic is not None else pmc_traffic(R),
+                         "traffic_source": "--pmc-traffic" if a.pmc_traffic is not None else
+                                           "newest profiles/r*_traffic.json (rocprofv3 --pmc passes of this command; "
+                                           "counters cannot be read from inside the run)",
                          "kernel": "stft_kernel<%d>" % BINS, "kernel_ms": k_stft,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ROW * R,
                          "scan_kernel_ms": k_scan},
@@ -358,23 +399,81 @@ def main():
             out["parity"] = {"rows_checked": pick, "max_err_rel_to_row_max": worst, "tolerance": 1e-5,
                              "scan_records_bit_exact": bool(scan_ok)}
 
-        # ---- CPU baseline (rank 0, N=1 only): the oracle port on the host cores of this box
+        # ---- the strict-precision mode next to the headline (never the headline): same input, fewer rows
+        if world == 1 and not a.no_strict:
+            r64 = min(R, 2048)
+            with ro.Stft(bins=BINS, overlap=OVERLAP, sample_rate=FS, device=local_rank, bands=bands,
+                         window=ro.RO_WINDOW_HANN if a.window == "hann" else ro.RO_WINDOW_NUTTALL,
+                         precision=ro.RO_PRECISION_F64) as st64:
+                ms64, k64, s64 = st64.time_resident(iq, ro.RO_IQ_F32, samples, 0, r64, rows, 5, d_records=recs[1],
+                                                    stream=sptr)
+                torch.cuda.synchronize(dev)
+                entry = {"mode": "RO_PRECISION_F64 (double window multiply, double multi-pass transform through HBM "
+                                 "scratch, double sqrt, one narrowing: the reference's arithmetic type)",
+                         "value": r64 / (float(np.mean(ms64[1:])) * 1e-3), "unit": "rows/s", "rows_per_step": r64,
+                         "ms_per_step": float(np.mean(ms64[1:])), "dtype": "f64"}
+                if not a.no_parity:
+                    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                    import ro_oracle as O
+                    worst = 0.0
+                    for r in (0, r64 - 1):
+                        seg = iq[r * HOP:r * HOP + BINS].cpu().numpy()
+                        want = O.stft(seg, BINS, OVERLAP, w=st64.window)[0].astype(np.float64)
+                        got = rows[r].cpu().numpy().astype(np.float64)
+                        worst = max(worst, float((np.abs(got - want) / np.maximum(want, 1e-300)).max()))
+                    entry["parity"] = {"rows_checked": [0, r64 - 1], "max_err_per_bin_relative": worst,
+                                       "tolerance_per_bin": 1e-5}
+            out["strict_precision"] = entry
+
+        # ---- CPU baseline (rank 0, N=1 only): the oracle port on the host cores of this box.  Its FP64 transform runs
+        # on libfftw3 itself (fftw_plan_dft_1d(..., FFTW_FORWARD, FFTW_ESTIMATE) + fftw_execute, the reference's call
+        # sites: src/FFTBackend.cpp:117-120,236) when this host has libfftw3.so.3, else on a vendor FFT behind the same
+        # fftw3 API (MKL's FFTW3 interface), else on the oracle's own radix-2 transform; `fft_engine` says which.
         if world == 1 and not a.no_cpu_baseline:
             n_cpu = min(R, 32768 if BINS >= 16384 else 262144)
             host = iq[:BINS + HOP * (n_cpu - 1)].cpu().numpy()
-            done, cdt = cpu_baseline(host, st.window, bands, a.cpu_seconds)
-            out["cpu_baseline"] = {"value": done / cdt, "unit": "rows/s", "cores": 1, "kind": "port",
-                                   "sample": "first %d rows of the same input (%.1f s): oracle/ro_oracle.c -O2, "
-                                             "FP64 radix-2 FFT + scan, single thread; %d of the host's %d cores are "
-                                             "available to this process" % (done, cdt, host_cores(), os.cpu_count() or 0)}
+            O = oracle_module()
+            ncores, navail = host_cores(), os.cpu_count() or 0
+            done_p, cdt_p = cpu_baseline(host, st.window, bands, a.cpu_seconds / 3, O)
+            port = {"value": done_p / cdt_p, "unit": "rows/s", "cores": 1, "kind": "port", "fft_engine": "port",
+                    "sample": "first %d rows of the same input (%.1f s): oracle/ro_oracle.c -O2, its own FP64 radix-2 "
+                              "FFT + scan, single thread" % (done_p, cdt_p)}
+            have_lib = O.use_fftw(True)
+            if have_lib:
+                engine = O.fft_engine()
+                done, cdt = cpu_baseline(host, st.window, bands, a.cpu_seconds * 2 / 3, O)
+                out["cpu_baseline"] = {"value": done / cdt, "unit": "rows/s", "cores": 1, "kind": "port",
+                                       "fft_engine": engine,
+                                       "sample": "first %d rows of the same input (%.1f s): oracle/ro_oracle.c -O2 (framing, "
+                                                 "window, magnitude, scan) with the FP64 transform on %s through the fftw3 "
+                                                 "API, FFTW_ESTIMATE plan, single thread; %d of the host's %d cores are "
+                                                 "available to this process" % (done, cdt, engine, ncores, navail)}
+                out["cpu_baseline_port_fft"] = port
+            else:
+                port["sample"] += "; no libfftw3.so.3 and no fftw3-API vendor library on this host; %d of the host's %d " \
+                                  "cores are available to this process" % (ncores, navail)
+                out["cpu_baseline"] = port
             # the upper bound of "what this host could do": one independent slice of the stream per core
-            cores = min(host_cores(), 64)
+            cores = min(ncores, 64)
             if cores > 1:
                 done_n, cdt_n = cpu_baseline_threads(host, st.window, bands, a.cpu_seconds / 2, cores)
                 out["cpu_baseline_all_cores"] = {"value": done_n / cdt_n, "unit": "rows/s", "cores": cores,
-                                                 "kind": "port",
+                                                 "kind": "port", "fft_engine": O.fft_engine(),
                                                  "sample": "%d rows of the same input in %.1f s, one thread per core"
                                                            % (done_n, cdt_n)}
+            O.use_fftw(False)
+            # the reference is built -O0 (Makefile:26-28): the same port compiled that way, radix-2 transform
+            try:
+                subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libro_oracle_O0.so"],
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                O0 = oracle_module(os.path.join(ROOT, "oracle", "libro_oracle_O0.so"))
+                done0, cdt0 = cpu_baseline(host, st.window, bands, min(4.0, a.cpu_seconds / 3), O0)
+                out["cpu_baseline_O0"] = {"value": done0 / cdt0, "unit": "rows/s", "cores": 1, "kind": "port",
+                                          "fft_engine": "port",
+                                          "sample": "first %d rows (%.1f s): the same source compiled -O0 like the "
+                                                    "reference's Makefile:26-28" % (done0, cdt0)}
+            except Exception as e:                                   # no compiler on the box: say so, do not fail the bench
+                out["cpu_baseline_O0"] = {"error": str(e)[:200]}
         print(json.dumps(out), flush=True)
 
     st.close()
