@@ -16,6 +16,7 @@
 #include "ro_fft_device.h"
 
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 // Diagnostic builds only (tools/ablate.sh): -DRO_ABLATE=<bits> removes one phase of the
@@ -1681,58 +1682,76 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void scan_kernel(ScanArgs a)
 // ---------------------------------------------------------------------------
 // Persistent launch: as many workgroups as the device can hold at once (rounded down to a
 // multiple of 8 so every XCD gets the same share), never more than there are rows.
-template <class PL, int FMT, int MODE> static hipError_t launch_plan(const StftArgs &a, hipStream_t s)
+// What a plan's kernel needs per DEVICE before its first launch there: the dynamic-LDS attribute set and its occupancy
+// known.  One entry per device ordinal, filled under a lock (a host may drive several devices and threads through the C
+// ABI's cfg.device; the round-1 version kept these in unsynchronised function-local statics of whichever device
+// launched first).
+struct DevicePlan {
+    bool ready = false;
+    int resident = 0;            // workgroups resident on the device (all CUs)
+    int per_cu = 1;              // ... per CU
+};
+constexpr int MAX_DEVICES = 64;
+
+template <class PL, int FMT, int MODE> static hipError_t device_plan(DevicePlan &out)
 {
-    static int resident = 0;            // workgroups resident on the device (all CUs)
-    static int per_cu_static = 1;       // ... per CU
-    if (resident == 0) {
+    static std::mutex lock;
+    static DevicePlan table[MAX_DEVICES];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> g(lock);
+    DevicePlan &d = table[dev];
+    if (!d.ready) {
         const void *fn = reinterpret_cast<const void *>(&stft_kernel<PL, FMT, MODE>);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, plan_lds_bytes<PL>());
-        if (e != hipSuccess) return e;
-        int dev = 0, cus = 0, per_cu = 0;
-        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, plan_lds_bytes<PL>())) != hipSuccess)
+            return e;
+        int cus = 0, per_cu = 0;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
         if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, PL::T, plan_lds_bytes<PL>())) != hipSuccess)
             return e;
-        if (per_cu < 1) per_cu = 1;
-        per_cu_static = per_cu;
-        resident = cus * per_cu;
+        d.per_cu = per_cu < 1 ? 1 : per_cu;
+        d.resident = cus * d.per_cu;
+        d.ready = true;
     }
+    out = d;
+    return hipSuccess;
+}
+
+#ifdef RO_DIAG_KNOBS
+// experiment knobs of the diagnostic builds (tools/sweep_env.sh): never compiled into the product library
+static int env_knob(const char *name, int unset)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : unset;
+}
+#endif
+
+template <class PL, int FMT, int MODE> static hipError_t launch_plan(const StftArgs &a, hipStream_t s)
+{
+    DevicePlan d;
+    hipError_t e = device_plan<PL, FMT, MODE>(d);
+    if (e != hipSuccess) return e;
     const int64_t per_xcd = (a.rows + 7) / 8;
-    int64_t slots = resident / 8;                       // workgroups per XCD
-    if (a.spare_cus > 0) slots -= (int64_t)a.spare_cus * per_cu_static;
+    int64_t slots = d.resident / 8;                     // workgroups per XCD
+    if (a.spare_cus > 0) slots -= (int64_t)a.spare_cus * d.per_cu;
     if (slots < 1) slots = 1;
     if (slots > per_xcd) slots = per_xcd;
-    {
-        static int cap = -1;                           // experiment knob: RO_SLOTS=<workgroups per XCD>
-        if (cap < 0) {
-            const char *e = getenv("RO_SLOTS");
-            cap = e ? atoi(e) : 0;
-        }
-        if (cap > 0 && slots > cap) slots = cap;
-    }
+#ifdef RO_DIAG_KNOBS
+    if (const int cap = env_knob("RO_SLOTS", 0); cap > 0 && slots > cap) slots = cap;      // workgroups per XCD
+#endif
     const unsigned grid = (unsigned)(slots * 8);
     StftArgs b = a;
     // The touches park hop*BYTES per resident workgroup in the XCD's 4 MiB L2 for most of a row time.  Past half of
     // it they push out the rows being transformed and every line is fetched twice (seen at overlap 0: FETCH_SIZE x2,
     // 19 % slower).  Plans with several workgroups per CU hide the miss behind each other and gain nothing (measured).
     b.prefetch = (plan_addtid<PL>() && slots * (int64_t)a.hop * Sample<FMT>::BYTES <= (2 << 20)) ? 1 : 0;
-    {
-        static int force = -2;                         // experiment knob: RO_PREFETCH=0/1 overrides the rule
-        if (force == -2) {
-            const char *e = getenv("RO_PREFETCH");
-            force = e ? atoi(e) : -1;
-        }
-        if (force >= 0) b.prefetch = force;
-    }
-    {
-        static int stagger = -1;                       // experiment knob: RO_STAGGER=<cycles per slot>
-        if (stagger < 0) {
-            const char *e = getenv("RO_STAGGER");
-            stagger = e ? atoi(e) : 0;
-        }
-        b.stagger = stagger;
-    }
+    b.stagger = 0;
+#ifdef RO_DIAG_KNOBS
+    if (const int force = env_knob("RO_PREFETCH", -1); force >= 0) b.prefetch = force;
+    b.stagger = env_knob("RO_STAGGER", 0);             // start delay per workgroup slot, shader cycles
+#endif
     hipLaunchKernelGGL((stft_kernel<PL, FMT, MODE>), dim3(grid), dim3(PL::T), plan_lds_bytes<PL>(), s, b);
     return hipGetLastError();
 }
