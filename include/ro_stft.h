@@ -221,7 +221,10 @@ int ro_stft_time_resident(ro_stft_t *h, const void *d_iq, int format, int64_t sa
  * ro_stft_fetch  = hand rows to the Recorder side in stream order
  *                  (replaces the synchronous Recorder::update() per row,
  *                  src/WaterfallBackend.cpp:534-536): up to max_rows rows, columns
- *                  [first_col, first_col+cols) of each, plus scan records.
+ *                  [first_col, first_col+cols) of each, plus scan records.  With a tile
+ *                  configured (tile_cols > 0) only the tile's columns travel to the host
+ *                  (what the FITS writer keeps, src/WaterfallBackend.cpp:176,204) and the
+ *                  requested columns must lie inside it.
  *                  *first_row_index = stream index of the first row returned. */
 int ro_stft_push(ro_stft_t *h, const void *iq, int format, int64_t samples, int64_t *rows_ready);
 int ro_stft_flush(ro_stft_t *h, int64_t *rows_ready);
@@ -230,7 +233,19 @@ int ro_stft_fetch(ro_stft_t *h, int64_t max_rows, int first_col, int cols,
                   int64_t *first_row_index, int64_t *rows_got);
 /* FFTBackend::startStream's reset of inMark_/info_ (src/FFTBackend.cpp:148-153) */
 int ro_stft_reset(ro_stft_t *h);
-/* counters in the spirit of FFTBackend::logProcessingTimes (src/FFTBackend.h:208-229) */
+/* Per-call timing, the counterpart of FFTBackend's three RunningAverage2 counters and logProcessingTimes /
+ * clearProcessingTime (src/FFTBackend.h:86-92, :208-235: average and maximum per process() call, per FFT, per
+ * analysis).  push = wall time of one ro_stft_push (the host side of Backend::process); batch = GPU time of the kernels
+ * of one batch (HIP events; window + FFT + magnitude, and the band scan where the plan fuses it), known once the batch
+ * has been fetched; row = the same per row; fetch = wall time of one ro_stft_fetch (includes waiting for the GPU). */
+typedef struct ro_stft_timing {
+    int64_t push_calls;  double push_ms_avg, push_ms_max;
+    int64_t batches;     double batch_gpu_ms_avg, batch_gpu_ms_max;
+    int64_t batch_rows;  double row_gpu_us_avg;
+    int64_t fetch_calls; double fetch_ms_avg, fetch_ms_max;
+} ro_stft_timing_t;
+int ro_stft_timing(ro_stft_t *h, ro_stft_timing_t *out, int reset /* != 0: clear the counters afterwards */);
+/* totals in the spirit of FFTBackend::logProcessingTimes (src/FFTBackend.h:208-229) */
 int ro_stft_stats(const ro_stft_t *h, int64_t *samples_in, int64_t *rows_out,
                   int64_t *launches, double *kernel_ms_total);
 

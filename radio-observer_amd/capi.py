@@ -37,6 +37,14 @@ class ScanRecord(C.Structure):
     _fields_ = [("noise", C.c_float), ("peak", C.c_int32), ("average", C.c_float)]
 
 
+class Timing(C.Structure):
+    """ro_stft_timing_t"""
+    _fields_ = [("push_calls", C.c_int64), ("push_ms_avg", C.c_double), ("push_ms_max", C.c_double),
+                ("batches", C.c_int64), ("batch_gpu_ms_avg", C.c_double), ("batch_gpu_ms_max", C.c_double),
+                ("batch_rows", C.c_int64), ("row_gpu_us_avg", C.c_double),
+                ("fetch_calls", C.c_int64), ("fetch_ms_avg", C.c_double), ("fetch_ms_max", C.c_double)]
+
+
 SCAN_DTYPE = np.dtype([("noise", np.float32), ("peak", np.int32), ("average", np.float32)])
 
 
@@ -91,6 +99,7 @@ _EXPORTS = {
     "ro_stft_fetch": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_float),
                                 C.POINTER(ScanRecord), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ro_stft_reset": (C.c_int, [C.c_void_p]),
+    "ro_stft_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "ro_stft_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                 C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }
@@ -337,8 +346,11 @@ class Stft:
         _check(library().ro_stft_flush(self._h, C.byref(ready)))
         return ready.value
 
-    def fetch(self, max_rows, first_col=0, cols=None, want_records=None):
-        cols = self.bins - first_col if cols is None else cols
+    def fetch(self, max_rows, first_col=None, cols=None, want_records=None):
+        if first_col is None:                        # default: everything this handle brings to the host
+            first_col = self.tile[0] if self.tile else 0
+        if cols is None:
+            cols = (self.tile[0] + self.tile[1] - first_col) if self.tile else self.bins - first_col
         want_records = self.scan_enabled if want_records is None else want_records
         rows = np.empty((max_rows, cols), dtype=np.float32)
         recs = np.empty(max_rows, dtype=SCAN_DTYPE) if want_records else None
@@ -353,6 +365,11 @@ class Stft:
 
     def reset(self):
         _check(library().ro_stft_reset(self._h))
+
+    def timing(self, reset=False):
+        t = Timing()
+        _check(library().ro_stft_timing(self._h, C.byref(t), 1 if reset else 0))
+        return {k: getattr(t, k) for k, _ in Timing._fields_}
 
     def stats(self):
         s, r, l = C.c_int64(), C.c_int64(), C.c_int64()

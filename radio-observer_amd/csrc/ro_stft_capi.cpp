@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <deque>
 #include <string>
 #include <vector>
@@ -137,30 +138,45 @@ struct ro_stft {
     float4 *d_twiddles_k = nullptr;    // packed copy for the radix-16/32 stages
     hipStream_t stream = nullptr;
 
-    // streaming state
+    // streaming state.  Three HIP streams and two slots of device buffers: while the kernels of batch n run on
+    // `stream`, batch n+1 is uploaded on `s_in` and batch n-1 goes home on `s_out`.
     int batch_rows = 0;
-    std::vector<float> staged;                 // interleaved f32 I,Q; samples before staged_begin are spent
+    int stage_fmt = RO_IQ_F32;                 // what `staged` holds: RO_IQ_F32 (8 B per sample) or RO_IQ_I16 (4 B)
+    bool stage_fmt_set = false;
+    std::vector<char> staged;                  // interleaved I,Q in stage_fmt; samples before staged_begin are spent
     size_t  staged_begin = 0;                  // first live sample in `staged`
     int64_t stream_sample0 = 0;                // stream index of the sample at staged_begin
-    float  *h_in[2] = {nullptr, nullptr};      // pinned H2D staging, alternating
-    hipEvent_t h_in_free[2] = {nullptr, nullptr};
+    struct Slot {
+        void  *d_iq = nullptr;                 // batch input  ((batch_rows-1)*hop + bins samples, 8 B each at most)
+        float *d_rows = nullptr;               // batch output (batch_rows x bins)
+        float *d_tile = nullptr;               // batch_rows x tile_cols when a tile is configured
+        ro_scan_record_t *d_records = nullptr;
+        void  *h_in = nullptr;                 // pinned upload staging
+        hipEvent_t uploaded = nullptr;         // H2D of this slot done (h_in reusable, kernels may start)
+        hipEvent_t computed = nullptr;         // kernels of this slot done (d_iq reusable, D2H may start)
+        hipEvent_t drained = nullptr;          // D2H of this slot done (d_rows / d_tile / d_records reusable)
+    } slot[2];
+    bool slots_ready = false;
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    int out_first = 0, out_cols = 0;           // columns of every row that travel to the host (the tile, or all)
     int64_t batch_seq = 0;
     std::vector<Batch *> batch_pool;           // recycled pinned batches
     int64_t rows_emitted = 0;                  // stream index of the next row to compute
-    float *d_iq = nullptr;                     // batch input  ((batch_rows-1)*hop + bins samples)
-    float *d_rows = nullptr;                   // batch output (batch_rows x bins)
-    ro_scan_record_t *d_records = nullptr;
     std::deque<Batch *> ready;
     int64_t rows_ready = 0;
     int64_t stat_samples = 0, stat_rows = 0, stat_launches = 0;
     double stat_kernel_ms = 0.0;
+    // per-call counters in the spirit of FFTBackend's RunningAverage2 trio (src/FFTBackend.h:86-92, :208-235)
+    ro_stft_timing_t timing{};
+    double push_ms_sum = 0.0, batch_ms_sum = 0.0, fetch_ms_sum = 0.0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     unsigned long long *d_stamps = nullptr;    // diagnostic builds (RO_STAMPS) only
 
     // large transforms (bins > 32768): full twiddle table + two complex scratch blocks in HBM
     bool    big = false;
     float2 *d_tw_big = nullptr;
-    unsigned *d_ln_keys = nullptr;     // min / max keys of ro_stft_ln_tile_resident
+    unsigned *d_ln_keys = nullptr;     // 16 pairs of min / max keys of ro_stft_ln_tile_resident, used in turn
+    unsigned ln_calls = 0;
     float2 *d_scratch[2] = {nullptr, nullptr};
     int64_t scratch_rows = 0;
 
@@ -378,7 +394,7 @@ Batch *acquire_batch(ro_stft *h)
     Batch *b = new (std::nothrow) Batch();
     if (!b) return nullptr;
     b->capacity_rows = h->batch_rows;
-    if (hipHostMalloc(reinterpret_cast<void **>(&b->data), (size_t)b->capacity_rows * h->bins * sizeof(float),
+    if (hipHostMalloc(reinterpret_cast<void **>(&b->data), (size_t)b->capacity_rows * h->out_cols * sizeof(float),
                       hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&b->records), (size_t)b->capacity_rows * sizeof(ro_scan_record_t),
                       hipHostMallocDefault) != hipSuccess ||
@@ -386,6 +402,9 @@ Batch *acquire_batch(ro_stft *h)
         hipEventCreate(&b->k0) != hipSuccess || hipEventCreate(&b->k1) != hipSuccess) {
         if (b->data) (void)hipHostFree(b->data);
         if (b->records) (void)hipHostFree(b->records);
+        if (b->done) (void)hipEventDestroy(b->done);
+        if (b->k0) (void)hipEventDestroy(b->k0);
+        if (b->k1) (void)hipEventDestroy(b->k1);
         delete b;
         return nullptr;
     }
@@ -410,38 +429,109 @@ void destroy_batch(Batch *b)
     delete b;
 }
 
-// run one batch of the streaming path: rows [rows_emitted, +rows) from the staged samples.
-// Everything is enqueued on the handle's stream and the call returns; the host only waits when
-// it is about to overwrite a pinned staging buffer whose upload has not finished.
+void free_stream_slots(ro_stft *h)
+{
+    for (auto &sl : h->slot) {
+        if (sl.d_iq) (void)hipFree(sl.d_iq);
+        if (sl.d_rows) (void)hipFree(sl.d_rows);
+        if (sl.d_tile) (void)hipFree(sl.d_tile);
+        if (sl.d_records) (void)hipFree(sl.d_records);
+        if (sl.h_in) (void)hipHostFree(sl.h_in);
+        if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
+        if (sl.computed) (void)hipEventDestroy(sl.computed);
+        if (sl.drained) (void)hipEventDestroy(sl.drained);
+        sl = ro_stft::Slot();
+    }
+    if (h->s_in) (void)hipStreamDestroy(h->s_in);
+    if (h->s_out) (void)hipStreamDestroy(h->s_out);
+    h->s_in = h->s_out = nullptr;
+    h->slots_ready = false;
+}
+
+// streaming buffers, all or nothing: a failure half way frees what was allocated, and the next push tries again
+int ensure_stream_slots(ro_stft *h)
+{
+    if (h->slots_ready) return RO_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t in_samples = (size_t)(h->batch_rows - 1) * h->hop + h->bins;
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
+    ok(hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking)) && ok(hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
+    for (auto &sl : h->slot) {
+        ok(hipMalloc(&sl.d_iq, in_samples * 2 * sizeof(float))) &&
+            ok(hipMalloc(&sl.d_rows, (size_t)h->batch_rows * h->bins * sizeof(float))) &&
+            ok(hipMalloc(&sl.d_records, (size_t)h->batch_rows * sizeof(ro_scan_record_t))) &&
+            ok(hipHostMalloc(&sl.h_in, in_samples * 2 * sizeof(float), hipHostMallocDefault)) &&
+            ok(hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming)) &&
+            ok(hipEventCreateWithFlags(&sl.computed, hipEventDisableTiming)) &&
+            ok(hipEventCreateWithFlags(&sl.drained, hipEventDisableTiming));
+        if (h->cfg.tile_cols > 0)
+            ok(hipMalloc(&sl.d_tile, (size_t)h->batch_rows * h->cfg.tile_cols * sizeof(float)));
+    }
+    if (e != hipSuccess) {
+        free_stream_slots(h);
+        return fail(RO_ERR_HIP, "allocating the streaming buffers failed: %s", hipGetErrorString(e));
+    }
+    h->slots_ready = true;
+    return RO_OK;
+}
+
+size_t stage_sample_bytes(const ro_stft *h) { return h->stage_fmt == RO_IQ_I16 ? 4 : 8; }
+
+// run one batch of the streaming path: rows [rows_emitted, +rows) from the staged samples.  Upload, kernels and
+// download are queued on three streams chained by events and the call returns; the host only waits when it is about
+// to overwrite a pinned staging buffer whose upload has not finished.
 int run_stream_batch(ro_stft *h, int64_t rows)
 {
     if (rows <= 0) return RO_OK;
     HIP_TRY(hipSetDevice(h->device));
+    const size_t sb = stage_sample_bytes(h);
     const int64_t need = (rows - 1) * (int64_t)h->hop + h->bins;       // samples
-    const int slot = (int)(h->batch_seq & 1);
-    HIP_TRY(hipEventSynchronize(h->h_in_free[slot]));                   // upload two batches ago is done
-    std::memcpy(h->h_in[slot], h->staged.data() + h->staged_begin * 2, (size_t)need * 2 * sizeof(float));
-    HIP_TRY(hipMemcpyAsync(h->d_iq, h->h_in[slot], (size_t)need * 2 * sizeof(float), hipMemcpyHostToDevice,
-                           h->stream));
-    HIP_TRY(hipEventRecord(h->h_in_free[slot], h->stream));
+    ro_stft::Slot &sl = h->slot[h->batch_seq & 1];
+    HIP_TRY(hipEventSynchronize(sl.uploaded));                          // the upload two batches ago is done
+    std::memcpy(sl.h_in, h->staged.data() + h->staged_begin * sb, (size_t)need * sb);
     Batch *b = acquire_batch(h);
     if (!b) return fail(RO_ERR_NOMEM, "out of pinned host memory for a row batch");
-    HIP_TRY(hipEventRecord(b->k0, h->stream));
-    {
-        ro_scan_record_t *recs = h->cfg.enable_scan ? h->d_records : nullptr;
-        int rc = launch_transform(h, h->d_iq, RO_IQ_F32, 0, rows, h->d_rows, h->bins, h->stream, nullptr, recs);
-        if (rc == RO_OK) rc = launch_tile_and_scan(h, h->d_rows, h->bins, rows, nullptr, recs, h->stream);
-        if (rc != RO_OK) { release_batch(h, b); return rc; }
+    int rc = RO_OK;
+    auto step = [&](hipError_t e, const char *what) {
+        if (rc == RO_OK && e != hipSuccess) rc = fail(RO_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+        return rc == RO_OK;
+    };
+    // upload (s_in): after the kernels that last read this slot's d_iq
+    step(hipStreamWaitEvent(h->s_in, sl.computed, 0), "hipStreamWaitEvent") &&
+        step(hipMemcpyAsync(sl.d_iq, sl.h_in, (size_t)need * sb, hipMemcpyHostToDevice, h->s_in), "upload") &&
+        step(hipEventRecord(sl.uploaded, h->s_in), "hipEventRecord");
+    // kernels (stream): after the upload, and after the download that last read this slot's outputs
+    step(hipStreamWaitEvent(h->stream, sl.uploaded, 0), "hipStreamWaitEvent") &&
+        step(hipStreamWaitEvent(h->stream, sl.drained, 0), "hipStreamWaitEvent") &&
+        step(hipEventRecord(b->k0, h->stream), "hipEventRecord");
+    if (rc == RO_OK) {
+        ro_scan_record_t *recs = h->cfg.enable_scan ? sl.d_records : nullptr;
+        rc = launch_transform(h, sl.d_iq, h->stage_fmt, 0, rows, sl.d_rows, h->bins, h->stream, sl.d_tile, recs);
+        if (rc == RO_OK) rc = launch_tile_and_scan(h, sl.d_rows, h->bins, rows, sl.d_tile, recs, h->stream);
     }
-    HIP_TRY(hipEventRecord(b->k1, h->stream));
+    step(hipEventRecord(b->k1, h->stream), "hipEventRecord") && step(hipEventRecord(sl.computed, h->stream), "hipEventRecord");
+    // download (s_out): only the columns somebody asked for travel -- the tile when one is configured
+    step(hipStreamWaitEvent(h->s_out, sl.computed, 0), "hipStreamWaitEvent");
+    if (rc == RO_OK) {
+        const float *src = h->cfg.tile_cols > 0 ? sl.d_tile : sl.d_rows;
+        step(hipMemcpyAsync(b->data, src, (size_t)rows * h->out_cols * sizeof(float), hipMemcpyDeviceToHost, h->s_out),
+             "download");
+        if (h->cfg.enable_scan)
+            step(hipMemcpyAsync(b->records, sl.d_records, (size_t)rows * sizeof(ro_scan_record_t), hipMemcpyDeviceToHost,
+                                h->s_out), "download");
+    }
+    step(hipEventRecord(sl.drained, h->s_out), "hipEventRecord") && step(hipEventRecord(b->done, h->s_out), "hipEventRecord");
+    if (rc != RO_OK) {
+        // nothing of this batch is handed out; whatever was queued is allowed to finish before the buffers are reused
+        (void)hipStreamSynchronize(h->s_in);
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamSynchronize(h->s_out);
+        release_batch(h, b);
+        return rc;
+    }
     b->first_row = h->rows_emitted;
     b->rows = rows;
-    HIP_TRY(hipMemcpyAsync(b->data, h->d_rows, (size_t)rows * h->bins * sizeof(float), hipMemcpyDeviceToHost,
-                           h->stream));
-    if (h->cfg.enable_scan)
-        HIP_TRY(hipMemcpyAsync(b->records, h->d_records, (size_t)rows * sizeof(ro_scan_record_t),
-                               hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipEventRecord(b->done, h->stream));
     b->pending = true;
     h->batch_seq += 1;
     h->stat_launches += 1;
@@ -450,8 +540,8 @@ int run_stream_batch(ro_stft *h, int64_t rows)
     // the samples no later row needs are spent: the next row starts rows*hop further on
     const int64_t consumed = rows * (int64_t)h->hop;
     h->staged_begin += (size_t)consumed;
-    if (h->staged_begin * 2 > h->staged.size() / 2 && h->staged_begin > (size_t)h->bins) {   // compact now and then
-        h->staged.erase(h->staged.begin(), h->staged.begin() + h->staged_begin * 2);
+    if (h->staged_begin * sb > h->staged.size() / 2 && h->staged_begin > (size_t)h->bins) {   // compact now and then
+        h->staged.erase(h->staged.begin(), h->staged.begin() + h->staged_begin * sb);
         h->staged_begin = 0;
     }
     h->stream_sample0 += consumed;
@@ -463,9 +553,16 @@ int run_stream_batch(ro_stft *h, int64_t rows)
 
 int64_t staged_complete_rows(const ro_stft *h)
 {
-    const int64_t have = (int64_t)(h->staged.size() / 2 - h->staged_begin);
+    const int64_t have = (int64_t)(h->staged.size() / stage_sample_bytes(h)) - (int64_t)h->staged_begin;
     if (have < h->bins) return 0;
     return (have - h->bins) / h->hop + 1;
+}
+
+double now_ms()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
 }  // namespace
@@ -679,7 +776,7 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
     CREATE_TRY(hipEventCreate(&h->ev0));
     CREATE_TRY(hipEventCreate(&h->ev1));
     CREATE_TRY(hipMalloc(&h->d_window, sizeof(float) * h->bins));
-    CREATE_TRY(hipMalloc(&h->d_ln_keys, 2 * sizeof(unsigned)));
+    CREATE_TRY(hipMalloc(&h->d_ln_keys, 16 * 2 * sizeof(unsigned)));
     CREATE_TRY(hipMalloc(&h->d_twiddles, sizeof(float2) * std::max<size_t>(tw.size(), 1)));
     CREATE_TRY(hipMemcpy(h->d_window, h->window.data(), sizeof(float) * h->bins, hipMemcpyHostToDevice));
     if (!h->big) {
@@ -712,6 +809,9 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
     }
 #undef CREATE_TRY
 
+    // what travels to the host in the streaming path: the tile when one is configured, else whole rows
+    h->out_first = cfg->tile_cols > 0 ? cfg->tile_first_col : 0;
+    h->out_cols = cfg->tile_cols > 0 ? cfg->tile_cols : h->bins;
     // streaming buffers are allocated lazily by the first push
     h->batch_rows = cfg->max_batch_rows > 0 ? cfg->max_batch_rows
                                             : std::max(1, (64 << 20) / (h->bins * 4));   // ~64 MiB of rows
@@ -723,25 +823,21 @@ extern "C" int ro_stft_destroy(ro_stft_t *h)
 {
     if (!h) return RO_OK;
     (void)hipSetDevice(h->device);
+    if (h->s_in) (void)hipStreamSynchronize(h->s_in);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->s_out) (void)hipStreamSynchronize(h->s_out);
+    free_stream_slots(h);
     if (h->d_window) (void)hipFree(h->d_window);
     if (h->d_window_k) (void)hipFree(h->d_window_k);
     if (h->d_ln_keys) (void)hipFree(h->d_ln_keys);
     if (h->d_twiddles) (void)hipFree(h->d_twiddles);
     if (h->d_twiddles_k) (void)hipFree(h->d_twiddles_k);
-    if (h->d_iq) (void)hipFree(h->d_iq);
-    if (h->d_rows) (void)hipFree(h->d_rows);
-    if (h->d_records) (void)hipFree(h->d_records);
     if (h->d_stamps) (void)hipFree(h->d_stamps);
     while (!h->ready.empty()) {
         destroy_batch(h->ready.front());
         h->ready.pop_front();
     }
     for (Batch *b : h->batch_pool) destroy_batch(b);
-    for (int i = 0; i < 2; ++i) {
-        if (h->h_in[i]) (void)hipHostFree(h->h_in[i]);
-        if (h->h_in_free[i]) (void)hipEventDestroy(h->h_in_free[i]);
-    }
     if (h->d_tw_big) (void)hipFree(h->d_tw_big);
     if (h->d_tw_f64) (void)hipFree(h->d_tw_f64);
     for (int i = 0; i < 2; ++i)
@@ -867,7 +963,7 @@ extern "C" int ro_stft_ln_tile_resident(ro_stft_t *h, const float *d_rows, int64
     a.rows_in = d_rows;
     a.ln_out = d_ln;
     a.u8_out = d_u8;
-    a.keys = h->d_ln_keys;
+    a.keys = h->d_ln_keys + 2 * (h->ln_calls++ & 15);      // a pair of its own for each of 16 calls in flight
     a.minmax = d_minmax;
     a.rows = rows;
     a.row_stride = row_stride;
@@ -948,47 +1044,63 @@ extern "C" int ro_stft_push(ro_stft_t *h, const void *iq, int format, int64_t sa
     if (samples < 0 || (samples > 0 && !iq)) return fail(RO_ERR_INVALID, "bad sample buffer");
     if (format != RO_IQ_F32 && format != RO_IQ_I16 && format != RO_IQ_F64)
         return fail(RO_ERR_INVALID, "unknown sample format %d", format);
+    const double t0 = now_ms();
+    int rc = ensure_stream_slots(h);
+    if (rc != RO_OK) return rc;
 
-    if (!h->d_iq) {
-        HIP_TRY(hipSetDevice(h->device));
-        const size_t in_samples = (size_t)(h->batch_rows - 1) * h->hop + h->bins;
-        HIP_TRY(hipMalloc(&h->d_iq, in_samples * 2 * sizeof(float)));
-        HIP_TRY(hipMalloc(&h->d_rows, (size_t)h->batch_rows * h->bins * sizeof(float)));
-        HIP_TRY(hipMalloc(&h->d_records, (size_t)h->batch_rows * sizeof(ro_scan_record_t)));
-        for (int i = 0; i < 2; ++i) {
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->h_in[i]), in_samples * 2 * sizeof(float),
-                                  hipHostMallocDefault));
-            HIP_TRY(hipEventCreateWithFlags(&h->h_in_free[i], hipEventDisableTiming));
-        }
+    // The caller's buffer is only valid during the call (src/WAVStream.cpp:113,123): copy now.  int16 samples stay
+    // int16 all the way to the kernel (half the staging memory and PCIe bytes: src/WAVStream.cpp:119-120 hands them
+    // over un-normalised, the kernel widens them); float32 and the double Complex are staged as float32 (lossless for
+    // every frontend of the reference).  A stream that changes format mid-way is widened to float32 once.
+    const bool in_i16 = format == RO_IQ_I16;
+    if (!h->stage_fmt_set) {
+        h->stage_fmt = in_i16 ? RO_IQ_I16 : RO_IQ_F32;
+        h->stage_fmt_set = true;
+    } else if (h->stage_fmt == RO_IQ_I16 && !in_i16) {
+        const size_t live = h->staged.size() / 4 - h->staged_begin;           // samples still needed, as int16 pairs
+        std::vector<char> wide(live * 8);
+        const int16_t *src = reinterpret_cast<const int16_t *>(h->staged.data()) + h->staged_begin * 2;
+        float *dst = reinterpret_cast<float *>(wide.data());
+        for (size_t i = 0; i < live * 2; ++i) dst[i] = (float)src[i];
+        h->staged.swap(wide);
+        h->staged_begin = 0;
+        h->stage_fmt = RO_IQ_F32;
     }
-
-    // the caller's buffer is only valid during the call (src/WAVStream.cpp:113,123): copy now.
+    const size_t sb = stage_sample_bytes(h);
     const size_t old = h->staged.size();
-    h->staged.resize(old + (size_t)samples * 2);
-    float *dst = h->staged.data() + old;
-    if (format == RO_IQ_F32) {
-        std::memcpy(dst, iq, (size_t)samples * 2 * sizeof(float));
-    } else if (format == RO_IQ_I16) {
-        const int16_t *s = static_cast<const int16_t *>(iq);
-        for (int64_t i = 0; i < samples * 2; ++i) dst[i] = (float)s[i];       // src/WAVStream.cpp:119-120
+    h->staged.resize(old + (size_t)samples * sb);
+    if (h->stage_fmt == RO_IQ_I16) {
+        std::memcpy(h->staged.data() + old, iq, (size_t)samples * 4);
     } else {
-        const double *s = static_cast<const double *>(iq);                     // struct Complex
-        for (int64_t i = 0; i < samples * 2; ++i) dst[i] = (float)s[i];
+        float *dst = reinterpret_cast<float *>(h->staged.data() + old);
+        if (format == RO_IQ_F32) {
+            std::memcpy(dst, iq, (size_t)samples * 2 * sizeof(float));
+        } else if (in_i16) {
+            const int16_t *src = static_cast<const int16_t *>(iq);
+            for (int64_t i = 0; i < samples * 2; ++i) dst[i] = (float)src[i];
+        } else {
+            const double *src = static_cast<const double *>(iq);               // struct Complex
+            for (int64_t i = 0; i < samples * 2; ++i) dst[i] = (float)src[i];
+        }
     }
     h->stat_samples += samples;
 
     while (staged_complete_rows(h) >= h->batch_rows) {
-        int rc = run_stream_batch(h, h->batch_rows);
+        rc = run_stream_batch(h, h->batch_rows);
         if (rc != RO_OK) return rc;
     }
     if (rows_ready) *rows_ready = h->rows_ready;
+    const double dt = now_ms() - t0;
+    h->timing.push_calls += 1;
+    h->push_ms_sum += dt;
+    h->timing.push_ms_max = std::max(h->timing.push_ms_max, dt);
     return RO_OK;
 }
 
 extern "C" int ro_stft_flush(ro_stft_t *h, int64_t *rows_ready)
 {
     if (!h) return fail(RO_ERR_INVALID, "null handle");
-    while (h->d_iq) {
+    while (h->slots_ready) {
         const int64_t n = std::min<int64_t>(staged_complete_rows(h), h->batch_rows);
         if (n <= 0) break;
         int rc = run_stream_batch(h, n);
@@ -1003,9 +1115,12 @@ extern "C" int ro_stft_fetch(ro_stft_t *h, int64_t max_rows, int first_col, int 
 {
     if (!h || !rows_got) return fail(RO_ERR_INVALID, "null argument");
     if (max_rows < 0) return fail(RO_ERR_INVALID, "negative max_rows");
-    if (rows_out && (first_col < 0 || cols <= 0 || first_col + cols > h->bins))
-        return fail(RO_ERR_INVALID, "columns [%d,+%d) outside [0,%d)", first_col, cols, h->bins);
+    if (rows_out && (first_col < h->out_first || cols <= 0 || first_col + cols > h->out_first + h->out_cols))
+        return fail(RO_ERR_INVALID, "columns [%d,+%d) outside [%d,+%d) -- what this handle brings to the host%s",
+                    first_col, cols, h->out_first, h->out_cols,
+                    h->cfg.tile_cols > 0 ? " (the configured tile)" : "");
     if (records_out && !h->cfg.enable_scan) return fail(RO_ERR_STATE, "scan records requested but scan is off");
+    const double t0 = now_ms();
     int64_t got = 0;
     if (first_row_index) *first_row_index = h->rows_emitted;
     if (first_row_index && !h->ready.empty())
@@ -1016,11 +1131,17 @@ extern "C" int ro_stft_fetch(ro_stft_t *h, int64_t max_rows, int first_col, int 
             HIP_TRY(hipEventSynchronize(b->done));
             b->pending = false;
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, b->k0, b->k1) == hipSuccess) h->stat_kernel_ms += ms;
+            if (hipEventElapsedTime(&ms, b->k0, b->k1) == hipSuccess) {
+                h->stat_kernel_ms += ms;
+                h->timing.batches += 1;
+                h->timing.batch_rows += b->rows;
+                h->batch_ms_sum += ms;
+                h->timing.batch_gpu_ms_max = std::max(h->timing.batch_gpu_ms_max, (double)ms);
+            }
         }
         const int64_t take = std::min(max_rows - got, b->rows - b->consumed);
         for (int64_t r = 0; r < take; ++r) {
-            const float *src = b->data + (size_t)(b->consumed + r) * h->bins + first_col;
+            const float *src = b->data + (size_t)(b->consumed + r) * h->out_cols + (first_col - h->out_first);
             if (rows_out) std::memcpy(rows_out + (size_t)(got + r) * cols, src, sizeof(float) * cols);
             if (records_out) records_out[got + r] = b->records[(size_t)(b->consumed + r)];
         }
@@ -1033,15 +1154,22 @@ extern "C" int ro_stft_fetch(ro_stft_t *h, int64_t max_rows, int first_col, int 
     }
     h->rows_ready -= got;
     *rows_got = got;
+    const double dt = now_ms() - t0;
+    h->timing.fetch_calls += 1;
+    h->fetch_ms_sum += dt;
+    h->timing.fetch_ms_max = std::max(h->timing.fetch_ms_max, dt);
     return RO_OK;
 }
 
 extern "C" int ro_stft_reset(ro_stft_t *h)
 {
     if (!h) return fail(RO_ERR_INVALID, "null handle");
+    if (h->s_in) (void)hipStreamSynchronize(h->s_in);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->s_out) (void)hipStreamSynchronize(h->s_out);
     h->staged.clear();
     h->staged_begin = 0;
+    h->stage_fmt_set = false;
     while (!h->ready.empty()) {
         release_batch(h, h->ready.front());
         h->ready.pop_front();
@@ -1049,6 +1177,23 @@ extern "C" int ro_stft_reset(ro_stft_t *h)
     h->stream_sample0 = 0;
     h->rows_emitted = 0;
     h->rows_ready = 0;
+    return RO_OK;
+}
+
+extern "C" int ro_stft_timing(ro_stft_t *h, ro_stft_timing_t *out, int reset)
+{
+    if (!h) return fail(RO_ERR_INVALID, "null handle");
+    if (out) {
+        *out = h->timing;
+        out->push_ms_avg = h->timing.push_calls ? h->push_ms_sum / (double)h->timing.push_calls : 0.0;
+        out->batch_gpu_ms_avg = h->timing.batches ? h->batch_ms_sum / (double)h->timing.batches : 0.0;
+        out->row_gpu_us_avg = h->timing.batch_rows ? h->batch_ms_sum * 1e3 / (double)h->timing.batch_rows : 0.0;
+        out->fetch_ms_avg = h->timing.fetch_calls ? h->fetch_ms_sum / (double)h->timing.fetch_calls : 0.0;
+    }
+    if (reset) {                                             // FFTBackend::clearProcessingTime, src/FFTBackend.h:231-235
+        h->timing = ro_stft_timing_t{};
+        h->push_ms_sum = h->batch_ms_sum = h->fetch_ms_sum = 0.0;
+    }
     return RO_OK;
 }
 

@@ -39,7 +39,10 @@ void WAVStream::run()
             // its parser -- the extension is skipped here
             if (size > 16) in_.ignore(size - 16);
         } else if (id == "inf1") {                                        // :91-97
-            inf1_ = readString((int)size);
+            // untrusted length: keep at most 64 KiB of it (a size above INT_MAX once meant a huge std::string)
+            const uint32_t keep = size < 65536u ? size : 65536u;
+            inf1_ = readString((int)keep);
+            if (size > keep) in_.ignore(size - keep);
         } else if (id == "data") {                                        // :169-176
             if (!dataRead_) {
                 startStream();

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 
 namespace ro {
@@ -131,7 +132,23 @@ void HipWaterfallBackend::startStream(StreamInfo info)
     c.iq_gain = cfg_.iq_gain;
     c.iq_phase_shift = cfg_.iq_phase_shift;
     c.device = cfg_.device;
-    c.max_batch_rows = cfg_.max_batch_rows;
+    // Rows reach Recorder::update() a batch late (the GPU wants more than one row per launch; recorders only look
+    // backwards).  The library's own default batch is sized for throughput (~64 MiB of rows: 87 s of stream at
+    // N = 32768 / 75 %); behind the Backend interface the default is bounded by LATENCY instead: at most one second
+    // of rows, and never more than an eighth of the row ring or a quarter of the raw-sample ring, so that an event's
+    // snapshot and raw capture (which reach back `advance` rows from the row being delivered) still find their data.
+    batchRows_ = cfg_.max_batch_rows;
+    if (batchRows_ <= 0) {
+        const int64_t one_second = (int64_t)std::ceil((double)fftSampleRate_);
+        const int64_t ring = buffer_.getCapacity() / 8;
+        const int64_t raw = cfg_.keep_raw ? (int64_t)rawCapacity_ / hop_ / 4 : one_second;
+        batchRows_ = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(one_second, ring), std::min<int64_t>(raw, 4096)));
+    }
+    if (cfg_.keep_raw && (int64_t)batchRows_ * hop_ + bins_ > rawCapacity_)
+        std::fprintf(stderr, "HipWaterfallBackend: batch of %d rows (%lld samples) exceeds the raw ring (%d samples): "
+                             "raw captures of events will hold newer samples than their rows\n",
+                     batchRows_, (long long)batchRows_ * hop_ + bins_, rawCapacity_);
+    c.max_batch_rows = batchRows_;
     c.enable_scan = scanEnabled_ ? 1 : 0;
     if (ro_stft_create(&c, &stft_) != RO_OK) {
         // the reference logs and carries on (LOG_ERROR + return); so does this: no rows will come

@@ -193,12 +193,14 @@ public:
     void process(const std::vector<Complex> &data, DataInfo info) override;
     void endStream() override;                                       // :600-607
     const std::string &lastError() const { return lastError_; }
+    int batchRows() const { return batchRows_; }                     // rows per kernel launch of this stream
 
 private:
     void drain(bool flush);
     void stampRowStarts(int64_t takeBegin, int64_t takeEnd, const WFTime &t);
 
     ro_stft_t *stft_ = nullptr;
+    int batchRows_ = 0;
     std::string lastError_;
 
     // framing bookkeeping that stays on the host (timestamps, raw marks: O(1) per row)

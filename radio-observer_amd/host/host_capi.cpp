@@ -187,6 +187,7 @@ int ro_host_pipeline_events(void *p, BolidEvent *out, int max)
     return (int)ev.size();
 }
 int ro_host_pipeline_state(void *p) { return (int)PIPE(p)->bolid.state(); }
+int ro_host_pipeline_batch_rows(void *p) { return PIPE(p)->backend.batchRows(); }
 
 
 // ---- frontends against a recording backend (no GPU): what exactly does Backend::process() receive?

@@ -71,7 +71,7 @@ class HostPipeline:
         L.ro_host_pipeline_rows.restype = C.c_int64
         L.ro_host_pipeline_error.argtypes = [C.c_void_p]
         L.ro_host_pipeline_error.restype = C.c_char_p
-        for n in ("ring_capacity", "ring_mark", "raw_capacity", "state"):
+        for n in ("ring_capacity", "ring_mark", "raw_capacity", "state", "batch_rows"):
             getattr(L, "ro_host_pipeline_" + n).argtypes = [C.c_void_p]
             getattr(L, "ro_host_pipeline_" + n).restype = C.c_int
         L.ro_host_pipeline_ring_row.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
@@ -159,6 +159,9 @@ class HostPipeline:
 
     def state(self):
         return self.L.ro_host_pipeline_state(self.h)
+
+    def batch_rows(self):
+        return self.L.ro_host_pipeline_batch_rows(self.h)
 
     def close(self):
         if self.h:

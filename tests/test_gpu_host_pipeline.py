@@ -53,6 +53,30 @@ def test_stream_rows_times_and_marks(oracle, bins, overlap, chunk, batch):
     p.close()
 
 
+def test_default_batch_is_bounded_by_latency(oracle):
+    """max_batch_rows = 0 (the default of every shipped config): rows reach the recorders within one second of
+    stream time and well inside the raw ring, while the stream is running -- not only at endStream()."""
+    bins, overlap, hop, fs = 4096, 3072, 1024, 48000
+    rng = np.random.default_rng(4)
+    T = 6 * fs                                                   # six seconds: 278 rows
+    iq = noise_iq(rng, T)
+    z = iq[:, 0].astype(np.float64) + 1j * iq[:, 1].astype(np.float64)
+    p = HostPipeline(bins, overlap, max_batch_rows=0, snapshot_length=1)
+    rate = fs / hop                                              # 46.875 rows/s
+    assert 1 <= p.batch_rows() <= int(np.ceil(rate))
+    assert p.batch_rows() * hop + bins <= p.raw_capacity()
+    worst = 0
+    for i in range(0, T, 4096):
+        p.process(z[i:i + 4096])
+        fed = min(i + 4096, T)
+        complete = (fed - bins) // hop + 1 if fed >= bins else 0
+        worst = max(worst, complete - p.rows)
+    assert worst <= p.batch_rows(), (worst, p.batch_rows())      # never more than one batch behind
+    p.end()
+    assert p.rows == (T - bins) // hop + 1 and p.error == ""
+    p.close()
+
+
 def test_bolid_detection_through_the_pipeline(oracle):
     """C4: chirps in noise through Frontend -> HipWaterfallBackend -> BolidRecorder; the events
     must equal the oracle's FSM driven by the oracle's FP64 rows."""

@@ -94,3 +94,44 @@ def test_short_and_empty_streams(ro):
         assert first == 0 and rows.shape == (1, 1024) and not rows.any()
         st.reset()
         assert st.flush() == 0
+
+
+def test_int16_stream_stays_int16_and_format_switch(ro, oracle):
+    """int16 samples (WAV) are staged and uploaded as int16 and widened by the kernel; a stream that switches to
+    float samples mid-way is widened once on the host -- same rows either way."""
+    bins, overlap = 4096, 3072
+    rng = np.random.default_rng(12)
+    i16 = rng.integers(-30000, 30000, size=(bins + 40 * 1024 + 5, 2), dtype=np.int16)
+    want = oracle.stft(i16.astype(np.float64), bins, overlap)
+    a, *_ = stream(ro, [i16[i:i + 1024] for i in range(0, len(i16), 1024)], bins, overlap, max_batch_rows=6)
+    assert a.shape == want.shape and rel_to_row_max(a, want) <= 1e-5
+    half = 17 * 1024 + 3
+    mixed = [i16[:half], i16[half:].astype(np.float32)]
+    b, *_ = stream(ro, mixed, bins, overlap, max_batch_rows=6)
+    assert np.array_equal(a, b)
+
+
+def test_tile_only_transport_and_timing(ro, oracle):
+    """With a tile configured only its columns travel to the host; fetch outside it is refused.  The timing
+    counters (FFTBackend::logProcessingTimes' counterpart) count calls and batches."""
+    bins, overlap, hop = 32768, 24576, 8192
+    rng = np.random.default_rng(13)
+    iq = noise_iq(rng, bins + 21 * hop)
+    tile = (23278, 615)
+    with ro.Stft(bins=bins, overlap=overlap, tile=tile, max_batch_rows=4) as st:
+        for i in range(0, len(iq), 4096):
+            st.push(iq[i:i + 4096])
+        st.flush()
+        with pytest.raises(ro.StftError):
+            st.fetch(1, first_col=0, cols=bins)
+        first, band, _ = st.fetch(1000)
+        assert first == 0 and band.shape == (22, 615)
+        t = st.timing()
+        assert t["push_calls"] == (len(iq) + 4095) // 4096 and t["batches"] == 6 and t["batch_rows"] == 22
+        assert 0 < t["batch_gpu_ms_avg"] <= t["batch_gpu_ms_max"] and t["row_gpu_us_avg"] > 0
+        assert t["push_ms_max"] >= t["push_ms_avg"] > 0 and t["fetch_calls"] == 1
+        st.timing(reset=True)
+        assert st.timing()["push_calls"] == 0
+    want = oracle.stft(iq, bins, overlap)[:, tile[0]:tile[0] + tile[1]]
+    full = oracle.stft(iq, bins, overlap)
+    assert np.abs(band.astype(np.float64) - want).max() <= 1e-5 * full.max()
