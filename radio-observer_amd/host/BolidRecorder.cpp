@@ -130,7 +130,6 @@ void BolidRecorder::update()
         }
         break;
     }
-    if (!pending_.empty()) drainPending(false);              // the worker's retry loop (WaterfallBackend.cpp:60-104)
 }
 
 }  // namespace ro

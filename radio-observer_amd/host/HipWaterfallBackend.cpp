@@ -30,7 +30,7 @@ WaterfallBase::WaterfallBase(const WaterfallConfig &cfg) : cfg_(cfg)
 void WaterfallBase::addRecorder(Recorder *recorder)
 {
     recorders_.push_back(recorder);
-    recorder->setBuffer(&buffer_, &rawBuffer_, &rawHandles_);
+    recorder->setBuffer(&buffer_, &rawBuffer_, &bufferMutex_, &rawHandles_);      // src/WaterfallBackend.cpp:566
 }
 
 bool WaterfallBase::beginStream(const StreamInfo &info, ro_bands_t *bands)
@@ -95,9 +95,14 @@ void WaterfallBase::finishStream()
 // WaterfallBackend::processFFT minus the arithmetic (src/WaterfallBackend.cpp:485-541)
 void WaterfallBase::processRow(const float *row, const ro_scan_record_t *scan, DataInfo info, int rawMark)
 {
-    float *dst = buffer_.push();                                                 // :488
-    std::memcpy(dst, row, sizeof(float) * (size_t)bins_);
-    rawHandles_[buffer_.mark()] = RawDataHandle(rawMark, info.timeOffset);       // :507 (one slot ahead)
+    {
+        // the ring's bookkeeping is shared with the recorders' worker threads (reservations, size); the row itself is
+        // written into a slot no queued snapshot covers
+        std::lock_guard<std::mutex> g(bufferMutex_);
+        float *dst = buffer_.push();                                             // :488
+        std::memcpy(dst, row, sizeof(float) * (size_t)bins_);
+        rawHandles_[buffer_.mark()] = RawDataHandle(rawMark, info.timeOffset);   // :507 (one slot ahead)
+    }
     if (scan) currentScan_ = *scan;
     rowsDelivered_++;
     if (keepLog_) rowLog_.push_back(RowInfo{info.offset, info.timeOffset, rawMark});

@@ -11,6 +11,7 @@
 
 #include <deque>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -35,11 +36,12 @@ class Recorder {
 public:
     explicit Recorder(WaterfallBase *backend) : backend_(backend) {}
     virtual ~Recorder() {}
-    void setBuffer(RingBuffer2D<float> *buffer, RingBuffer2D<float> *rawBuffer,
+    void setBuffer(RingBuffer2D<float> *buffer, RingBuffer2D<float> *rawBuffer, std::mutex *bufferMutex,
                    std::vector<RawDataHandle> *rawHandles)
     {
         buffer_ = buffer;
         rawBuffer_ = rawBuffer;
+        bufferMutex_ = bufferMutex;
         rawHandles_ = rawHandles;
     }
     int getSampleRate() const;
@@ -61,6 +63,7 @@ protected:
     WaterfallBase              *backend_;
     RingBuffer2D<float>        *buffer_ = nullptr;
     RingBuffer2D<float>        *rawBuffer_ = nullptr;     // raw I/Q, 2 floats per sample (src/FFTBackend.h:99)
+    std::mutex                 *bufferMutex_ = nullptr;   // guards the row ring's bookkeeping (WaterfallBackend.h:249)
     std::vector<RawDataHandle> *rawHandles_ = nullptr;
 };
 
@@ -157,6 +160,7 @@ protected:
     WFTime fixedClock_;
     bool   useFixedClock_ = false;
     RingBuffer2D<float>        buffer_;
+    std::mutex                 bufferMutex_;     // WaterfallBackend::bufferMutex_: recorders' workers share the ring
     RingBuffer2D<float>        rawBuffer_;
     std::vector<RawDataHandle> rawHandles_;
     std::vector<Recorder *>    recorders_;

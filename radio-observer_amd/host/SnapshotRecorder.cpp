@@ -1,6 +1,7 @@
 #include "SnapshotRecorder.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <ctime>
@@ -37,6 +38,16 @@ SnapshotRecorder::SnapshotRecorder(WaterfallBase *backend, const SnapshotConfig 
     rightFrequency_ = std::max(cfg.low_freq, cfg.hi_freq);
 }
 
+SnapshotRecorder::~SnapshotRecorder() { joinWorker(); }
+
+void SnapshotRecorder::joinWorker()
+{
+    if (worker_.joinable()) {
+        snapshots_.close();
+        worker_.join();
+    }
+}
+
 int SnapshotRecorder::requestBufferSize()
 {
     const float rate = backend_->getFFTSampleRate();
@@ -59,10 +70,15 @@ void SnapshotRecorder::start()
     }
     nextSnapshot_ = Snapshot();
     nextSnapshot_.fileName = getFileName(fftMarkToTime(nextSnapshot_.start));   // :394-395 (epoch-zero name on
-    pending_.clear();                                                            //  the first file: App. B-4)
+    joinWorker();                                                                //  the first file: App. B-4)
     queued_.clear();
-    written_.clear();
-    writtenRaw_.clear();
+    {
+        std::lock_guard<std::mutex> g(listMutex_);
+        written_.clear();
+        writtenRaw_.clear();
+    }
+    snapshots_.reopen();
+    worker_ = std::thread(&SnapshotRecorder::threadMethod, this);               // :396
 }
 
 std::string SnapshotRecorder::getFileName(const char *typ, WFTime time) const
@@ -77,46 +93,71 @@ std::string SnapshotRecorder::getFileName(WFTime time) const { return getFileNam
 
 void SnapshotRecorder::startWriting()
 {
-    if (nextSnapshot_.length == 0) nextSnapshot_.length = buffer_->size(nextSnapshot_.start);      // :111-112
-    if (snapshotRows_ < nextSnapshot_.length) nextSnapshot_.length = snapshotRows_;                // :113-114
+    {
+        std::lock_guard<std::mutex> g(*bufferMutex_);                                               // :109-119
+        if (nextSnapshot_.length == 0) nextSnapshot_.length = buffer_->size(nextSnapshot_.start);  // :111-112
+        if (snapshotRows_ < nextSnapshot_.length) nextSnapshot_.length = snapshotRows_;            // :113-114
+        nextSnapshot_.reservation = buffer_->reserve(nextSnapshot_.start, nextSnapshot_.start + nextSnapshot_.length);   // :117
+    }
     const int end = nextSnapshot_.start + nextSnapshot_.length;
-    nextSnapshot_.reservation = buffer_->reserve(nextSnapshot_.start, end);                         // :117
-    pending_.push_back(nextSnapshot_);                                                              // :120
     queued_.push_back(nextSnapshot_);
+    snapshots_.send(nextSnapshot_);                                                                 // :120
     nextSnapshot_ = Snapshot();
     nextSnapshot_.start = end;                                                                      // :122
     nextSnapshot_.fileName = getFileName(fftMarkToTime(nextSnapshot_.start));                       // :125
-    drainPending(false);
 }
 
-// the worker's loop body (:60-104): write what is complete, keep the rest for later
-void SnapshotRecorder::drainPending(bool final)
+// The worker (src/WaterfallBackend.cpp:60-104): takes what update() queued, writes every snapshot whose rows are
+// complete, keeps the others for the next turn.  It reads ring rows without the lock, like the reference: the rows
+// of a queued snapshot are reserved and the ring is eight snapshots long; only the ring's bookkeeping (size,
+// reservations) is touched under the buffer mutex.
+void SnapshotRecorder::threadMethod()
 {
-    std::vector<Snapshot> keep;
-    for (const Snapshot &s : pending_) {
-        if (buffer_->size(s.start) >= s.length) {
-            if (cfg_.write_files) {
-                write(s);
-                if (s.includeRawData) writeRaw(s);                    // :80-81
+    std::vector<Snapshot> work;
+    for (;;) {
+        const bool open = snapshots_.drain(work, /*block=*/true, work.empty() ? 50 : 2);
+        std::vector<Snapshot> keep;
+        for (const Snapshot &s : work) {
+            bool complete;
+            {
+                std::lock_guard<std::mutex> g(*bufferMutex_);
+                complete = buffer_->size(s.start) >= s.length;                                      // :76
             }
-            buffer_->freeReservation(s.reservation);
-        } else if (!final) {
-            keep.push_back(s);
+            if (complete) {
+                if (cfg_.write_files) {
+                    write(s);
+                    if (s.includeRawData) writeRaw(s);                                              // :80-81
+                }
+                std::lock_guard<std::mutex> g(*bufferMutex_);
+                buffer_->freeReservation(s.reservation);                                            // :87-90
+            } else if (open) {
+                keep.push_back(s);                     // rows still to come; at the end an unfinished one is dropped
+            }
         }
+        work.swap(keep);
+        if (!open) break;
     }
-    pending_.swap(keep);
 }
 
 void SnapshotRecorder::update()
 {
-    if (buffer_->size(nextSnapshot_.start) >= snapshotRows_ + 2) startWriting();                   // :417-426
-    else if (!pending_.empty()) drainPending(false);
+    bool due;
+    {
+        std::lock_guard<std::mutex> g(*bufferMutex_);
+        due = buffer_->size(nextSnapshot_.start) >= snapshotRows_ + 2;                             // :417-426
+    }
+    if (due) startWriting();
 }
 
 void SnapshotRecorder::stop()
 {
-    if (buffer_->size(nextSnapshot_.start) >= 0 && writeUnfinished_) startWriting();               // :402-403
-    drainPending(true);
+    bool any;
+    {
+        std::lock_guard<std::mutex> g(*bufferMutex_);
+        any = buffer_->size(nextSnapshot_.start) >= 0;                                             // :402 (always true)
+    }
+    if (any && writeUnfinished_) startWriting();                                                   // :402-403
+    joinWorker();                                                                                  // :404-411
 }
 
 bool SnapshotRecorder::write(const Snapshot &s)
@@ -151,7 +192,10 @@ bool SnapshotRecorder::write(const Snapshot &s)
     int rowIndex = s.start;
     for (int y = 0; y < s.length; ++y, ++rowIndex) w.write(y, 1, buffer_->at(rowIndex) + leftBin_);   // :203-205
     const bool ok = w.close();
-    if (ok) written_.push_back(s.fileName);
+    if (ok) {
+        std::lock_guard<std::mutex> g(listMutex_);
+        written_.push_back(s.fileName);
+    }
     return ok;
 }
 
@@ -183,7 +227,10 @@ bool SnapshotRecorder::writeRaw(const Snapshot &s)
     int rowIndex = start;
     for (int y = 0; y < length; ++y, ++rowIndex) w.write(y, 1, rawBuffer_->at(rowIndex));            // :258-260
     const bool ok = w.close();
-    if (ok) writtenRaw_.push_back(name);
+    if (ok) {
+        std::lock_guard<std::mutex> g(listMutex_);
+        writtenRaw_.push_back(name);
+    }
     return ok;
 }
 
