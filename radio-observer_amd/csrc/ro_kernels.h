@@ -30,6 +30,7 @@ struct StftArgs {
     int           stagger;     // start delay per workgroup slot, shader cycles (0 = none)
     int           prefetch;    // set by the launcher: touch the next row's new samples ahead of time
     int           spare_cus;   // CUs per XCD the persistent grid leaves to other kernels (ro_stft_config_t)
+    int           dec, dec_log2; // MODE 2 (sub-transform of a large transform): decimation factor, its log2; else 1, 0
     // fused per-row band scan (BolidRecorder::noise/peak/average on the row while it is still in LDS): plans that
     // support it (stft_fuses_scan) fill records[row] themselves, the others leave it to launch_scan
     ro_scan_record_t *records; // rows records, or nullptr
@@ -104,6 +105,19 @@ struct BigArgsD {
 };
 int        f64_radices(int bins, int radices[8]); // passes of the FP64 path for a power of two 256 .. 2^20 (0 = unsupported)
 hipError_t launch_f64_pass(int radix, bool first, bool last, int fmt, const BigArgsD &a, hipStream_t s);
+
+// ---- large transforms, two passes: `dec` decimated sub-transforms of length bins / dec with the single-pass kernels
+// (spectra to scratch), then the radix-`dec` combine below
+struct CombineArgs {
+    const float2 *spec;        // [rows][dec][m] sub-spectra S_r[k'], bin k' at element k'
+    const float2 *tw;          // [dec][m]: entry r m + k' = exp(-2 pi i r k' / bins) (exact, in the order the combine reads)
+    float        *rows_out;    // [rows][row_stride] magnitudes, fft-shifted
+    int64_t       rows, row_stride;
+    int           m;           // length of a sub-transform
+    int           dec;         // radix of the combine: 2 .. 32
+};
+bool       big_split(int bins, int *sub_bins, int *dec);   // how a large transform is cut (false: not a large size)
+hipError_t launch_combine(const CombineArgs &a, hipStream_t s);
 
 bool       big_supported(int bins);               // power of two in (32768, 2^20]
 int        big_radices(int bins, int radices[8]); // number of passes

@@ -856,13 +856,17 @@ template <> struct Sample<RO_FMT_I16> {
 // magnitude has just been stored.
 // MODE 0: magnitude rows (the waterfall).  MODE 1: the complex spectrum itself, bin k at element k of the row
 // (what fftw_execute leaves in out_ and FFTBackend::processFFT receives, src/FFTBackend.h:104): same transform, the
-// epilogue stores v[] as it is -- no magnitude, no shift, no LDS staging.
+// epilogue stores v[] as it is -- no magnitude, no shift, no LDS staging.  MODE 2: MODE 1 on DECIMATED input, the
+// first pass of a large transform (bins > 32768 = dec x N): kernel row k is phase r = k mod dec of stream row k / dec,
+// its samples are x[row hop + r + dec m], its window the r-th decimated table; the spectra S_r go to scratch and
+// combine_kernel finishes the row (X[k' + N q] = sum_r W_dec^(rq) W_(dec N)^(r k') S_r[k']).
 template <class PL, int FMT, int MODE>
 __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
 {
     constexpr int N = PL::N, T = PL::T, P = PL::P;
     constexpr int R0 = PL::R0;
     constexpr bool ADDTID = plan_addtid<PL>();
+    constexpr bool DEC = MODE == 2;                 // decimated input (sub-transform of a large transform)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using S = Sample<FMT>;
 
@@ -904,9 +908,18 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
     // NB stage-0 butterflies per thread: "logical thread" j = tid + T*b (b < NB) owns v[R0*b .. R0*b + R0-1].  The
     // paired scheme needs one butterfly per logical thread; the add-TID plan runs 1024 of them on 1024 or 512 threads.
     constexpr int NB = P / R0, TL = T * NB;
-    constexpr bool PAIRED = (NB == 1 || ADDTID) && (R0 % 2 == 0) && RO_PAIRED_LOADS;
+    // (decimated input: neighbouring columns are `dec` samples apart in memory, so no 16-byte pairs)
+    constexpr bool PAIRED = (NB == 1 || ADDTID) && (R0 % 2 == 0) && RO_PAIRED_LOADS && !DEC;
     constexpr int H = R0 / 2;
-    constexpr bool SWAP32 = plan_swap32<PL>();
+    constexpr bool SWAP32 = plan_swap32<PL>() && !DEC;
+    const int dmul = DEC ? a.dec : 1;               // element stride of the samples, in samples
+    // descriptor of kernel row k's samples / window coefficients (zero-sized when !valid: the loads become no-ops)
+    auto row_rsrc = [&](int64_t k, bool valid) {
+        const int64_t srow = DEC ? k >> a.dec_log2 : k;
+        const int r = DEC ? (int)(k & (a.dec - 1)) : 0;
+        return make_rsrc(iq + ((a.first_row + srow) * (int64_t)a.hop + r) * S::BYTES,
+                         valid ? (unsigned)(N * dmul - r) * S::BYTES : 0u);
+    };
     auto pair_off = [&](int b) { return plan_pair_off<PL>(tid + T * b); };   // first sample logical thread b fetches
     auto load_row = [&](const __amdgpu_buffer_rsrc_t &rs) {
         if constexpr (PAIRED) {
@@ -925,13 +938,13 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             for (int i = 0; i < P; ++i) {
                 // slot i: butterfly i / R0, leg i % R0 of stage 0
                 if constexpr (RO_ABLATE & 32) v[i] = (v2f){(float)(tid + i), 1.0f};
-                else v[i] = S::load(rs, (tid + T * (i / R0)) * S::BYTES, (i % R0) * (N / R0) * S::BYTES);
+                else v[i] = S::load(rs, (tid + T * (i / R0)) * S::BYTES * dmul, (i % R0) * (N / R0) * S::BYTES * dmul);
             }
         }
     };
 
     // ---- prologue: samples of the first row
-    load_row(make_rsrc(iq + (a.first_row + row) * (int64_t)a.hop * S::BYTES, N * S::BYTES));
+    load_row(row_rsrc(row, true));
 
     constexpr int RL = PL::R3 > 1 ? PL::R3 : (PL::R2 > 1 ? PL::R2 : (PL::R1 > 1 ? PL::R1 : PL::R0));
     unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
@@ -995,16 +1008,21 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
     // (the pipelined plan has fewer registers to spare -- the fused scan's two waves keep their band in registers
     // while the next row's samples are already landing: a quarter; with half, hipcc parks one coefficient quad in
     // scratch for the whole row)
-    constexpr int NW_EARLY = ((NW * (plan_pipe<PL>() ? RO_PIPE_WIN_EARLY_PCT : RO_WIN_EARLY_PCT)) / 100) & ~1;
+    // (decimated input: unpaired loads, one register per coefficient -- no room for an early share)
+    constexpr int NW_EARLY = DEC ? 0 : ((NW * (plan_pipe<PL>() ? RO_PIPE_WIN_EARLY_PCT : RO_WIN_EARLY_PCT)) / 100) & ~1;
     using c0 = std::integral_constant<int, 0>;
     using cE = std::integral_constant<int, NW_EARLY>;
     using cN = std::integral_constant<int, NW>;
     const float *win_tab = WPERM ? a.window_k : a.window;
-    load_window(make_rsrc(win_tab, N * 4), c0{}, cN{});
+    // (decimated input: phase r of a row has its own table of N coefficients, w[r + dec m])
+    auto win_rsrc = [&](int64_t k, bool valid) {
+        return make_rsrc(win_tab + (DEC ? (k & (a.dec - 1)) * (int64_t)N : 0), valid ? N * 4 : 0);
+    };
+    load_window(win_rsrc(row, true), c0{}, cN{});
     // window and twiddle tables resident in registers (see RO_RESIDENT_TABLES)
     constexpr bool RES = RO_RESIDENT_TABLES && N <= 8192 && !RO_ABLATE;              // twiddles (and window)
     // the 512-thread form of the N = 32768 plan has 256 VGPRs per thread: the window stays, the twiddles do not fit
-    constexpr bool RESW = RES || (RO_T512_RESW && ADDTID && T == 512 && !RO_ABLATE);
+    constexpr bool RESW = (RES && !DEC) || (RO_T512_RESW && ADDTID && T == 512 && !RO_ABLATE);
     v2f tw1[PL::R1 > 1 ? P / PL::R1 : 1][TW_SET];
     v2f tw2[PL::R2 > 1 ? P / PL::R2 : 1][TW_SET];
     v2f tw3[PL::R3 > 1 ? P / PL::R3 : 1][TW_SET];
@@ -1094,9 +1112,9 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         // from here on and the loads overlap the whole transform instead of the epilogue's
         // memory burst.  (Unconditional: the same table every row.)
         if constexpr (ADDTID) asm volatile("" ::"v"(touch));     // see touch_next
-        if constexpr (!RESW) load_window(make_rsrc(win_tab, N * 4), c0{}, cE{});
         const int64_t next = row + stride;
         const bool has_next = next < xcd_end;
+        if constexpr (!RESW) load_window(win_rsrc(has_next ? next : row, true), c0{}, cE{});
         auto touch_next = [&]() {
             if constexpr (!ADDTID) return;          // only the add-TID plan is launched with a.prefetch
             // samples [next*hop + N - hop, next*hop + N) = hop * BYTES bytes: one dword per 128-byte line and thread
@@ -1176,9 +1194,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
                 // registers receive legs 2j, 2j+1 of the NEXT row's samples -- for j < PIPE_J; the last legs are
                 // requested behind the scan (they are also the last ones the window stage asks for), whose two waves
                 // would not fit the 128 VGPRs with all 64 of them in flight.
-                const __amdgpu_buffer_rsrc_t rs_next =
-                    make_rsrc(iq + (a.first_row + (has_next ? next : row)) * (int64_t)a.hop * S::BYTES,
-                              has_next ? N * S::BYTES : 0);     // zero-sized after the last row: the loads are no-ops
+                const __amdgpu_buffer_rsrc_t rs_next = row_rsrc(has_next ? next : row, has_next);   // zero-sized after the last row
                 const int po = pair_off(0) * S::BYTES;
                 // The image writes of pair j are issued one pair late (from done(j + 1), the last ones behind the
                 // level): v_sqrt_f32 runs in the transcendental pipe and hipcc pads no hazards in front of inline asm.
@@ -1251,7 +1267,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
                 for (int k = 2 * PIPE_J; k < H; ++k)
                     S::load_pair(rs_next, po, k * (N / R0) * S::BYTES, v[k], v[H + k]);
             }
-            if constexpr (!RESW) load_window(make_rsrc(win_tab, has_next ? N * 4 : 0), cE{}, cN{});
+            if constexpr (!RESW) load_window(win_rsrc(has_next ? next : row, has_next), cE{}, cN{});
             stamp(8);
             prev_out = a.rows_out + row * a.row_stride;
             prev_bytes = N * 4;
@@ -1302,7 +1318,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         // requested into the freed registers, and only then the row is read back 16 bytes per
         // lane and stored -- 1 KiB per wave-instruction, the stores being the LAST thing in the
         // VMEM queue.
-        if constexpr (MODE == 1) {
+        if constexpr (MODE >= 1) {
             // slot r of butterfly b is bin (tid + T b) + r N/RL: 8 bytes per lane, 512 contiguous bytes per wave
             const __amdgpu_buffer_rsrc_t rs_spec =
                 make_rsrc(a.spec_out + row * a.spec_stride, (unsigned)N * 8u);
@@ -1315,9 +1331,8 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
                     __builtin_amdgcn_raw_buffer_store_b64(t, rs_spec, (tid + T * b) * 8, r * (N / RL) * 8, RO_STORE_AUX);
                 }
             }
-            load_row(make_rsrc(iq + (a.first_row + (has_next ? next : row)) * (int64_t)a.hop * S::BYTES,
-                               has_next ? N * S::BYTES : 0));
-            if constexpr (!RESW) load_window(make_rsrc(win_tab, has_next ? N * 4 : 0), cE{}, cN{});
+            load_row(row_rsrc(has_next ? next : row, has_next));
+            if constexpr (!RESW) load_window(win_rsrc(has_next ? next : row, has_next), cE{}, cN{});
             st_acc[9] += 1;
             if (!has_next) break;
             row = next;
@@ -1354,11 +1369,10 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         }
         stamp(10);                                  // magnitudes -> LDS writes issued
         // a zero-sized descriptor turns the loads into no-ops after the last row
-        load_row(make_rsrc(iq + (a.first_row + (has_next ? next : row)) * (int64_t)a.hop * S::BYTES,
-                           has_next ? N * S::BYTES : 0));
+        load_row(row_rsrc(has_next ? next : row, has_next));
         // unconditional (zero-sized descriptor after the last row): a branch here would keep the
         // old coefficients alive next to the new ones
-        if constexpr (!RESW) load_window(make_rsrc(win_tab, has_next ? N * 4 : 0), cE{}, cN{});
+        if constexpr (!RESW) load_window(win_rsrc(has_next ? next : row, has_next), cE{}, cN{});
         stamp(7);                                   // next-row loads issued
         // the add-TID writes sit inside inline asm: hipcc does not count them, so the barrier's own lgkmcnt wait
         // is missing unless it is spelled out (the image is read by OTHER waves right behind the barrier)
@@ -1463,6 +1477,53 @@ __global__ __launch_bounds__(256) void big_pass_kernel(BigArgs a)
             const v2f x = v[bitrev<R>(k)];
             out[j0 + k * a.ns] = make_float2(x.x, x.y);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Large transforms in two passes (bins = dec x M, the station sizes of Bolidozor.json:45 and Ionozor.json:27).
+// Pass A: stft_kernel MODE 2, `dec` decimated length-M transforms per row with the single-pass plans
+// (S_r[k'] = sum_m w[r + dec m] x[r + dec m] exp(-2 pi i m k'/M)), spectra to a scratch block small enough to stay in
+// the 256 MiB Infinity Cache.  Pass B, here: X[k' + M q] = sum_r W_dec^(r q) (W_bins^(r k') S_r[k']) -- one thread per
+// k', a radix-dec butterfly in registers, twiddles from one exp(-2 pi i j/bins) table (exact entries), magnitudes out
+// in runs of consecutive k' (coalesced), fft-shifted.  HBM traffic per row: hop*8 in, 8 bins out and in again, 4 bins
+// out -- against 16 B per point and pass for the four or five passes of big_pass_kernel (which remains for the
+// multi-pass FP64 mode's structure and as the fallback below 64 Ki... see launch_transform).
+// ---------------------------------------------------------------------------
+template <int R> __global__ __launch_bounds__(256) void combine_kernel(CombineArgs a)
+{
+    // two consecutive k' per thread: 16-byte loads of sub-spectra and twiddles, 8-byte stores
+    const int per_row = a.m / 2;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = g / per_row;
+    if (row >= a.rows) return;
+    const int k = 2 * (int)(g - row * per_row);
+    const float4 *in = reinterpret_cast<const float4 *>(a.spec + (row * R) * (int64_t)a.m + k);
+    const float4 *tw = reinterpret_cast<const float4 *>(a.tw + k);
+    const int m4 = a.m / 2;                                       // float4 units per sub-spectrum
+    v2f u[R], v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float4 x = in[(int64_t)r * m4];
+        u[r] = (v2f){x.x, x.y};
+        v[r] = (v2f){x.z, x.w};
+        if (r > 0) {
+            const float4 t = tw[(int64_t)r * m4];                 // W_bins^(r k'), W_bins^(r (k'+1)): combine-order table
+            u[r] = cmul(u[r], (v2f){t.x, t.y});
+            v[r] = cmul(v[r], (v2f){t.z, t.w});
+        }
+    }
+    dif<R>(u);
+    dif<R>(v);
+    float *out = a.rows_out + row * a.row_stride;
+    const int n = a.m * R;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const v2f x = u[bitrev<R>(q)], y = v[bitrev<R>(q)];
+        const v2f sx = x * x, sy = y * y;
+        const v2f mag = (v2f){__builtin_amdgcn_sqrtf(sx.x + sx.y), __builtin_amdgcn_sqrtf(sy.x + sy.y)};
+        // k even: no wrap inside the pair; write-once rows: non-temporal
+        __builtin_nontemporal_store(mag, reinterpret_cast<v2f *>(out + ((k + q * a.m + n / 2) & (n - 1))));
     }
 }
 
@@ -1743,10 +1804,11 @@ template <class PL, int FMT, int MODE> static hipError_t launch_plan(const StftA
 #endif
     const unsigned grid = (unsigned)(slots * 8);
     StftArgs b = a;
+    if (MODE != 2) { b.dec = 1; b.dec_log2 = 0; }
     // The touches park hop*BYTES per resident workgroup in the XCD's 4 MiB L2 for most of a row time.  Past half of
     // it they push out the rows being transformed and every line is fetched twice (seen at overlap 0: FETCH_SIZE x2,
     // 19 % slower).  Plans with several workgroups per CU hide the miss behind each other and gain nothing (measured).
-    b.prefetch = (plan_addtid<PL>() && slots * (int64_t)a.hop * Sample<FMT>::BYTES <= (2 << 20)) ? 1 : 0;
+    b.prefetch = (MODE != 2 && plan_addtid<PL>() && slots * (int64_t)a.hop * Sample<FMT>::BYTES <= (2 << 20)) ? 1 : 0;
     b.stagger = 0;
 #ifdef RO_DIAG_KNOBS
     if (const int force = env_knob("RO_PREFETCH", -1); force >= 0) b.prefetch = force;
@@ -1769,6 +1831,16 @@ using Plan256   = Plan<  256,   64,  4,  4,  4, 4, false>;
 template <class PL> static hipError_t launch_fmt(const StftArgs &a, int fmt, hipStream_t s)
 {
     const bool spec = a.spec_out != nullptr;
+    if (a.dec > 1) {                                   // sub-transforms of a large transform: decimated in, spectra out
+        // (not for the 1024-thread N = 32768 plan: with unpaired loads its window coefficients take 32 registers
+        // and it spills; big_split never asks for it)
+        if constexpr (PL::N <= 16384) {
+            if (!spec) return hipErrorInvalidValue;
+            if (fmt == RO_FMT_F32) return launch_plan<PL, RO_FMT_F32, 2>(a, s);
+            if (fmt == RO_FMT_I16) return launch_plan<PL, RO_FMT_I16, 2>(a, s);
+        }
+        return hipErrorInvalidValue;
+    }
     if (fmt == RO_FMT_F32) return spec ? launch_plan<PL, RO_FMT_F32, 1>(a, s) : launch_plan<PL, RO_FMT_F32, 0>(a, s);
     if (fmt == RO_FMT_I16) return spec ? launch_plan<PL, RO_FMT_I16, 1>(a, s) : launch_plan<PL, RO_FMT_I16, 0>(a, s);
     return hipErrorInvalidValue;
@@ -1965,6 +2037,37 @@ hipError_t launch_big_pass(int radix, bool first, bool last, int fmt, const BigA
         }
     }
     return hipErrorInvalidValue;
+}
+
+// bins = dec x sub_bins: radix 16 on top of the single-pass plans where the size allows (radix 32 for 2^20)
+bool big_split(int bins, int *sub_bins, int *dec)
+{
+    if (!big_supported(bins)) return false;
+    // The smallest decimation the single-pass plans allow: phase r of a row reads every dec-th sample, so one of its
+    // wave-loads touches dec times the cache lines of a contiguous one (measured at 65536: 16 x 4096 0.33 us per row
+    // in the first pass, TA-bound).  2^20 would need 32 x 32768 (the one plan without a decimated form: unpaired loads
+    // make it spill) and stays on the multi-pass kernels.
+    const int d = bins / 16384;                                   // 65536 = 4 x 16384 ... 524288 = 32 x 16384
+    if (d > 32) return false;
+    *dec = d;
+    *sub_bins = bins / d;
+    return stft_supported(*sub_bins);
+}
+
+hipError_t launch_combine(const CombineArgs &a, hipStream_t s)
+{
+    if (a.rows <= 0) return hipSuccess;
+    const int64_t blocks = (a.rows * (int64_t)(a.m / 2) + 255) / 256;
+    if (blocks > 0x7fffffff) return hipErrorInvalidValue;
+    switch (a.dec) {
+    case 2:  hipLaunchKernelGGL(combine_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+    case 4:  hipLaunchKernelGGL(combine_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+    case 8:  hipLaunchKernelGGL(combine_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+    case 16: hipLaunchKernelGGL(combine_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+    case 32: hipLaunchKernelGGL(combine_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 int f64_radices(int bins, int radices[8])

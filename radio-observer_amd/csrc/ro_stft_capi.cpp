@@ -19,6 +19,11 @@
 #include "../../include/ro_stft.h"
 #include "ro_kernels.h"
 
+// scratch of the two-pass large transforms (sub-spectra between the two kernels), MiB
+#ifndef RO_SPEC_SCRATCH_MB
+#define RO_SPEC_SCRATCH_MB 2048
+#endif
+
 namespace {
 
 thread_local std::string g_error;
@@ -179,6 +184,13 @@ struct ro_stft {
     unsigned ln_calls = 0;
     float2 *d_scratch[2] = {nullptr, nullptr};
     int64_t scratch_rows = 0;
+    // ... in two passes where the size allows (bins = dec x sub_bins): tables of the sub-transform, the window cut
+    // into `dec` decimated tables, one scratch block of sub-spectra
+    int     sub_bins = 0, dec = 0;
+    float  *d_window_dec = nullptr;
+    float2 *d_tw_combine = nullptr;    // [dec][sub_bins]: exp(-2 pi i r k' / bins)
+    float2 *d_spec = nullptr;
+    int64_t spec_rows = 0;
 
     // strict precision (RO_PRECISION_F64): double twiddle table + two complex-double scratch blocks
     bool     f64 = false;
@@ -350,6 +362,39 @@ int launch_transform(ro_stft *h, const void *d_iq, int format, int64_t first_row
     if (!h->big) {
         ro::StftArgs a = make_stft_args(h, d_iq, first_row, rows, d_rows, row_stride, d_tile, d_records);
         HIP_TRY(ro::launch_stft(h->bins, format, a, s));
+        return RO_OK;
+    }
+    if (h->dec > 1) {
+        // two passes: `dec` decimated sub-transforms per row (spectra to scratch), then the radix-`dec` combine, in
+        // chunks of up to 2 GiB of sub-spectra (8 B per bin).  Chunks small enough to stay in the 256 MiB Infinity
+        // Cache between the two kernels were measured SLOWER (0.121 / 0.130 / 0.141 / 0.144 of the HBM peak with
+        // 96 / 192 / 768 / 2048 MiB at bins = 65536): two launches per 384 rows cost more than the cache gives back.
+        if (!h->d_spec) {
+            h->spec_rows = std::max<int64_t>(1, ((int64_t)RO_SPEC_SCRATCH_MB << 20) / ((int64_t)h->bins * 8));
+            HIP_TRY(hipMalloc(&h->d_spec, (size_t)h->spec_rows * h->bins * sizeof(float2)));
+        }
+        int log2 = 0;
+        while ((1 << log2) < h->dec) ++log2;
+        for (int64_t done = 0; done < rows; done += h->spec_rows) {
+            const int64_t n = std::min(h->spec_rows, rows - done);
+            ro::StftArgs a = make_stft_args(h, d_iq, first_row + done, n * h->dec, nullptr, 0);
+            a.window = h->d_window_dec;
+            a.window_k = h->d_window_dec;
+            a.spec_out = h->d_spec;
+            a.spec_stride = h->sub_bins;
+            a.dec = h->dec;
+            a.dec_log2 = log2;
+            HIP_TRY(ro::launch_stft(h->sub_bins, format, a, s));
+            ro::CombineArgs c{};
+            c.spec = h->d_spec;
+            c.tw = h->d_tw_combine;
+            c.rows_out = d_rows + done * row_stride;
+            c.rows = n;
+            c.row_stride = row_stride;
+            c.m = h->sub_bins;
+            c.dec = h->dec;
+            HIP_TRY(ro::launch_combine(c, s));
+        }
         return RO_OK;
     }
     if (!h->d_scratch[0]) {
@@ -757,8 +802,10 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
         build_window(cfg->window_kind, h->bins, h->window.data());
     h->big = ro::big_supported(h->bins);
     h->f64 = cfg->precision == RO_PRECISION_F64;
-    std::vector<float2> tw = h->big ? std::vector<float2>() : build_twiddles(h->bins);
-    if (!h->big && (int)tw.size() != ro::stft_twiddle_count(h->bins)) {
+    if (h->big && !ro::big_split(h->bins, &h->sub_bins, &h->dec)) h->sub_bins = h->dec = 0;
+    const int plan_bins = h->big ? h->sub_bins : h->bins;           // whose stage tables this handle needs (0: none)
+    std::vector<float2> tw = plan_bins ? build_twiddles(plan_bins) : std::vector<float2>();
+    if (plan_bins && (int)tw.size() != ro::stft_twiddle_count(plan_bins)) {
         delete h;
         return fail(RO_ERR_STATE, "internal: twiddle table size mismatch");
     }
@@ -790,10 +837,10 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
     }
     if (!tw.empty())
         CREATE_TRY(hipMemcpy(h->d_twiddles, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice));
-    if (!h->big) {
-        const int units = ro::stft_packed_twiddle_count(h->bins);
+    if (plan_bins) {
+        const int units = ro::stft_packed_twiddle_count(plan_bins);
         std::vector<float4> pk((size_t)std::max(units, 1));
-        if (units > 0) ro::stft_pack_twiddles(h->bins, tw.data(), pk.data());
+        if (units > 0) ro::stft_pack_twiddles(plan_bins, tw.data(), pk.data());
         CREATE_TRY(hipMalloc(&h->d_twiddles_k, sizeof(float4) * pk.size()));
         CREATE_TRY(hipMemcpy(h->d_twiddles_k, pk.data(), sizeof(float4) * pk.size(), hipMemcpyHostToDevice));
     }
@@ -801,6 +848,24 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
         std::vector<double2> full = build_full_twiddles_f64(h->bins);
         CREATE_TRY(hipMalloc(&h->d_tw_f64, sizeof(double2) * full.size()));
         CREATE_TRY(hipMemcpy(h->d_tw_f64, full.data(), sizeof(double2) * full.size(), hipMemcpyHostToDevice));
+    }
+    if (h->big && h->dec > 1) {
+        // the window cut into `dec` decimated tables: table r holds w[r + dec m], m < sub_bins
+        std::vector<float> wd((size_t)h->bins);
+        for (int r = 0; r < h->dec; ++r)
+            for (int m = 0; m < h->sub_bins; ++m) wd[(size_t)r * h->sub_bins + m] = h->window[(size_t)r + (size_t)h->dec * m];
+        CREATE_TRY(hipMalloc(&h->d_window_dec, sizeof(float) * wd.size()));
+        CREATE_TRY(hipMemcpy(h->d_window_dec, wd.data(), sizeof(float) * wd.size(), hipMemcpyHostToDevice));
+        // the combine's twiddles in the order it reads them, each rounded once from long double
+        std::vector<float2> tc((size_t)h->bins);
+        const long double two_pi = 8.0L * atanl(1.0L);
+        for (int r = 0; r < h->dec; ++r)
+            for (int k = 0; k < h->sub_bins; ++k) {
+                const long double ang = -two_pi * (long double)((long long)r * k) / (long double)h->bins;
+                tc[(size_t)r * h->sub_bins + k] = make_float2((float)cosl(ang), (float)sinl(ang));
+            }
+        CREATE_TRY(hipMalloc(&h->d_tw_combine, sizeof(float2) * tc.size()));
+        CREATE_TRY(hipMemcpy(h->d_tw_combine, tc.data(), sizeof(float2) * tc.size(), hipMemcpyHostToDevice));
     }
     if (h->big) {
         std::vector<float2> full = build_full_twiddles(h->bins);
@@ -839,6 +904,9 @@ extern "C" int ro_stft_destroy(ro_stft_t *h)
     }
     for (Batch *b : h->batch_pool) destroy_batch(b);
     if (h->d_tw_big) (void)hipFree(h->d_tw_big);
+    if (h->d_window_dec) (void)hipFree(h->d_window_dec);
+    if (h->d_tw_combine) (void)hipFree(h->d_tw_combine);
+    if (h->d_spec) (void)hipFree(h->d_spec);
     if (h->d_tw_f64) (void)hipFree(h->d_tw_f64);
     for (int i = 0; i < 2; ++i)
         if (h->d_scratch_d[i]) (void)hipFree(h->d_scratch_d[i]);
