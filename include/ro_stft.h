@@ -97,7 +97,11 @@ typedef struct ro_stft_config {
                                    /* stream (an RCCL collective) make progress.     */
     int32_t      precision;        /* RO_PRECISION_* (ABI 2; a caller that passes the */
                                    /* ABI-1 struct_size gets RO_PRECISION_F32)        */
-    int32_t      reserved0;        /* must be 0 (keeps the struct free of padding)   */
+    int32_t      tile_ln;          /* 1: with the tile, also its natural log and the  */
+                                   /* per-row min / max of that log (the offline      */
+                                   /* viewer's FN_LOG and colour range, fits2png:46,  */
+                                   /* :476-477) straight from the transform; needs    */
+                                   /* tile_cols > 0                                   */
 } ro_stft_config_t;
 
 typedef struct ro_stft ro_stft_t;
@@ -171,6 +175,21 @@ int ro_stft_run_resident(ro_stft_t *h, const void *d_iq, int format, int64_t sam
                          float *d_rows, int64_t row_stride,
                          float *d_tile, ro_scan_record_t *d_records, void *stream);
 
+/* ro_stft_run_resident plus the viewer's log image of the tile, produced by the transform itself (tile_ln = 1):
+ *   d_ln_tile    device, rows x tile_cols floats: logf(pixel) of every tile pixel (-inf for a zero pixel)
+ *   d_ln_minmax  device, rows x 2 floats: min and max of that row's log over its NON-ZERO pixels (+inf, -inf for a
+ *                row without any) -- the image's colour range (fits2png:476-477) is the min / max over its rows,
+ *                and ro_ln_levels turns log values into the viewer's grey levels once that range is known
+ * d_ln_minmax may be NULL.  For bins = 32768 the log is taken in the transform's epilogue, on the magnitudes still in LDS;
+ * for the other sizes by a small kernel over the tile. */
+int ro_stft_run_resident_ln(ro_stft_t *h, const void *d_iq, int format, int64_t samples,
+                            int64_t first_row, int64_t rows, float *d_rows, int64_t row_stride,
+                            float *d_tile, float *d_ln_tile, float *d_ln_minmax,
+                            ro_scan_record_t *d_records, void *stream);
+/* The viewer's grey levels of log values given the image's range: level = (uint8)((ln - mn) / (mx - mn) * 255) in
+ * float32 arithmetic, truncating; -inf (a zero pixel) and a flat image give 0 (fits2png:444-445, :495-497).  Host. */
+int ro_ln_levels(const float *ln, int64_t count, float mn, float mx, uint8_t *levels_out);
+
 /* The complex spectra themselves instead of their magnitudes: what fftw_execute leaves in out_
  * (src/FFTBackend.cpp:236) and hands to the protected hook FFTBackend::processFFT(const fftw_complex *data,
  * int size, DataInfo, int rawMark) (src/FFTBackend.h:104) -- bin k of row r at d_spectra[r * stride + k] as
@@ -231,6 +250,10 @@ int ro_stft_flush(ro_stft_t *h, int64_t *rows_ready);
 int ro_stft_fetch(ro_stft_t *h, int64_t max_rows, int first_col, int cols,
                   float *rows_out, ro_scan_record_t *records_out,
                   int64_t *first_row_index, int64_t *rows_got);
+/* ro_stft_fetch for a handle with tile_ln = 1: the whole tile of each row, its log, the row's min / max of the log
+ * (2 floats) and the scan record -- any of the four may be NULL. */
+int ro_stft_fetch_ln(ro_stft_t *h, int64_t max_rows, float *tile_out, float *ln_out, float *minmax_out,
+                     ro_scan_record_t *records_out, int64_t *first_row_index, int64_t *rows_got);
 /* FFTBackend::startStream's reset of inMark_/info_ (src/FFTBackend.cpp:148-153) */
 int ro_stft_reset(ro_stft_t *h);
 /* Per-call timing, the counterpart of FFTBackend's three RunningAverage2 counters and logProcessingTimes /

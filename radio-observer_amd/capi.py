@@ -55,7 +55,7 @@ class Config(C.Structure):
                 ("iq_phase_shift", C.c_int32), ("device", C.c_int32), ("max_batch_rows", C.c_int32),
                 ("enable_scan", C.c_int32), ("bands", Bands), ("tile_first_col", C.c_int32),
                 ("tile_cols", C.c_int32), ("spare_cus_per_xcd", C.c_int32), ("precision", C.c_int32),
-                ("reserved0", C.c_int32)]
+                ("tile_ln", C.c_int32)]
 
 
 _EXPORTS = {
@@ -85,6 +85,12 @@ _EXPORTS = {
     "ro_stft_set_bands": (C.c_int, [C.c_void_p, C.POINTER(Bands)]),
     "ro_stft_run_resident": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64,
                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ro_stft_run_resident_ln": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64,
+                                          C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]),
+    "ro_ln_levels": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p]),
+    "ro_stft_fetch_ln": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ro_stft_spectra_resident": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64,
                                            C.c_void_p, C.c_int64, C.c_void_p]),
     "ro_stft_scan_resident": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
@@ -201,6 +207,14 @@ def stitch_rows(gathered, total_rows, world):
     return out
 
 
+def ln_levels(ln, mn, mx):
+    """the viewer's grey levels of log values given the image's range -- ro_ln_levels (host)"""
+    a = np.ascontiguousarray(ln, dtype=np.float32)
+    out = np.empty(a.shape, np.uint8)
+    _check(library().ro_ln_levels(C.c_void_p(a.ctypes.data), a.size, float(mn), float(mx), C.c_void_p(out.ctypes.data)))
+    return out
+
+
 def bins_supported(bins):
     return bool(library().ro_bins_supported(bins))
 
@@ -227,7 +241,7 @@ class Stft:
 
     def __init__(self, bins=32768, overlap=0, sample_rate=48000, window=RO_WINDOW_NUTTALL,
                  window_table=None, iq_gain=0.0, iq_phase_shift=0, device=0, max_batch_rows=0,
-                 bands=None, tile=None, spare_cus_per_xcd=0, precision=RO_PRECISION_F32):
+                 bands=None, tile=None, spare_cus_per_xcd=0, precision=RO_PRECISION_F32, tile_ln=False):
         cfg = Config()
         cfg.struct_size = C.sizeof(Config)
         cfg.bins, cfg.overlap, cfg.sample_rate = bins, overlap, sample_rate
@@ -250,6 +264,7 @@ class Stft:
             cfg.tile_first_col, cfg.tile_cols = tile
         cfg.spare_cus_per_xcd = spare_cus_per_xcd
         cfg.precision = precision
+        cfg.tile_ln = 1 if tile_ln else 0
         self._h = C.c_void_p()
         _check(library().ro_stft_create(C.byref(cfg), C.byref(self._h)))
         self.bins = bins
@@ -296,6 +311,28 @@ class Stft:
         _check(library().ro_stft_run_resident(self._h, _ptr(d_iq), fmt, samples, first_row, rows,
                                               _ptr(d_rows), row_stride or self.bins, _ptr(d_tile),
                                               _ptr(d_records), _ptr(stream)))
+
+    def run_resident_ln(self, d_iq, fmt, samples, first_row, rows, d_rows, d_tile, d_ln=None, d_minmax=None,
+                        row_stride=None, d_records=None, stream=None):
+        """run_resident + the log of the tile and the rows' min / max of it (handle created with tile_ln=True)"""
+        _check(library().ro_stft_run_resident_ln(self._h, _ptr(d_iq), fmt, samples, first_row, rows, _ptr(d_rows),
+                                                 row_stride or self.bins, _ptr(d_tile), _ptr(d_ln), _ptr(d_minmax),
+                                                 _ptr(d_records), _ptr(stream)))
+
+    def fetch_ln(self, max_rows):
+        """(first_row, tile, ln, minmax[rows, 2], records or None) of up to max_rows rows (tile_ln handles)"""
+        cols = self.tile[1]
+        tile = np.empty((max_rows, cols), np.float32)
+        ln = np.empty((max_rows, cols), np.float32)
+        mm = np.empty((max_rows, 2), np.float32)
+        recs = np.empty(max_rows, dtype=SCAN_DTYPE) if self.scan_enabled else None
+        first, got = C.c_int64(), C.c_int64()
+        _check(library().ro_stft_fetch_ln(self._h, max_rows, C.c_void_p(tile.ctypes.data), C.c_void_p(ln.ctypes.data),
+                                          C.c_void_p(mm.ctypes.data),
+                                          C.c_void_p(recs.ctypes.data) if recs is not None else None,
+                                          C.byref(first), C.byref(got)))
+        g = got.value
+        return first.value, tile[:g], ln[:g], mm[:g], (recs[:g] if recs is not None else None)
 
     def spectra_resident(self, d_iq, fmt, samples, first_row, rows, d_spectra, stride=None, stream=None):
         """complex spectra (rows x stride x {re, im} float32, bin k at element k) instead of magnitudes"""

@@ -38,6 +38,10 @@ struct StftArgs {
     // fused band tile: columns [tile_first, +tile_cols) of every row, compact (rows x tile_cols), or nullptr
     float        *tile_out;
     int           tile_first, tile_cols;
+    // ... and its log (ln_out: rows x tile_cols) with the two tile waves' partial min / max of it (ln_part: rows x 4
+    // floats = {min, max} of the first and of the second half of the columns); launch_ln_finish folds them per row
+    float        *ln_out;
+    float        *ln_part;
 };
 
 struct TileArgs {
@@ -134,5 +138,8 @@ hipError_t launch_stft(int bins, int fmt, const StftArgs &a, hipStream_t s);
 hipError_t launch_scan(const ScanArgs &a, hipStream_t s);
 hipError_t launch_tile(const TileArgs &a, hipStream_t s);
 hipError_t launch_ln_tile(const LnArgs &a, hipStream_t s);
+// per-row log of a compact tile + min / max (plans without the fused epilogue), and the fold of the fused partials
+hipError_t launch_ln_rows(const float *tile, float *ln_out, float *minmax, int64_t rows, int cols, hipStream_t s);
+hipError_t launch_ln_finish(const float *ln_part, float *minmax, int64_t rows, hipStream_t s);
 
 }  // namespace ro

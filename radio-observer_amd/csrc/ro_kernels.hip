@@ -1258,7 +1258,32 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
                         const int c0 = wave == TILE_WAVE_A ? 0 : half;
                         const int c1 = wave == TILE_WAVE_A ? (half < tile_cols ? half : tile_cols) : tile_cols;
                         float *dst = a.tile_out + row * (int64_t)tile_cols;
-                        for (int c = c0 + lane; c < c1; c += 64) dst[c] = img(tile_first + c);
+                        if (a.ln_out == nullptr) {
+                            for (int c = c0 + lane; c < c1; c += 64) dst[c] = img(tile_first + c);
+                        } else {
+                            // the viewer's log image of the tile (fits2png:46) and this wave's share of the row's
+                            // min / max over the non-zero pixels (:476-477), while the magnitudes are still in LDS
+                            float *ldst = a.ln_out + row * (int64_t)tile_cols;
+                            unsigned kmin = 0xffffffffu, kmax = 0u;
+                            for (int c = c0 + lane; c < c1; c += 64) {
+                                const float x = img(tile_first + c);
+                                const float l = logf(x);
+                                dst[c] = x;
+                                ldst[c] = l;
+                                if (x != 0.f) {
+                                    const unsigned key = order_key(l);
+                                    kmin = min(kmin, key);
+                                    kmax = max(kmax, key);
+                                }
+                            }
+                            kmin = wave_min_u32(kmin);
+                            kmax = wave_max_u32(kmax);
+                            if (lane == 0) {
+                                float *part = a.ln_part + row * 4 + (wave == TILE_WAVE_A ? 0 : 2);
+                                part[0] = kmin == 0xffffffffu ? __builtin_inff() : key_to_float(kmin);
+                                part[1] = kmax == 0u ? -__builtin_inff() : key_to_float(kmax);
+                            }
+                        }
                     }
                 }
                 // the legs the last level did not request, then the rest of the window coefficients (behind the scan,
@@ -1714,6 +1739,43 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(LnArgs a)
     }
 }
 
+// ln of a compact tile, one wave per row, with the row's min / max over the non-zero pixels: what the fused epilogue
+// of the N = 32768 plan computes from LDS, for the plans without it (and the FP64 mode)
+__global__ __launch_bounds__(256) void ln_rows_kernel(const float *tile, float *ln_out, float *minmax, int64_t rows, int cols)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *src = tile + row * (int64_t)cols;
+    unsigned kmin = 0xffffffffu, kmax = 0u;
+    for (int c = lane; c < cols; c += 64) {
+        const float x = src[c];
+        const float l = logf(x);
+        if (ln_out) ln_out[row * (int64_t)cols + c] = l;
+        if (x != 0.f) {
+            const unsigned key = order_key(l);
+            kmin = min(kmin, key);
+            kmax = max(kmax, key);
+        }
+    }
+    kmin = wave_min_u32(kmin);
+    kmax = wave_max_u32(kmax);
+    if (lane == 0 && minmax) {
+        minmax[2 * row] = kmin == 0xffffffffu ? __builtin_inff() : key_to_float(kmin);
+        minmax[2 * row + 1] = kmax == 0u ? -__builtin_inff() : key_to_float(kmax);
+    }
+}
+
+// fold the two tile waves' partial min / max of the fused epilogue into one pair per row
+__global__ __launch_bounds__(256) void ln_finish_kernel(const float *part, float *minmax, int64_t rows)
+{
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const float4 p = reinterpret_cast<const float4 *>(part)[row];
+    minmax[2 * row] = fminf(p.x, p.z);
+    minmax[2 * row + 1] = fmaxf(p.y, p.w);
+}
+
 constexpr int SCAN_WAVES = 4;         // rows per workgroup
 
 __global__ __launch_bounds__(64 * SCAN_WAVES) void scan_kernel(ScanArgs a)
@@ -2137,6 +2199,20 @@ hipError_t launch_ln_tile(const LnArgs &a, hipStream_t s)
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(ln_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
     hipLaunchKernelGGL(ln_quant_kernel, dim3((unsigned)(a.u8_out ? blocks : 1)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_ln_rows(const float *tile, float *ln_out, float *minmax, int64_t rows, int cols, hipStream_t s)
+{
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ln_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, tile, ln_out, minmax, rows, cols);
+    return hipGetLastError();
+}
+
+hipError_t launch_ln_finish(const float *ln_part, float *minmax, int64_t rows, hipStream_t s)
+{
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ln_finish_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, ln_part, minmax, rows);
     return hipGetLastError();
 }
 

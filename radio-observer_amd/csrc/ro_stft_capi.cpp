@@ -120,7 +120,9 @@ std::vector<double2> build_full_twiddles_f64(int bins)
 struct Batch {
     int64_t first_row = 0;
     int64_t rows = 0;
-    float *data = nullptr;                     // capacity_rows x bins, pinned
+    float *data = nullptr;                     // capacity_rows x out_cols, pinned
+    float *ln = nullptr;                       // capacity_rows x out_cols (tile_ln), pinned
+    float *minmax = nullptr;                   // capacity_rows x 2 (tile_ln), pinned
     ro_scan_record_t *records = nullptr;       // capacity_rows, pinned
     int64_t capacity_rows = 0;
     int64_t consumed = 0;                      // rows already fetched
@@ -155,6 +157,8 @@ struct ro_stft {
         void  *d_iq = nullptr;                 // batch input  ((batch_rows-1)*hop + bins samples, 8 B each at most)
         float *d_rows = nullptr;               // batch output (batch_rows x bins)
         float *d_tile = nullptr;               // batch_rows x tile_cols when a tile is configured
+        float *d_ln = nullptr;                 // ... its log and the rows' min / max of it (tile_ln)
+        float *d_minmax = nullptr;
         ro_scan_record_t *d_records = nullptr;
         void  *h_in = nullptr;                 // pinned upload staging
         hipEvent_t uploaded = nullptr;         // H2D of this slot done (h_in reusable, kernels may start)
@@ -191,6 +195,10 @@ struct ro_stft {
     float2 *d_tw_combine = nullptr;    // [dec][sub_bins]: exp(-2 pi i r k' / bins)
     float2 *d_spec = nullptr;
     int64_t spec_rows = 0;
+
+    // tile_ln: partial min / max of the fused epilogue's two tile waves (rows x 4 floats), grown on demand
+    float  *d_ln_part = nullptr;
+    int64_t ln_part_rows = 0;
 
     // strict precision (RO_PRECISION_F64): double twiddle table + two complex-double scratch blocks
     bool     f64 = false;
@@ -241,7 +249,7 @@ int validate_resident(const ro_stft *h, const void *d_iq, int format, int64_t sa
 
 ro::StftArgs make_stft_args(const ro_stft *h, const void *d_iq, int64_t first_row, int64_t rows,
                             float *d_rows, int64_t row_stride, float *d_tile = nullptr,
-                            ro_scan_record_t *d_records = nullptr)
+                            ro_scan_record_t *d_records = nullptr, float *d_ln = nullptr)
 {
     ro::StftArgs a{};
     a.iq = d_iq;
@@ -268,6 +276,8 @@ ro::StftArgs make_stft_args(const ro_stft *h, const void *d_iq, int64_t first_ro
         a.tile_out = d_tile;
         a.tile_first = h->cfg.tile_first_col;
         a.tile_cols = h->cfg.tile_cols;
+        a.ln_out = d_tile ? d_ln : nullptr;
+        a.ln_part = h->d_ln_part;
     }
     return a;
 }
@@ -307,14 +317,31 @@ ro::ScanArgs make_scan_args(const ro_stft *h, const float *d_rows, int64_t row_s
 // d_tile / d_records (either may be null): produced here too, by the transform's own epilogue where the plan fuses them
 // (N = 32768), by tile_kernel / scan_kernel behind it otherwise
 int launch_transform(ro_stft *h, const void *d_iq, int format, int64_t first_row, int64_t rows, float *d_rows,
-                     int64_t row_stride, hipStream_t s, float *d_tile = nullptr, ro_scan_record_t *d_records = nullptr);
+                     int64_t row_stride, hipStream_t s, float *d_tile = nullptr, ro_scan_record_t *d_records = nullptr,
+                     float *d_ln = nullptr);
 
+// d_ln / d_minmax: the tile's log and the rows' min / max of it (tile_ln); need d_tile
 int launch_tile_and_scan(ro_stft *h, const float *d_rows, int64_t row_stride, int64_t rows, float *d_tile,
-                         ro_scan_record_t *d_records, hipStream_t s)
+                         ro_scan_record_t *d_records, hipStream_t s, float *d_ln = nullptr, float *d_minmax = nullptr)
 {
-    if (!h->f64 && ro::stft_fuses_scan(h->bins)) return RO_OK;      // already written by the transform
+    const bool want_ln = d_tile && (d_ln || d_minmax);
+    if (!h->f64 && ro::stft_fuses_scan(h->bins)) {                  // tile, log and records written by the transform
+        if (want_ln && d_minmax) HIP_TRY(ro::launch_ln_finish(h->d_ln_part, d_minmax, rows, s));
+        return RO_OK;
+    }
     if (d_tile) HIP_TRY(ro::launch_tile(make_tile_args(h, d_rows, row_stride, rows, d_tile), s));
+    if (want_ln) HIP_TRY(ro::launch_ln_rows(d_tile, d_ln, d_minmax, rows, h->cfg.tile_cols, s));
     if (d_records) HIP_TRY(ro::launch_scan(make_scan_args(h, d_rows, row_stride, rows, d_records), s));
+    return RO_OK;
+}
+
+// scratch of the fused log: the two tile waves' partial min / max, 4 floats per row of the launch
+int ensure_ln_part(ro_stft *h, int64_t rows)
+{
+    if (rows <= h->ln_part_rows) return RO_OK;
+    if (h->d_ln_part) { (void)hipDeviceSynchronize(); (void)hipFree(h->d_ln_part); h->d_ln_part = nullptr; h->ln_part_rows = 0; }
+    HIP_TRY(hipMalloc(&h->d_ln_part, (size_t)rows * 4 * sizeof(float)));
+    h->ln_part_rows = rows;
     return RO_OK;
 }
 
@@ -356,11 +383,15 @@ int launch_transform_f64(ro_stft *h, const void *d_iq, int format, int64_t first
 }
 
 int launch_transform(ro_stft *h, const void *d_iq, int format, int64_t first_row, int64_t rows, float *d_rows,
-                     int64_t row_stride, hipStream_t s, float *d_tile, ro_scan_record_t *d_records)
+                     int64_t row_stride, hipStream_t s, float *d_tile, ro_scan_record_t *d_records, float *d_ln)
 {
     if (h->f64) return launch_transform_f64(h, d_iq, format, first_row, rows, d_rows, row_stride, s);
     if (!h->big) {
-        ro::StftArgs a = make_stft_args(h, d_iq, first_row, rows, d_rows, row_stride, d_tile, d_records);
+        if (d_tile && d_ln && ro::stft_fuses_scan(h->bins)) {
+            int rc = ensure_ln_part(h, rows);
+            if (rc != RO_OK) return rc;
+        }
+        ro::StftArgs a = make_stft_args(h, d_iq, first_row, rows, d_rows, row_stride, d_tile, d_records, d_ln);
         HIP_TRY(ro::launch_stft(h->bins, format, a, s));
         return RO_OK;
     }
@@ -443,9 +474,16 @@ Batch *acquire_batch(ro_stft *h)
                       hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&b->records), (size_t)b->capacity_rows * sizeof(ro_scan_record_t),
                       hipHostMallocDefault) != hipSuccess ||
+        (h->cfg.tile_ln &&
+         (hipHostMalloc(reinterpret_cast<void **>(&b->ln), (size_t)b->capacity_rows * h->out_cols * sizeof(float),
+                        hipHostMallocDefault) != hipSuccess ||
+          hipHostMalloc(reinterpret_cast<void **>(&b->minmax), (size_t)b->capacity_rows * 2 * sizeof(float),
+                        hipHostMallocDefault) != hipSuccess)) ||
         hipEventCreateWithFlags(&b->done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&b->k0) != hipSuccess || hipEventCreate(&b->k1) != hipSuccess) {
         if (b->data) (void)hipHostFree(b->data);
+        if (b->ln) (void)hipHostFree(b->ln);
+        if (b->minmax) (void)hipHostFree(b->minmax);
         if (b->records) (void)hipHostFree(b->records);
         if (b->done) (void)hipEventDestroy(b->done);
         if (b->k0) (void)hipEventDestroy(b->k0);
@@ -467,6 +505,8 @@ void release_batch(ro_stft *h, Batch *b)
 void destroy_batch(Batch *b)
 {
     if (b->data) (void)hipHostFree(b->data);
+    if (b->ln) (void)hipHostFree(b->ln);
+    if (b->minmax) (void)hipHostFree(b->minmax);
     if (b->records) (void)hipHostFree(b->records);
     if (b->done) (void)hipEventDestroy(b->done);
     if (b->k0) (void)hipEventDestroy(b->k0);
@@ -480,6 +520,8 @@ void free_stream_slots(ro_stft *h)
         if (sl.d_iq) (void)hipFree(sl.d_iq);
         if (sl.d_rows) (void)hipFree(sl.d_rows);
         if (sl.d_tile) (void)hipFree(sl.d_tile);
+        if (sl.d_ln) (void)hipFree(sl.d_ln);
+        if (sl.d_minmax) (void)hipFree(sl.d_minmax);
         if (sl.d_records) (void)hipFree(sl.d_records);
         if (sl.h_in) (void)hipHostFree(sl.h_in);
         if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
@@ -512,6 +554,9 @@ int ensure_stream_slots(ro_stft *h)
             ok(hipEventCreateWithFlags(&sl.drained, hipEventDisableTiming));
         if (h->cfg.tile_cols > 0)
             ok(hipMalloc(&sl.d_tile, (size_t)h->batch_rows * h->cfg.tile_cols * sizeof(float)));
+        if (h->cfg.tile_ln)
+            ok(hipMalloc(&sl.d_ln, (size_t)h->batch_rows * h->cfg.tile_cols * sizeof(float))) &&
+                ok(hipMalloc(&sl.d_minmax, (size_t)h->batch_rows * 2 * sizeof(float)));
     }
     if (e != hipSuccess) {
         free_stream_slots(h);
@@ -552,8 +597,9 @@ int run_stream_batch(ro_stft *h, int64_t rows)
         step(hipEventRecord(b->k0, h->stream), "hipEventRecord");
     if (rc == RO_OK) {
         ro_scan_record_t *recs = h->cfg.enable_scan ? sl.d_records : nullptr;
-        rc = launch_transform(h, sl.d_iq, h->stage_fmt, 0, rows, sl.d_rows, h->bins, h->stream, sl.d_tile, recs);
-        if (rc == RO_OK) rc = launch_tile_and_scan(h, sl.d_rows, h->bins, rows, sl.d_tile, recs, h->stream);
+        rc = launch_transform(h, sl.d_iq, h->stage_fmt, 0, rows, sl.d_rows, h->bins, h->stream, sl.d_tile, recs, sl.d_ln);
+        if (rc == RO_OK)
+            rc = launch_tile_and_scan(h, sl.d_rows, h->bins, rows, sl.d_tile, recs, h->stream, sl.d_ln, sl.d_minmax);
     }
     step(hipEventRecord(b->k1, h->stream), "hipEventRecord") && step(hipEventRecord(sl.computed, h->stream), "hipEventRecord");
     // download (s_out): only the columns somebody asked for travel -- the tile when one is configured
@@ -565,6 +611,12 @@ int run_stream_batch(ro_stft *h, int64_t rows)
         if (h->cfg.enable_scan)
             step(hipMemcpyAsync(b->records, sl.d_records, (size_t)rows * sizeof(ro_scan_record_t), hipMemcpyDeviceToHost,
                                 h->s_out), "download");
+        if (h->cfg.tile_ln) {
+            step(hipMemcpyAsync(b->ln, sl.d_ln, (size_t)rows * h->out_cols * sizeof(float), hipMemcpyDeviceToHost, h->s_out),
+                 "download");
+            step(hipMemcpyAsync(b->minmax, sl.d_minmax, (size_t)rows * 2 * sizeof(float), hipMemcpyDeviceToHost, h->s_out),
+                 "download");
+        }
     }
     step(hipEventRecord(sl.drained, h->s_out), "hipEventRecord") && step(hipEventRecord(b->done, h->s_out), "hipEventRecord");
     if (rc != RO_OK) {
@@ -749,7 +801,8 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
     cfg = &cfg_full;
     if (cfg->precision != RO_PRECISION_F32 && cfg->precision != RO_PRECISION_F64)
         return fail(RO_ERR_INVALID, "unknown precision %d", cfg->precision);
-    if (cfg->reserved0 != 0) return fail(RO_ERR_INVALID, "reserved0 must be 0");
+    if (cfg->tile_ln != 0 && cfg->tile_ln != 1) return fail(RO_ERR_INVALID, "tile_ln must be 0 or 1");
+    if (cfg->tile_ln && cfg->tile_cols <= 0) return fail(RO_ERR_INVALID, "tile_ln needs a tile (tile_cols > 0)");
     if (!ro::stft_supported(cfg->bins) && !ro::big_supported(cfg->bins))
         return fail(RO_ERR_UNSUPPORTED, "bins = %d has no kernel (powers of two 256..1048576)", cfg->bins);
     if (cfg->iq_phase_shift != 0)
@@ -908,6 +961,7 @@ extern "C" int ro_stft_destroy(ro_stft_t *h)
     if (h->d_tw_combine) (void)hipFree(h->d_tw_combine);
     if (h->d_spec) (void)hipFree(h->d_spec);
     if (h->d_tw_f64) (void)hipFree(h->d_tw_f64);
+    if (h->d_ln_part) (void)hipFree(h->d_ln_part);
     for (int i = 0; i < 2; ++i)
         if (h->d_scratch_d[i]) (void)hipFree(h->d_scratch_d[i]);
     for (int i = 0; i < 2; ++i)
@@ -984,6 +1038,40 @@ extern "C" int ro_stft_run_resident(ro_stft_t *h, const void *d_iq, int format, 
     if (rc != RO_OK) return rc;
     h->stat_launches += 1;
     h->stat_rows += rows;
+    return RO_OK;
+}
+
+extern "C" int ro_stft_run_resident_ln(ro_stft_t *h, const void *d_iq, int format, int64_t samples, int64_t first_row,
+                                       int64_t rows, float *d_rows, int64_t row_stride, float *d_tile, float *d_ln_tile,
+                                       float *d_ln_minmax, ro_scan_record_t *d_records, void *stream)
+{
+    int rc = validate_resident(h, d_iq, format, samples, first_row, rows, d_rows, row_stride, d_tile, d_records);
+    if (rc != RO_OK || rows == 0) return rc;
+    if (!h->cfg.tile_ln) return fail(RO_ERR_STATE, "this handle was not created with tile_ln");
+    if (!d_tile) return fail(RO_ERR_INVALID, "the log image is cut from the tile: d_tile is required");
+    if (d_ln_minmax && !d_ln_tile) return fail(RO_ERR_INVALID, "the range comes with the log image: pass d_ln_tile too");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    // the fused epilogue always writes the log when asked for its range (the partial min / max come with it)
+    float *ln = d_ln_tile;
+    rc = launch_transform(h, d_iq, format, first_row, rows, d_rows, row_stride, s, d_tile, d_records, ln);
+    if (rc != RO_OK) return rc;
+    rc = launch_tile_and_scan(h, d_rows, row_stride, rows, d_tile, d_records, s, ln, d_ln_minmax);
+    if (rc != RO_OK) return rc;
+    h->stat_launches += 1;
+    h->stat_rows += rows;
+    return RO_OK;
+}
+
+extern "C" int ro_ln_levels(const float *ln, int64_t count, float mn, float mx, uint8_t *levels_out)
+{
+    if (count < 0 || (count > 0 && (!ln || !levels_out))) return fail(RO_ERR_INVALID, "ro_ln_levels: bad arguments");
+    const float span = mx - mn;
+    for (int64_t i = 0; i < count; ++i) {
+        // float32 throughout, like numpy in the viewer (fits2png:444-445); -inf = a zero pixel (dropped there)
+        const float level = (ln[i] - mn) / span * 255.f;
+        levels_out[i] = (std::isfinite(ln[i]) && span > 0.f) ? (uint8_t)(int)level : (uint8_t)0;
+    }
     return RO_OK;
 }
 
@@ -1226,6 +1314,42 @@ extern "C" int ro_stft_fetch(ro_stft_t *h, int64_t max_rows, int first_col, int 
     h->timing.fetch_calls += 1;
     h->fetch_ms_sum += dt;
     h->timing.fetch_ms_max = std::max(h->timing.fetch_ms_max, dt);
+    return RO_OK;
+}
+
+extern "C" int ro_stft_fetch_ln(ro_stft_t *h, int64_t max_rows, float *tile_out, float *ln_out, float *minmax_out,
+                                ro_scan_record_t *records_out, int64_t *first_row_index, int64_t *rows_got)
+{
+    if (!h || !rows_got) return fail(RO_ERR_INVALID, "null argument");
+    if (!h->cfg.tile_ln) return fail(RO_ERR_STATE, "this handle was not created with tile_ln");
+    if (max_rows < 0) return fail(RO_ERR_INVALID, "negative max_rows");
+    if (records_out && !h->cfg.enable_scan) return fail(RO_ERR_STATE, "scan records requested but scan is off");
+    int64_t got = 0;
+    if (first_row_index) *first_row_index = h->rows_emitted;
+    if (first_row_index && !h->ready.empty())
+        *first_row_index = h->ready.front()->first_row + h->ready.front()->consumed;
+    const size_t w = (size_t)h->out_cols;
+    while (got < max_rows && !h->ready.empty()) {
+        Batch *b = h->ready.front();
+        if (b->pending) {
+            HIP_TRY(hipEventSynchronize(b->done));
+            b->pending = false;
+        }
+        const int64_t take = std::min(max_rows - got, b->rows - b->consumed);
+        const size_t at = (size_t)b->consumed;
+        if (tile_out) std::memcpy(tile_out + (size_t)got * w, b->data + at * w, sizeof(float) * w * (size_t)take);
+        if (ln_out) std::memcpy(ln_out + (size_t)got * w, b->ln + at * w, sizeof(float) * w * (size_t)take);
+        if (minmax_out) std::memcpy(minmax_out + (size_t)got * 2, b->minmax + at * 2, sizeof(float) * 2 * (size_t)take);
+        if (records_out) std::memcpy(records_out + got, b->records + at, sizeof(ro_scan_record_t) * (size_t)take);
+        b->consumed += take;
+        got += take;
+        if (b->consumed == b->rows) {
+            h->ready.pop_front();
+            release_batch(h, b);
+        }
+    }
+    h->rows_ready -= got;
+    *rows_got = got;
     return RO_OK;
 }
 

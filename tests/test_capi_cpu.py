@@ -136,3 +136,12 @@ def test_shard_helpers_of_the_c_abi(ro):
     assert ro.shard_samples(5, 0, 4096, 2048) == (5 * 2048, 0)
     with pytest.raises(ro.StftError):
         ro.shard_rows(10, 4, 4)
+
+
+def test_ln_levels_host_helper_matches_the_viewers_formula(ro, oracle):
+    rng = np.random.default_rng(8)
+    image = np.abs(rng.standard_normal((40, 77))).astype(np.float32) * 50
+    image[3, 5] = 0.0
+    ln, want_u8, (mn, mx) = oracle.ln_levels(image)
+    assert np.array_equal(ro.ln_levels(ln, mn, mx), want_u8)
+    assert not ro.ln_levels(ln, 1.0, 1.0).any()                     # flat range: all zero

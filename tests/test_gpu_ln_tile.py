@@ -106,3 +106,64 @@ def test_ln_tile_optional_outputs_and_errors(ro, oracle, torch_cuda):
                 st.ln_tile_resident(d_rows, 9, first, cols, d_minmax=torch_cuda.zeros(2, device="cuda"))
         with pytest.raises(ro.StftError):
             st.ln_tile_resident(d_rows, 9, 0, 16)            # no output requested
+
+
+@pytest.mark.parametrize("bins,overlap,tile", [(32768, 24576, (23278, 615)), (32768, 24576, (22528, 2048)),
+                                               (4096, 2048, (2900, 300)), (65536, 49152, (40000, 1000))])
+def test_fused_ln_tile_of_the_transform(ro, oracle, torch_cuda, bins, overlap, tile):
+    """tile_ln = 1: the transform itself hands out the tile, its log and every row's min / max of the log (bins = 32768:
+    from the magnitudes still in LDS; other sizes: a small kernel over the tile).  Same bars as the stand-alone ln tile;
+    the image range is the min / max over the rows, and ro_ln_levels gives the viewer's grey levels."""
+    torch = torch_cuda
+    hop = bins - overlap
+    R = 37
+    rng = np.random.default_rng(bins + tile[1])
+    iq = add_tone(noise_iq(rng, bins + (R - 1) * hop), 10600.0, 20.0)
+    d_iq = torch.from_numpy(iq).cuda()
+    rows = torch.empty((R, bins), dtype=torch.float32, device="cuda")
+    d_tile = torch.empty((R, tile[1]), dtype=torch.float32, device="cuda")
+    d_ln = torch.full((R, tile[1]), 7.0, dtype=torch.float32, device="cuda")
+    d_mm = torch.zeros((R, 2), dtype=torch.float32, device="cuda")
+    with ro.Stft(bins=bins, overlap=overlap, tile=tile, tile_ln=True) as st:
+        st.run_resident_ln(d_iq, ro.RO_IQ_F32, iq.shape[0], 0, R, rows, d_tile, d_ln=d_ln, d_minmax=d_mm,
+                           stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    image = rows.cpu().numpy()[:, tile[0]:tile[0] + tile[1]]
+    assert np.array_equal(d_tile.cpu().numpy(), image)
+    ln, mm = d_ln.cpu().numpy(), d_mm.cpu().numpy()
+    want_ln, want_u8, (mn, mx) = oracle.ln_levels(np.ascontiguousarray(image))
+    assert ln_close(ln, want_ln)
+    assert np.array_equal(mm[:, 0], ln.min(axis=1)) and np.array_equal(mm[:, 1], ln.max(axis=1))   # reductions are exact
+    gmn, gmx = mm[:, 0].min(), mm[:, 1].max()
+    assert ln_close(np.array([gmn, gmx], np.float32), np.array([mn, mx], np.float32))
+    u8 = ro.ln_levels(ln, gmn, gmx)
+    assert np.array_equal(u8, viewer_levels(ln, image, gmn, gmx))
+    d = np.abs(u8.astype(np.int16) - want_u8.astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3
+
+
+def test_streamed_ln_tile_equals_resident(ro, oracle, torch_cuda):
+    torch = torch_cuda
+    bins, overlap, hop, tile = 32768, 24576, 8192, (23278, 615)
+    rng = np.random.default_rng(21)
+    R = 19
+    iq = noise_iq(rng, bins + (R - 1) * hop + 100)
+    iq[5 * hop:5 * hop + 64] = 0.0
+    with ro.Stft(bins=bins, overlap=overlap, tile=tile, tile_ln=True, max_batch_rows=4) as st:
+        for i in range(0, len(iq), 4096):
+            st.push(iq[i:i + 4096])
+        st.flush()
+        first, t, ln, mm, _ = st.fetch_ln(1000)
+        assert first == 0 and t.shape == ln.shape == (R, 615) and mm.shape == (R, 2)
+        d_iq = torch.from_numpy(iq).cuda()
+        rows = torch.empty((R, bins), dtype=torch.float32, device="cuda")
+        d_tile = torch.empty((R, 615), dtype=torch.float32, device="cuda")
+        d_ln = torch.empty((R, 615), dtype=torch.float32, device="cuda")
+        d_mm = torch.empty((R, 2), dtype=torch.float32, device="cuda")
+        st.run_resident_ln(d_iq, ro.RO_IQ_F32, iq.shape[0], 0, R, rows, d_tile, d_ln=d_ln, d_minmax=d_mm,
+                           stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        with pytest.raises(ro.StftError):
+            st.run_resident_ln(d_iq, ro.RO_IQ_F32, iq.shape[0], 0, R, rows, d_tile, d_minmax=d_mm)
+    assert np.array_equal(t, d_tile.cpu().numpy()) and np.array_equal(ln, d_ln.cpu().numpy())
+    assert np.array_equal(mm, d_mm.cpu().numpy())
