@@ -108,6 +108,13 @@
 #ifndef RO_WIN_EARLY_PCT
 #define RO_WIN_EARLY_PCT 50
 #endif
+// N = 32768 pipelined plan, experiment (off): stage twiddles resident in registers as {w, w^4} per stage (8 VGPRs), the
+// other three powers of a pass (w^2, w^8, w^16) by squaring -- no twiddle loads at all (96 KiB of L2 reads per row).
+// The kernel sits at 127 of its 128 VGPRs: with the eight more hipcc spills 16-28 registers whatever else is given up
+// (early window share 0, fewer sample legs in flight), so the packed table is re-read every row.
+#ifndef RO_PIPE_RES_TW
+#define RO_PIPE_RES_TW 0
+#endif
 #ifndef RO_PIPE_WIN_EARLY_PCT
 #define RO_PIPE_WIN_EARLY_PCT 25
 #endif
@@ -1041,6 +1048,19 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
     // 12 -- one of them second-oldest on its SIMD -- the fused scan cost 12 % of the kernel.)
     constexpr int SCAN_WAVE_NOISE = RO_SCAN_W0, SCAN_WAVE_PEAK = RO_SCAN_W1, TILE_WAVE_A = RO_SCAN_W2, TILE_WAVE_B = RO_SCAN_W3;
     constexpr int PIPE_J = RO_PIPE_J;      // butterfly pairs of the last level that request next-row samples (of 8)
+    // RO_PIPE_RES_TW: {w, w^4} of both twiddled passes, loaded once (packed table: unit 0 = {w, w^2}, unit 1 = {w^4, w^8})
+    v2f rtw[4] = {(v2f){1.f, 0.f}, (v2f){1.f, 0.f}, (v2f){1.f, 0.f}, (v2f){1.f, 0.f}};
+    if constexpr (PIPE && RO_PIPE_RES_TW) {
+        auto unit_lo = [&](int pk, int ns, int q) {
+            const int koff = (tid & (ns - 1)) * 16;
+            const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_twk, koff, (pk + q * ns) * 16, 0);
+            return (v2f){__uint_as_float(u.x), __uint_as_float(u.y)};
+        };
+        rtw[0] = unit_lo(PL::PK1, PL::NS1, 0);
+        rtw[1] = unit_lo(PL::PK1, PL::NS1, 1);
+        rtw[2] = unit_lo(PL::PK2, PL::NS2, 0);
+        rtw[3] = unit_lo(PL::PK2, PL::NS2, 1);
+    }
     const float *prev_out = a.rows_out;
     unsigned prev_bytes = 0;
     unsigned touch = 0;                    // destination of the next-row prefetch touches (touch_next)
@@ -1150,7 +1170,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
                 if constexpr (RO_PIPE_WSTORES) store_chunk(4 + h, rs_prev);
                 else { store_chunk(2 * h, rs_prev); store_chunk(2 * h + 1, rs_prev); }
             });
-            tw_prefetch<P, T, 32, PL::NS1, PL::TW1, PL::PK1>(tw1, rs_tw, rs_twk, tid);
+            if constexpr (!RO_PIPE_RES_TW) tw_prefetch<P, T, 32, PL::NS1, PL::TW1, PL::PK1>(tw1, rs_tw, rs_twk, tid);
             stamp(2);                               // butterflies 0, levels 0..3 (+ the previous row's read-back and stores)
             wg_sync();                              // every wave has read its part of the image back: LDS is free
             stamp(7);
@@ -1165,11 +1185,18 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             exchange_tail<1, SWAP32>(smem, v, tid);
             stamp(3);                               // exchange 1
             // ---- pass 1
+            if constexpr (RO_PIPE_RES_TW) {
+                tw1[0][0] = rtw[0];
+                tw1[0][1] = cmul(rtw[0], rtw[0]);
+                tw1[0][2] = rtw[1];
+                tw1[0][3] = cmul(rtw[1], rtw[1]);
+                tw1[0][4] = cmul(tw1[0][3], tw1[0][3]);
+            }
             fdit32_head(v, tw1[0][4], tw1[0][3], tw1[0][2], tw1[0][1]);
             // the touch sits behind the butterflies: in front of them hipcc's wait for this pass's twiddles would sit
             // through the touch's HBM miss as well
             touch_next();
-            tw_prefetch<P, T, 32, PL::NS2, PL::TW2, PL::PK2>(tw2, rs_tw, rs_twk, tid);
+            if constexpr (!RO_PIPE_RES_TW) tw_prefetch<P, T, 32, PL::NS2, PL::TW2, PL::PK2>(tw2, rs_tw, rs_twk, tid);
             stamp(4);
             wg_sync();                              // exchange 1's y plane has been gathered by everyone
             stamp(11);
@@ -1183,6 +1210,13 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             exchange_tail<2, SWAP32>(smem, v, tid);
             stamp(5);                               // exchange 2
             // ---- pass 2
+            if constexpr (RO_PIPE_RES_TW) {
+                tw2[0][0] = rtw[2];
+                tw2[0][1] = cmul(rtw[2], rtw[2]);
+                tw2[0][2] = rtw[3];
+                tw2[0][3] = cmul(rtw[3], rtw[3]);
+                tw2[0][4] = cmul(tw2[0][3], tw2[0][3]);
+            }
             fdit32_head(v, tw2[0][4], tw2[0][3], tw2[0][2], tw2[0][1]);
             stamp(6);
             wg_sync();                              // exchange 2's y plane has been gathered by everyone
