@@ -112,6 +112,9 @@
 // other three powers of a pass (w^2, w^8, w^16) by squaring -- no twiddle loads at all (96 KiB of L2 reads per row).
 // The kernel sits at 127 of its 128 VGPRs: with the eight more hipcc spills 16-28 registers whatever else is given up
 // (early window share 0, fewer sample legs in flight), so the packed table is re-read every row.
+#ifndef RO_PIPE_TW1_EARLY
+#define RO_PIPE_TW1_EARLY 0
+#endif
 #ifndef RO_PIPE_RES_TW
 #define RO_PIPE_RES_TW 0
 #endif
@@ -1164,13 +1167,18 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             // =====================================================================================================
             static_assert(P == 32 && NB == 1 && SWAP32, "one radix-32 butterfly per thread");
             const unsigned wave_bytes = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6) * 256u;
-            // ---- pass 0, levels 0..3; the previous row's image goes out between them
+            // ---- pass 0, levels 0..3; the previous row's image goes out between them.
+            // (RO_PIPE_TW1_EARLY, experiment, off: pass 1's twiddles requested in front of the eight image stores, so
+            // that the wait for them does not also cover the stores' acknowledgements -- vmcnt retires in issue order
+            // and counts stores.  Measured 0.957-0.974 ms against 0.947-0.957 without: the acknowledgements are not
+            // what pass 1 waits for.)
+            if constexpr (!RO_PIPE_RES_TW && RO_PIPE_TW1_EARLY) tw_prefetch<P, T, 32, PL::NS1, PL::TW1, PL::PK1>(tw1, rs_tw, rs_twk, tid);
             dit32_head(v, [&](auto hc) {
                 constexpr int h = decltype(hc)::value;
                 if constexpr (RO_PIPE_WSTORES) store_chunk(4 + h, rs_prev);
                 else { store_chunk(2 * h, rs_prev); store_chunk(2 * h + 1, rs_prev); }
             });
-            if constexpr (!RO_PIPE_RES_TW) tw_prefetch<P, T, 32, PL::NS1, PL::TW1, PL::PK1>(tw1, rs_tw, rs_twk, tid);
+            if constexpr (!RO_PIPE_RES_TW && !RO_PIPE_TW1_EARLY) tw_prefetch<P, T, 32, PL::NS1, PL::TW1, PL::PK1>(tw1, rs_tw, rs_twk, tid);
             stamp(2);                               // butterflies 0, levels 0..3 (+ the previous row's read-back and stores)
             wg_sync();                              // every wave has read its part of the image back: LDS is free
             stamp(7);
