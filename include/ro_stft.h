@@ -142,6 +142,19 @@ int64_t ro_shard_max_rows(int64_t total_rows, int world);
  * the row order the FITS writer (src/WaterfallBackend.cpp:141-211) and BolidRecorder's state
  * machine (src/BolidRecorder.cpp:171-273) consume.  Host memory; `out` may not alias `gathered`. */
 int     ro_stitch_rows(const void *gathered, int64_t total_rows, int world, size_t row_bytes, void *out);
+/* The one exchange step of a multi-GPU run, for a host that owns an RCCL communicator (one process per GPU): the
+ * all-gather that puts every shard's rows (band tile, ln tile or 12-byte scan records) on every rank, in the equal-block
+ * layout ro_stitch_rows / ro_stitch_rows_device undo.
+ *   nccl_comm   the host's ncclComm_t; librccl is dlopen'ed on first use (RO_ERR_UNSUPPORTED if the box has none)
+ *   d_local     device, local_rows x row_bytes: this rank's rows (local_rows as ro_shard_rows gives for `rank`)
+ *   d_staging   device, ro_shard_max_rows x row_bytes of scratch (the zero-padded send block)
+ *   d_gathered  device, world x ro_shard_max_rows x row_bytes
+ * Asynchronous on `stream` (copy into the staging block, then ncclAllGather as bytes). */
+int     ro_allgather_rows(void *nccl_comm, const void *d_local, int64_t local_rows, int64_t total_rows, int world,
+                          int rank, size_t row_bytes, void *d_staging, void *d_gathered, void *stream);
+/* ro_stitch_rows for device memory: world device-to-device copies on `stream` */
+int     ro_stitch_rows_device(const void *d_gathered, int64_t total_rows, int world, size_t row_bytes, void *d_out,
+                              void *stream);
 /* 1 if `bins` has a kernel in this build: powers of two 256 .. 1048576 (single pass up to
  * 32768, multi-pass through HBM scratch above) */
 int     ro_bins_supported(int bins);

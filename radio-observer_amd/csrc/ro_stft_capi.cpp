@@ -6,6 +6,8 @@
 // HIP kernels.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -775,6 +777,55 @@ extern "C" int ro_stitch_rows(const void *gathered, int64_t total_rows, int worl
         ro_shard_rows(total_rows, world, g, &first, &rows);
         std::memcpy(dst + (size_t)first * row_bytes, src + (size_t)g * (size_t)block * row_bytes,
                     (size_t)rows * row_bytes);
+    }
+    return RO_OK;
+}
+
+// the all-gather itself: RCCL, resolved at run time so that the library has no link-time dependency on it
+extern "C" int ro_allgather_rows(void *nccl_comm, const void *d_local, int64_t local_rows, int64_t total_rows, int world,
+                                 int rank, size_t row_bytes, void *d_staging, void *d_gathered, void *stream)
+{
+    if (!nccl_comm || world < 1 || rank < 0 || rank >= world || total_rows < 0 || row_bytes == 0 || !d_staging ||
+        !d_gathered || (local_rows > 0 && !d_local))
+        return fail(RO_ERR_INVALID, "ro_allgather_rows: bad arguments");
+    int64_t first = 0, mine = 0;
+    ro_shard_rows(total_rows, world, rank, &first, &mine);
+    if (local_rows != mine)
+        return fail(RO_ERR_INVALID, "ro_allgather_rows: rank %d of %d owns %lld of %lld rows, not %lld", rank, world,
+                    (long long)mine, (long long)total_rows, (long long)local_rows);
+    typedef int (*allgather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
+    static allgather_fn all_gather = nullptr;
+    if (!all_gather) {
+        void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        all_gather = lib ? (allgather_fn)dlsym(lib, "ncclAllGather") : nullptr;
+        if (!all_gather) return fail(RO_ERR_UNSUPPORTED, "librccl (ncclAllGather) not found on this host");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t block = ro_shard_max_rows(total_rows, world);
+    if (block == 0) return RO_OK;
+    const size_t used = (size_t)local_rows * row_bytes, whole = (size_t)block * row_bytes;
+    if (used) HIP_TRY(hipMemcpyAsync(d_staging, d_local, used, hipMemcpyDeviceToDevice, s));
+    if (whole > used) HIP_TRY(hipMemsetAsync(static_cast<char *>(d_staging) + used, 0, whole - used, s));
+    const int rc = all_gather(d_staging, d_gathered, whole, /*ncclInt8*/ 0, nccl_comm, s);
+    if (rc != 0) return fail(RO_ERR_HIP, "ncclAllGather failed with code %d", rc);
+    return RO_OK;
+}
+
+extern "C" int ro_stitch_rows_device(const void *d_gathered, int64_t total_rows, int world, size_t row_bytes, void *d_out,
+                                     void *stream)
+{
+    if (total_rows < 0 || world < 1 || (total_rows > 0 && (!d_gathered || !d_out)))
+        return fail(RO_ERR_INVALID, "ro_stitch_rows_device: bad arguments");
+    const int64_t block = ro_shard_max_rows(total_rows, world);
+    for (int g = 0; g < world; ++g) {
+        int64_t first = 0, rows = 0;
+        ro_shard_rows(total_rows, world, g, &first, &rows);
+        if (rows > 0)
+            HIP_TRY(hipMemcpyAsync(static_cast<char *>(d_out) + (size_t)first * row_bytes,
+                                   static_cast<const char *>(d_gathered) + (size_t)g * (size_t)block * row_bytes,
+                                   (size_t)rows * row_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     }
     return RO_OK;
 }
