@@ -107,11 +107,8 @@ def test_fused_records_equal_standalone_scan(ro, oracle, torch_cuda):
     d_recs = torch.zeros((32, 3), dtype=torch.float32, device="cuda")
     with ro.Stft(bins=bins, overlap=overlap, bands=bands) as st:
         st.run_resident(d_iq, ro.RO_IQ_F32, iq.shape[0], 0, 32, d_rows, d_records=d_recs)
-        import ctypes
+        # the handle's own stream was used (stream=None): synchronise the device before reading
         torch.cuda.synchronize()
-        import time; time.sleep(0.05)
-    # the handle's own stream was used (stream=None): synchronise the device before reading
-    torch.cuda.synchronize()
     rows = d_rows.cpu().numpy()
     got = d_recs.cpu().numpy().view(ro.capi.SCAN_DTYPE).reshape(-1)
     n, p, a = oracle.scan_rows(rows, bands.low_noise, bands.noise_width, bands.low_detect,
