@@ -30,7 +30,9 @@ struct StftArgs {
     int           stagger;     // start delay per workgroup slot, shader cycles (0 = none)
     int           prefetch;    // set by the launcher: touch the next row's new samples ahead of time
     int           spare_cus;   // CUs per XCD the persistent grid leaves to other kernels (ro_stft_config_t)
-    int           dec, dec_log2; // MODE 2 (sub-transform of a large transform): decimation factor, its log2; else 1, 0
+    int           dec, dec_log2; // MODE 2 / 3 (large transform, bins = dec x N): the factor, its log2; else 1, 0
+    const float2 *dif_tw;        // MODE 3: exp(-2 pi i j / dec), j < dec
+    const float2 *dif_rot;       // MODE 3: [dec][N] exp(-2 pi i q m / (dec N)); non-null selects MODE 3
     // fused per-row band scan (BolidRecorder::noise/peak/average on the row while it is still in LDS): plans that
     // support it (stft_fuses_scan) fill records[row] themselves, the others leave it to launch_scan
     ro_scan_record_t *records; // rows records, or nullptr

@@ -870,13 +870,29 @@ template <> struct Sample<RO_FMT_I16> {
 // first pass of a large transform (bins > 32768 = dec x N): kernel row k is phase r = k mod dec of stream row k / dec,
 // its samples are x[row hop + r + dec m], its window the r-th decimated table; the spectra S_r go to scratch and
 // combine_kernel finishes the row (X[k' + N q] = sum_r W_dec^(rq) W_(dec N)^(r k') S_r[k']).
+// waves per SIMD the register allocation must leave room for.  MODE 3 wants two of its 512-thread workgroups on a CU
+// (4 waves per SIMD, 128 VGPRs): one sums its blocks -- loads -- while the other runs its butterflies.
+#ifndef RO_DIF_WAVES
+#define RO_DIF_WAVES 4
+#endif
+template <class PL, int FMT, int MODE> constexpr int plan_min_waves() { return MODE == 3 ? RO_DIF_WAVES : 1; }
+
 template <class PL, int FMT, int MODE>
-__global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
+__global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft_kernel(StftArgs a)
 {
     constexpr int N = PL::N, T = PL::T, P = PL::P;
     constexpr int R0 = PL::R0;
     constexpr bool ADDTID = plan_addtid<PL>();
     constexpr bool DEC = MODE == 2;                 // decimated input (sub-transform of a large transform)
+    // MODE 3: a large transform (bins = dec x N) in ONE kernel, decimation in frequency.  Kernel row k is residue
+    // q = k mod dec of stream row k / dec:
+    //   X[q + dec k'] = sum_m W_N^(m k') { W_bins^(m q) sum_r W_dec^(r q) w[m + N r] x[m + N r] },   m, k' < N, r < dec
+    // i.e. the window stage sums the `dec` contiguous blocks of the row (coalesced 16-byte loads, every workgroup
+    // reads the whole row: dec x the loads, all but the first from L2), rotates by W_bins^(m q), and the N-point
+    // transform follows unchanged; bin q + dec k' leaves as column q + dec j of the fft-shifted row (4-byte stores
+    // `dec` floats apart -- the dec workgroups of a stream row run side by side on one XCD and fill its lines
+    // together in that XCD's L2).  No scratch: HBM sees the algorithmic bytes only.
+    constexpr bool DIF = MODE == 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using S = Sample<FMT>;
 
@@ -925,12 +941,19 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
     const int dmul = DEC ? a.dec : 1;               // element stride of the samples, in samples
     // descriptor of kernel row k's samples / window coefficients (zero-sized when !valid: the loads become no-ops)
     auto row_rsrc = [&](int64_t k, bool valid) {
-        const int64_t srow = DEC ? k >> a.dec_log2 : k;
+        const int64_t srow = (DEC || DIF) ? k >> a.dec_log2 : k;
         const int r = DEC ? (int)(k & (a.dec - 1)) : 0;
         return make_rsrc(iq + ((a.first_row + srow) * (int64_t)a.hop + r) * S::BYTES,
                          valid ? (unsigned)(N * dmul - r) * S::BYTES : 0u);
     };
-    auto pair_off = [&](int b) { return plan_pair_off<PL>(tid + T * b); };   // first sample logical thread b fetches
+    // the thread index as a value hipcc cannot hoist address arithmetic out of the row loop with (MODE 3 sits at its
+    // 128 VGPRs: a few shifts and adds per use are cheaper than an invariant parked in scratch)
+    auto fresh_tid = [&]() {
+        int lt = tid;
+        if constexpr (DIF) asm volatile("" : "+v"(lt));
+        return lt;
+    };
+    auto pair_off = [&](int b) { return plan_pair_off<PL>(fresh_tid() + T * b); };   // first sample logical thread b fetches
     auto load_row = [&](const __amdgpu_buffer_rsrc_t &rs) {
         if constexpr (PAIRED) {
 #pragma unroll
@@ -1019,7 +1042,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
     // while the next row's samples are already landing: a quarter; with half, hipcc parks one coefficient quad in
     // scratch for the whole row)
     // (decimated input: unpaired loads, one register per coefficient -- no room for an early share)
-    constexpr int NW_EARLY = DEC ? 0 : ((NW * (plan_pipe<PL>() ? RO_PIPE_WIN_EARLY_PCT : RO_WIN_EARLY_PCT)) / 100) & ~1;
+    constexpr int NW_EARLY = (DEC || DIF) ? 0 : ((NW * (plan_pipe<PL>() ? RO_PIPE_WIN_EARLY_PCT : RO_WIN_EARLY_PCT)) / 100) & ~1;
     using c0 = std::integral_constant<int, 0>;
     using cE = std::integral_constant<int, NW_EARLY>;
     using cN = std::integral_constant<int, NW>;
@@ -1028,7 +1051,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
     auto win_rsrc = [&](int64_t k, bool valid) {
         return make_rsrc(win_tab + (DEC ? (k & (a.dec - 1)) * (int64_t)N : 0), valid ? N * 4 : 0);
     };
-    load_window(win_rsrc(row, true), c0{}, cN{});
+    if constexpr (!DIF) load_window(win_rsrc(row, true), c0{}, cN{});
     // window and twiddle tables resident in registers (see RO_RESIDENT_TABLES)
     constexpr bool RES = RO_RESIDENT_TABLES && N <= 8192 && !RO_ABLATE;              // twiddles (and window)
     // the 512-thread form of the N = 32768 plan has 256 VGPRs per thread: the window stays, the twiddles do not fit
@@ -1091,13 +1114,98 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             }
             if constexpr (PAIRED) {
                 const bool odd = tid & 1;
+                if constexpr (DIF) {
+                    // v[] holds block 0 of the row; add the other dec-1 blocks, each times its window block and
+                    // W_dec^(r q), then rotate by W_bins^(m q).  Everything here is per element, so it happens
+                    // before the lane swap below, with the loads' own (lane, slot) -> m map.
+                    static_assert(WPERM && NB == 1, "MODE 3 runs on the plans with one paired butterfly per thread");
+                    load_window(win_rsrc(row, true), c0{}, cN{});
+                    const int q = (int)(row & (a.dec - 1));
+                    const char *blk = iq + (a.first_row + (row >> a.dec_log2)) * (int64_t)a.hop * S::BYTES;
+                    const int po = pair_off(0);
+                    // A unit = KC legs of one block: KC 16-byte sample loads and KC/2 16-byte window loads.  Two
+                    // units' registers; the loads of unit u+1 are issued in front of the arithmetic of unit u (and
+                    // kept there by a fake dependence on unit u-1's results), so a wave always has one unit in flight.
+                    constexpr int KC = 4, NU = H / KC;
+                    struct Unit { v2f xl[KC], xh[KC]; v4f wq[KC / 2]; };
+                    Unit ua, ub;
+                    auto unit_load = [&](Unit &u, const __amdgpu_buffer_rsrc_t &rs_b, const __amdgpu_buffer_rsrc_t &rs_w,
+                                         int k0, float dep) {
+                        const int pod = after(po, dep), ltd = after(tid, dep);
+#pragma unroll
+                        for (int j = 0; j < KC; ++j)
+                            S::load_pair(rs_b, pod * S::BYTES, (k0 + j) * (N / R0) * S::BYTES, u.xl[j], u.xh[j]);
+#pragma unroll
+                        for (int j = 0; j < KC / 2; ++j) {
+                            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_w, ltd * 16, ((k0 / 2) + j) * TL * 16, 0);
+                            u.wq[j] = (v4f){__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
+                        }
+                    };
+                    auto unit_add = [&](Unit &u, int k0, v2f cxx, v2f cyn) {
+#pragma unroll
+                        for (int j = 0; j < KC; ++j) {
+                            const int k = k0 + j;
+                            if (a.gain != 0.0f) { u.xl[j] = u.xl[j] + gain2; u.xh[j] = u.xh[j] + gain2; }
+                            const v4f c4 = u.wq[j / 2];
+                            const v2f e = u.xl[j] * ((k & 1) ? c4.zz : c4.xx);
+                            const v2f o = u.xh[j] * ((k & 1) ? c4.ww : c4.yy);
+                            v[k] = __builtin_elementwise_fma(e.yx, cyn, __builtin_elementwise_fma(e, cxx, v[k]));
+                            v[H + k] = __builtin_elementwise_fma(o.yx, cyn, __builtin_elementwise_fma(o, cxx, v[H + k]));
+                        }
+                    };
+                    // block r's descriptors; r = dec: the rotation table (8-byte entries: the float sample path), no window
+                    auto blk_rsrc = [&](int r) {
+                        return r < a.dec ? make_rsrc(blk + (int64_t)r * N * S::BYTES, N * S::BYTES) : make_rsrc(nullptr, 0);
+                    };
+                    auto wblk_rsrc = [&](int r) { return make_rsrc(win_tab + (int64_t)r * N, r < a.dec ? N * 4 : 0); };
+                    static_assert(NU == 4, "the unit schedule below is written out for four units per block");
+                    unit_load(ua, blk_rsrc(1), wblk_rsrc(1), 0, v[0].x);
+#pragma unroll
+                    for (int k = 0; k < H; ++k) {                  // block 0
+                        const v4f c4 = w4[k / 2];
+                        v[k] = v[k] * ((k & 1) ? c4.zz : c4.xx);
+                        v[H + k] = v[H + k] * ((k & 1) ? c4.ww : c4.yy);
+                    }
+#pragma unroll 1
+                    for (int r = 1; r < a.dec; ++r) {
+                        const __amdgpu_buffer_rsrc_t rs_b = blk_rsrc(r), rs_w = wblk_rsrc(r);
+                        const float2 c = a.dif_tw[(r * q) & (a.dec - 1)];
+                        const v2f cxx = (v2f){c.x, c.x}, cyn = (v2f){-c.y, c.y};
+                        unit_load(ub, rs_b, rs_w, KC, v[H + 3 * KC].x);
+                        unit_add(ua, 0, cxx, cyn);
+                        unit_load(ua, rs_b, rs_w, 2 * KC, v[0].x);
+                        unit_add(ub, KC, cxx, cyn);
+                        unit_load(ub, rs_b, rs_w, 3 * KC, v[H + KC].x);
+                        unit_add(ua, 2 * KC, cxx, cyn);
+                        unit_load(ua, blk_rsrc(r + 1), wblk_rsrc(r + 1), 0, v[H + 2 * KC].x);     // (zero-sized past the last block)
+                        unit_add(ub, 3 * KC, cxx, cyn);
+                    }
+                    // (residue 0 needs no rotation: W^0)
+                    const __amdgpu_buffer_rsrc_t rs_rot = make_rsrc(a.dif_rot + (int64_t)q * N, N * 8);
+                    if (q != 0)
+#pragma unroll
+                    for (int k0 = 0; k0 < H; k0 += KC) {
+                        v2f tl[KC], th[KC];
+                        const int pod = k0 >= 2 * KC ? after(po, v[H + k0 - 2 * KC].x) : po;
+#pragma unroll
+                        for (int j = 0; j < KC; ++j)
+                            Sample<RO_FMT_F32>::load_pair(rs_rot, pod * 8, (k0 + j) * (N / R0) * 8, tl[j], th[j]);
+#pragma unroll
+                        for (int j = 0; j < KC; ++j) {
+                            v[k0 + j] = cmul(v[k0 + j], tl[j]);
+                            v[H + k0 + j] = cmul(v[H + k0 + j], th[j]);
+                        }
+                    }
+                }
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
 #pragma unroll
                 for (int k = 0; k < H; ++k) {
                     v2f &lo = v[R0 * b + k], &hi = v[R0 * b + H + k];
                     v2f we, wo;                                    // coefficient of the even / odd column, both halves
-                    if constexpr (WPERM) {
+                    if constexpr (DIF) {
+                        we = wo = (v2f){1.0f, 1.0f};               // (already applied)
+                    } else if constexpr (WPERM) {
                         const v4f c4 = w4[b * (NW / 2) + k / 2];
                         we = (k & 1) ? c4.zz : c4.xx;
                         wo = (k & 1) ? c4.ww : c4.yy;
@@ -1105,8 +1213,8 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
                         we = w[k].xx;
                         wo = w[k].yy;
                     }
-                    const v2f e = lo * we;                         // even column, leg k (H+k on odd lanes)
-                    const v2f o = hi * wo;                         // odd column
+                    const v2f e = DIF ? lo : lo * we;              // even column, leg k (H+k on odd lanes)
+                    const v2f o = DIF ? hi : hi * wo;              // odd column
                     if constexpr (SWAP32) {
                         // lanes 0..31 hold legs k, lanes 32..63 legs H+k of both columns: the upper half of slot k
                         // trades places with the lower half of slot H+k (v_permlane32_swap_b32)
@@ -1137,7 +1245,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         if constexpr (ADDTID) asm volatile("" ::"v"(touch));     // see touch_next
         const int64_t next = row + stride;
         const bool has_next = next < xcd_end;
-        if constexpr (!RESW) load_window(win_rsrc(has_next ? next : row, true), c0{}, cE{});
+        if constexpr (!RESW && !DIF) load_window(win_rsrc(has_next ? next : row, true), c0{}, cE{});
         auto touch_next = [&]() {
             if constexpr (!ADDTID) return;          // only the add-TID plan is launched with a.prefetch
             // samples [next*hop + N - hop, next*hop + N) = hop * BYTES bytes: one dword per 128-byte line and thread
@@ -1345,13 +1453,13 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         }
 
         butterflies<P, R0>(v);
-        if constexpr (PL::R1 > 1 && !RES) tw_prefetch<P, T, PL::R1, PL::NS1, PL::TW1, PL::PK1>(tw1, rs_tw, rs_twk, tid);
+        if constexpr (PL::R1 > 1 && !RES) tw_prefetch<P, T, PL::R1, PL::NS1, PL::TW1, PL::PK1>(tw1, rs_tw, rs_twk, fresh_tid());
         stamp(2);                                   // butterflies 0
 
         // ---- stage 1
         if constexpr (PL::R1 > 1) {
             if constexpr (ADDTID) exchange_addtid<1, SWAP32, P / 32, T>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
-            else exchange<PL, PL::R0, 1, PL::R1>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
+            else exchange<PL, PL::R0, 1, PL::R1>(smem, v, fresh_tid(), [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             stamp(3);                               // exchange 1
             tw_butterflies<P, PL::R1>(v, tw1);
             // behind the butterflies: in front of them hipcc's wait for this pass's twiddles (which it believes to be
@@ -1361,9 +1469,9 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         }
         // ---- stage 2
         if constexpr (PL::R2 > 1) {
-            if constexpr (!RES) tw_prefetch<P, T, PL::R2, PL::NS2, PL::TW2, PL::PK2>(tw2, rs_tw, rs_twk, tid);
+            if constexpr (!RES) tw_prefetch<P, T, PL::R2, PL::NS2, PL::TW2, PL::PK2>(tw2, rs_tw, rs_twk, fresh_tid());
             if constexpr (ADDTID) exchange_addtid<2, SWAP32, P / 32, T>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
-            else exchange<PL, PL::R1, PL::NS1, PL::R2>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
+            else exchange<PL, PL::R1, PL::NS1, PL::R2>(smem, v, fresh_tid(), [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             stamp(5);                               // exchange 2
             if constexpr (RO_PREFETCH_NEXT == 3) touch_next();
             tw_butterflies<P, PL::R2>(v, tw2);
@@ -1385,7 +1493,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         // requested into the freed registers, and only then the row is read back 16 bytes per
         // lane and stored -- 1 KiB per wave-instruction, the stores being the LAST thing in the
         // VMEM queue.
-        if constexpr (MODE >= 1) {
+        if constexpr (MODE == 1 || MODE == 2) {
             // slot r of butterfly b is bin (tid + T b) + r N/RL: 8 bytes per lane, 512 contiguous bytes per wave
             const __amdgpu_buffer_rsrc_t rs_spec =
                 make_rsrc(a.spec_out + row * a.spec_stride, (unsigned)N * 8u);
@@ -1422,6 +1530,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
             }
         } else {
             float *lds_m = reinterpret_cast<float *>(smem);
+            const int lt = fresh_tid();
 #pragma unroll
             for (int b = 0; b < P / RL; ++b) {
 #pragma unroll
@@ -1430,7 +1539,7 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
                     const v2f sq = x * x;
                     const float mag = __builtin_amdgcn_sqrtf(sq.x + sq.y);   // v_sqrt_f32, 1 ulp
                     const int cbase = (r * (N / RL) + N / 2) & (N - 1);
-                    lds_m[tid + T * b + cbase] = mag;            // j < N/RL, cbase a multiple of it: no wrap
+                    lds_m[lt + T * b + cbase] = mag;             // j < N/RL, cbase a multiple of it: no wrap
                 }
             }
         }
@@ -1439,14 +1548,34 @@ __global__ __launch_bounds__(PL::T) void stft_kernel(StftArgs a)
         load_row(row_rsrc(has_next ? next : row, has_next));
         // unconditional (zero-sized descriptor after the last row): a branch here would keep the
         // old coefficients alive next to the new ones
-        if constexpr (!RESW) load_window(win_rsrc(has_next ? next : row, has_next), cE{}, cN{});
+        // (MODE 3 asks for block 0's coefficients at the head of its window stage: across the loop's back edge they
+        // were the 32 registers too many)
+        if constexpr (!RESW && !DIF) load_window(win_rsrc(has_next ? next : row, has_next), cE{}, cN{});
         stamp(7);                                   // next-row loads issued
         // the add-TID writes sit inside inline asm: hipcc does not count them, so the barrier's own lgkmcnt wait
         // is missing unless it is spelled out (the image is read by OTHER waves right behind the barrier)
         if constexpr (ADDTID) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wg_sync();
         stamp(11);                                  // barrier 1
-        {
+        if constexpr (DIF) {
+            // image element j is column q + dec j of the shifted row (add-TID plans, whose image is in natural order:
+            // column q + dec ((j + N/2) mod N)): one float per lane, `dec` floats apart (default cache policy: the
+            // other residues' workgroups fill the same lines)
+            const int q = (int)(row & (a.dec - 1));
+            const __amdgpu_buffer_rsrc_t rs_out =
+                make_rsrc(a.rows_out + (row >> a.dec_log2) * a.row_stride, (unsigned)N * (unsigned)a.dec * 4u);
+            const float *lds_m1 = reinterpret_cast<const float *>(smem);
+            const int lt = fresh_tid();
+            const int vo = (lt * a.dec + q) * 4;
+            int step = T * a.dec * 4;
+            asm volatile("" : "+s"(step));                  // (else hipcc keeps P multiples of it in SGPRs all row long)
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const int io = ADDTID ? ((i + P / 2) & (P - 1)) : i;
+                buf_store_f(lds_m1[lt + T * i], rs_out, vo, io * step);
+                if ((i & 7) == 7) asm volatile("" ::: "memory");
+            }
+        } else {
             const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(a.rows_out + row * a.row_stride, N * 4);
             const float4 *lds_m4 = reinterpret_cast<const float4 *>(smem);
 #pragma unroll
@@ -1908,11 +2037,11 @@ template <class PL, int FMT, int MODE> static hipError_t launch_plan(const StftA
 #endif
     const unsigned grid = (unsigned)(slots * 8);
     StftArgs b = a;
-    if (MODE != 2) { b.dec = 1; b.dec_log2 = 0; }
+    if (MODE < 2) { b.dec = 1; b.dec_log2 = 0; }
     // The touches park hop*BYTES per resident workgroup in the XCD's 4 MiB L2 for most of a row time.  Past half of
     // it they push out the rows being transformed and every line is fetched twice (seen at overlap 0: FETCH_SIZE x2,
     // 19 % slower).  Plans with several workgroups per CU hide the miss behind each other and gain nothing (measured).
-    b.prefetch = (MODE != 2 && plan_addtid<PL>() && slots * (int64_t)a.hop * Sample<FMT>::BYTES <= (2 << 20)) ? 1 : 0;
+    b.prefetch = (MODE < 2 && plan_addtid<PL>() && slots * (int64_t)a.hop * Sample<FMT>::BYTES <= (2 << 20)) ? 1 : 0;
     b.stagger = 0;
 #ifdef RO_DIAG_KNOBS
     if (const int force = env_knob("RO_PREFETCH", -1); force >= 0) b.prefetch = force;
@@ -1935,6 +2064,14 @@ using Plan256   = Plan<  256,   64,  4,  4,  4, 4, false>;
 template <class PL> static hipError_t launch_fmt(const StftArgs &a, int fmt, hipStream_t s)
 {
     const bool spec = a.spec_out != nullptr;
+    if (a.dec > 1 && a.dif_rot) {                      // a large transform in one kernel (MODE 3)
+        if constexpr (PL::N == 32768) {
+            if (spec) return hipErrorInvalidValue;
+            if (fmt == RO_FMT_F32) return launch_plan<PL, RO_FMT_F32, 3>(a, s);
+            if (fmt == RO_FMT_I16) return launch_plan<PL, RO_FMT_I16, 3>(a, s);
+        }
+        return hipErrorInvalidValue;
+    }
     if (a.dec > 1) {                                   // sub-transforms of a large transform: decimated in, spectra out
         // (not for the 1024-thread N = 32768 plan: with unpaired loads its window coefficients take 32 registers
         // and it spills; big_split never asks for it)

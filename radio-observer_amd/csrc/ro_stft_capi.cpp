@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <ctime>
 #include <deque>
@@ -22,6 +23,13 @@
 #include "ro_kernels.h"
 
 // scratch of the two-pass large transforms (sub-spectra between the two kernels), MiB
+// largest bins / 16384 the one-kernel form of the large transforms is used for (see ro_stft_create)
+#ifndef RO_DIF_MAX_DEC
+#define RO_DIF_MAX_DEC 8
+#endif
+#ifndef RO_DIF_SUB
+#define RO_DIF_SUB 32768
+#endif
 #ifndef RO_SPEC_SCRATCH_MB
 #define RO_SPEC_SCRATCH_MB 2048
 #endif
@@ -196,6 +204,10 @@ struct ro_stft {
     float  *d_window_dec = nullptr;
     float2 *d_tw_combine = nullptr;    // [dec][sub_bins]: exp(-2 pi i r k' / bins)
     float2 *d_spec = nullptr;
+    // one-kernel form of the large transforms (decimation in frequency, ro::stft_kernel MODE 3)
+    bool    dif = false;
+    float  *d_window_dif = nullptr;    // [dec][sub_bins]: window block r in the sub-plan's kernel order
+    float2 *d_dif_tw = nullptr;        // exp(-2 pi i j / dec)
     int64_t spec_rows = 0;
 
     // tile_ln: partial min / max of the fused epilogue's two tile waves (rows x 4 floats), grown on demand
@@ -395,6 +407,20 @@ int launch_transform(ro_stft *h, const void *d_iq, int format, int64_t first_row
         }
         ro::StftArgs a = make_stft_args(h, d_iq, first_row, rows, d_rows, row_stride, d_tile, d_records, d_ln);
         HIP_TRY(ro::launch_stft(h->bins, format, a, s));
+        return RO_OK;
+    }
+    if (h->dec > 1 && h->dif) {
+        // one kernel, no scratch: kernel row srow * dec + q makes the bins q + dec k' of stream row srow
+        int log2 = 0;
+        while ((1 << log2) < h->dec) ++log2;
+        ro::StftArgs a = make_stft_args(h, d_iq, first_row, rows * h->dec, d_rows, row_stride);
+        a.window = h->d_window;
+        a.window_k = h->d_window_dif;
+        a.dec = h->dec;
+        a.dec_log2 = log2;
+        a.dif_tw = h->d_dif_tw;
+        a.dif_rot = h->d_tw_combine;
+        HIP_TRY(ro::launch_stft(h->sub_bins, format, a, s));
         return RO_OK;
     }
     if (h->dec > 1) {
@@ -907,6 +933,17 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
     h->big = ro::big_supported(h->bins);
     h->f64 = cfg->precision == RO_PRECISION_F64;
     if (h->big && !ro::big_split(h->bins, &h->sub_bins, &h->dec)) h->sub_bins = h->dec = 0;
+    if (h->big && !h->f64) {
+        // The one-kernel form (ro::stft_kernel MODE 3) reads bins / sub_bins x the row through L2 per output row and
+        // nothing extra through HBM: the largest single-pass plan as its base, and only while that beats the two
+        // passes' trip through HBM.  (Diagnostic builds: RO_BIG_FORM=twopass|dif for A/B runs.)
+        const int sub = RO_DIF_SUB, dec = h->bins / sub;
+        bool dif = dec >= 2 && dec <= RO_DIF_MAX_DEC;
+#ifdef RO_DIAG_KNOBS
+        if (const char *e = getenv("RO_BIG_FORM")) dif = dec >= 2 && dec <= 32 && std::strcmp(e, "dif") == 0;
+#endif
+        if (dif) { h->dif = true; h->sub_bins = sub; h->dec = dec; }
+    }
     const int plan_bins = h->big ? h->sub_bins : h->bins;           // whose stage tables this handle needs (0: none)
     std::vector<float2> tw = plan_bins ? build_twiddles(plan_bins) : std::vector<float2>();
     if (plan_bins && (int)tw.size() != ro::stft_twiddle_count(plan_bins)) {
@@ -971,6 +1008,28 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
         CREATE_TRY(hipMalloc(&h->d_tw_combine, sizeof(float2) * tc.size()));
         CREATE_TRY(hipMemcpy(h->d_tw_combine, tc.data(), sizeof(float2) * tc.size(), hipMemcpyHostToDevice));
     }
+    if (h->dif) {
+        std::vector<float> wk((size_t)h->bins);
+        for (int r = 0; r < h->dec; ++r)
+            if (!ro::stft_window_layout(h->sub_bins, h->window.data() + (size_t)r * h->sub_bins,
+                                        wk.data() + (size_t)r * h->sub_bins)) {
+                ro_stft_destroy(h);
+                return fail(RO_ERR_UNSUPPORTED, "no window layout for bins=%d", h->sub_bins);
+            }
+        CREATE_TRY(hipMalloc(&h->d_window_dif, sizeof(float) * wk.size()));
+        CREATE_TRY(hipMemcpy(h->d_window_dif, wk.data(), sizeof(float) * wk.size(), hipMemcpyHostToDevice));
+        std::vector<float2> td((size_t)h->dec);
+        const long double two_pi = 8.0L * atanl(1.0L);
+        for (int j = 0; j < h->dec; ++j) {
+            // (quarter turns exact: cosl(pi/2) is 6e-20, not 0)
+            const long double ang = -two_pi * (long double)j / (long double)h->dec;
+            long double c = cosl(ang), sn = sinl(ang);
+            if ((4 * j) % h->dec == 0) { c = roundl(c); sn = roundl(sn); }
+            td[(size_t)j] = make_float2((float)c, (float)sn);
+        }
+        CREATE_TRY(hipMalloc(&h->d_dif_tw, sizeof(float2) * td.size()));
+        CREATE_TRY(hipMemcpy(h->d_dif_tw, td.data(), sizeof(float2) * td.size(), hipMemcpyHostToDevice));
+    }
     if (h->big) {
         std::vector<float2> full = build_full_twiddles(h->bins);
         CREATE_TRY(hipMalloc(&h->d_tw_big, sizeof(float2) * full.size()));
@@ -1011,6 +1070,8 @@ extern "C" int ro_stft_destroy(ro_stft_t *h)
     if (h->d_window_dec) (void)hipFree(h->d_window_dec);
     if (h->d_tw_combine) (void)hipFree(h->d_tw_combine);
     if (h->d_spec) (void)hipFree(h->d_spec);
+    if (h->d_window_dif) (void)hipFree(h->d_window_dif);
+    if (h->d_dif_tw) (void)hipFree(h->d_dif_tw);
     if (h->d_tw_f64) (void)hipFree(h->d_tw_f64);
     if (h->d_ln_part) (void)hipFree(h->d_ln_part);
     for (int i = 0; i < 2; ++i)
