@@ -30,9 +30,10 @@ struct StftArgs {
     int           stagger;     // start delay per workgroup slot, shader cycles (0 = none)
     int           prefetch;    // set by the launcher: touch the next row's new samples ahead of time
     int           spare_cus;   // CUs per XCD the persistent grid leaves to other kernels (ro_stft_config_t)
-    int           dec, dec_log2; // MODE 2 / 3 (large transform, bins = dec x N): the factor, its log2; else 1, 0
+    int           dec, dec_log2; // MODE 3 (large transform, bins = dec x N): the factor, its log2; else 1, 0
     const float2 *dif_tw;        // MODE 3: exp(-2 pi i j / dec), j < dec
-    const float2 *dif_rot;       // MODE 3: [dec][N] exp(-2 pi i q m / (dec N)); non-null selects MODE 3
+    const float2 *dif_rot;       // MODE 3: [dec][N] exp(-2 pi i q m / (dec N))
+    int           big_form;      // 1 selects MODE 3 (a large transform in one kernel), else 0
     // fused per-row band scan (BolidRecorder::noise/peak/average on the row while it is still in LDS): plans that
     // support it (stft_fuses_scan) fill records[row] themselves, the others leave it to launch_scan
     ro_scan_record_t *records; // rows records, or nullptr
@@ -77,22 +78,6 @@ struct ScanArgs {
     int               avg_bins;
 };
 
-// ---- large transforms (bins > 32768): multi-pass Stockham through HBM scratch
-struct BigArgs {
-    const void   *iq;          // FIRST pass: sample 0 of the stream
-    const float  *window;      // FIRST pass
-    const float2 *tw;          // exp(-2 pi i m / N), m in [0, N)
-    const float2 *in;          // middle / last passes: [rows][N]
-    float2       *out;         // first / middle passes: [rows][N]
-    float        *rows_out;    // LAST pass: [rows][row_stride]
-    int64_t       first_row;   // stream row index of scratch row 0
-    int64_t       rows;
-    int64_t       row_stride;
-    int           hop;
-    int           n;           // N
-    int           ns;          // product of the radices of earlier passes
-    float         gain;
-};
 // ---- strict precision (RO_PRECISION_F64): the same multi-pass recurrence in double, any supported size
 struct BigArgsD {
     const void    *iq;         // FIRST pass: sample 0 of the stream
@@ -112,22 +97,30 @@ struct BigArgsD {
 int        f64_radices(int bins, int radices[8]); // passes of the FP64 path for a power of two 256 .. 2^20 (0 = unsupported)
 hipError_t launch_f64_pass(int radix, bool first, bool last, int fmt, const BigArgsD &a, hipStream_t s);
 
-// ---- large transforms, two passes: `dec` decimated sub-transforms of length bins / dec with the single-pass kernels
-// (spectra to scratch), then the radix-`dec` combine below
-struct CombineArgs {
-    const float2 *spec;        // [rows][dec][m] sub-spectra S_r[k'], bin k' at element k'
-    const float2 *tw;          // [dec][m]: entry r m + k' = exp(-2 pi i r k' / bins) (exact, in the order the combine reads)
-    float        *rows_out;    // [rows][row_stride] magnitudes, fft-shifted
-    int64_t       rows, row_stride;
-    int           m;           // length of a sub-transform
-    int           dec;         // radix of the combine: 2 .. 32
+// ---- large transforms (bins = dec x 32768), see the note in front of fold_kernel
+// First pass of the two-pass form of a large transform (bins = dec x m, decimation in frequency):
+//   out[(row dec + q) m + i] = W_bins^(i q) sum_r W_dec^(r q) w[i + m r] x[row hop + i + m r],   i < m, q, r < dec
+// every access a run of consecutive i; the N = 32768 kernel then transforms `out`'s rows (no overlap, a window of ones).
+struct FoldArgs {
+    const void   *iq;
+    const float  *window;      // bins floats, natural order
+    const float2 *rot;         // [dec][m]: exp(-2 pi i q i / bins)
+    float2       *out;         // [rows][dec][m]
+    int64_t       first_row, rows;
+    int           hop, m, dec;
+    float         gain;
 };
-bool       big_split(int bins, int *sub_bins, int *dec);   // how a large transform is cut (false: not a large size)
-hipError_t launch_combine(const CombineArgs &a, hipStream_t s);
-
+hipError_t launch_fold(int format, const FoldArgs &a, hipStream_t s);
+// Last step: out[row][q + dec j] = in[(row dec + q) m + j] -- the dec sub-rows of a stream row
+// (each already fft-shifted in itself, which is the large row's own shift) interleaved into the row.
+struct InterleaveArgs {
+    const float *in;           // [rows][dec][m]
+    float       *out;          // [rows][row_stride]
+    int64_t      rows, row_stride;
+    int          m, dec;
+};
+hipError_t launch_interleave(const InterleaveArgs &a, hipStream_t s);
 bool       big_supported(int bins);               // power of two in (32768, 2^20]
-int        big_radices(int bins, int radices[8]); // number of passes
-hipError_t launch_big_pass(int radix, bool first, bool last, int fmt, const BigArgs &a, hipStream_t s);
 
 bool       stft_supported(int bins);
 bool       stft_fuses_scan(int bins);             // the plan writes StftArgs::records / tile_out from its epilogue

@@ -866,10 +866,8 @@ template <> struct Sample<RO_FMT_I16> {
 // magnitude has just been stored.
 // MODE 0: magnitude rows (the waterfall).  MODE 1: the complex spectrum itself, bin k at element k of the row
 // (what fftw_execute leaves in out_ and FFTBackend::processFFT receives, src/FFTBackend.h:104): same transform, the
-// epilogue stores v[] as it is -- no magnitude, no shift, no LDS staging.  MODE 2: MODE 1 on DECIMATED input, the
-// first pass of a large transform (bins > 32768 = dec x N): kernel row k is phase r = k mod dec of stream row k / dec,
-// its samples are x[row hop + r + dec m], its window the r-th decimated table; the spectra S_r go to scratch and
-// combine_kernel finishes the row (X[k' + N q] = sum_r W_dec^(rq) W_(dec N)^(r k') S_r[k']).
+// epilogue stores v[] as it is -- no magnitude, no shift, no LDS staging.  MODE 3: a large transform in one kernel
+// (below).
 // waves per SIMD the register allocation must leave room for.  MODE 3 wants two of its 512-thread workgroups on a CU
 // (4 waves per SIMD, 128 VGPRs): one sums its blocks -- loads -- while the other runs its butterflies.
 #ifndef RO_DIF_WAVES
@@ -883,7 +881,6 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
     constexpr int N = PL::N, T = PL::T, P = PL::P;
     constexpr int R0 = PL::R0;
     constexpr bool ADDTID = plan_addtid<PL>();
-    constexpr bool DEC = MODE == 2;                 // decimated input (sub-transform of a large transform)
     // MODE 3: a large transform (bins = dec x N) in ONE kernel, decimation in frequency.  Kernel row k is residue
     // q = k mod dec of stream row k / dec:
     //   X[q + dec k'] = sum_m W_N^(m k') { W_bins^(m q) sum_r W_dec^(r q) w[m + N r] x[m + N r] },   m, k' < N, r < dec
@@ -934,17 +931,13 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
     // NB stage-0 butterflies per thread: "logical thread" j = tid + T*b (b < NB) owns v[R0*b .. R0*b + R0-1].  The
     // paired scheme needs one butterfly per logical thread; the add-TID plan runs 1024 of them on 1024 or 512 threads.
     constexpr int NB = P / R0, TL = T * NB;
-    // (decimated input: neighbouring columns are `dec` samples apart in memory, so no 16-byte pairs)
-    constexpr bool PAIRED = (NB == 1 || ADDTID) && (R0 % 2 == 0) && RO_PAIRED_LOADS && !DEC;
+    constexpr bool PAIRED = (NB == 1 || ADDTID) && (R0 % 2 == 0) && RO_PAIRED_LOADS;
     constexpr int H = R0 / 2;
-    constexpr bool SWAP32 = plan_swap32<PL>() && !DEC;
-    const int dmul = DEC ? a.dec : 1;               // element stride of the samples, in samples
+    constexpr bool SWAP32 = plan_swap32<PL>();
     // descriptor of kernel row k's samples / window coefficients (zero-sized when !valid: the loads become no-ops)
     auto row_rsrc = [&](int64_t k, bool valid) {
-        const int64_t srow = (DEC || DIF) ? k >> a.dec_log2 : k;
-        const int r = DEC ? (int)(k & (a.dec - 1)) : 0;
-        return make_rsrc(iq + ((a.first_row + srow) * (int64_t)a.hop + r) * S::BYTES,
-                         valid ? (unsigned)(N * dmul - r) * S::BYTES : 0u);
+        const int64_t srow = DIF ? k >> a.dec_log2 : k;
+        return make_rsrc(iq + (a.first_row + srow) * (int64_t)a.hop * S::BYTES, valid ? (unsigned)N * S::BYTES : 0u);
     };
     // the thread index as a value hipcc cannot hoist address arithmetic out of the row loop with (MODE 3 sits at its
     // 128 VGPRs: a few shifts and adds per use are cheaper than an invariant parked in scratch)
@@ -971,7 +964,7 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
             for (int i = 0; i < P; ++i) {
                 // slot i: butterfly i / R0, leg i % R0 of stage 0
                 if constexpr (RO_ABLATE & 32) v[i] = (v2f){(float)(tid + i), 1.0f};
-                else v[i] = S::load(rs, (tid + T * (i / R0)) * S::BYTES * dmul, (i % R0) * (N / R0) * S::BYTES * dmul);
+                else v[i] = S::load(rs, (tid + T * (i / R0)) * S::BYTES, (i % R0) * (N / R0) * S::BYTES);
             }
         }
     };
@@ -1041,21 +1034,17 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
     // (the pipelined plan has fewer registers to spare -- the fused scan's two waves keep their band in registers
     // while the next row's samples are already landing: a quarter; with half, hipcc parks one coefficient quad in
     // scratch for the whole row)
-    // (decimated input: unpaired loads, one register per coefficient -- no room for an early share)
-    constexpr int NW_EARLY = (DEC || DIF) ? 0 : ((NW * (plan_pipe<PL>() ? RO_PIPE_WIN_EARLY_PCT : RO_WIN_EARLY_PCT)) / 100) & ~1;
+    constexpr int NW_EARLY = DIF ? 0 : ((NW * (plan_pipe<PL>() ? RO_PIPE_WIN_EARLY_PCT : RO_WIN_EARLY_PCT)) / 100) & ~1;
     using c0 = std::integral_constant<int, 0>;
     using cE = std::integral_constant<int, NW_EARLY>;
     using cN = std::integral_constant<int, NW>;
     const float *win_tab = WPERM ? a.window_k : a.window;
-    // (decimated input: phase r of a row has its own table of N coefficients, w[r + dec m])
-    auto win_rsrc = [&](int64_t k, bool valid) {
-        return make_rsrc(win_tab + (DEC ? (k & (a.dec - 1)) * (int64_t)N : 0), valid ? N * 4 : 0);
-    };
+    auto win_rsrc = [&](int64_t, bool valid) { return make_rsrc(win_tab, valid ? N * 4 : 0); };
     if constexpr (!DIF) load_window(win_rsrc(row, true), c0{}, cN{});
     // window and twiddle tables resident in registers (see RO_RESIDENT_TABLES)
     constexpr bool RES = RO_RESIDENT_TABLES && N <= 8192 && !RO_ABLATE;              // twiddles (and window)
     // the 512-thread form of the N = 32768 plan has 256 VGPRs per thread: the window stays, the twiddles do not fit
-    constexpr bool RESW = (RES && !DEC) || (RO_T512_RESW && ADDTID && T == 512 && !RO_ABLATE);
+    constexpr bool RESW = RES || (RO_T512_RESW && ADDTID && T == 512 && !RO_ABLATE);
     v2f tw1[PL::R1 > 1 ? P / PL::R1 : 1][TW_SET];
     v2f tw2[PL::R2 > 1 ? P / PL::R2 : 1][TW_SET];
     v2f tw3[PL::R3 > 1 ? P / PL::R3 : 1][TW_SET];
@@ -1493,7 +1482,7 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
         // requested into the freed registers, and only then the row is read back 16 bytes per
         // lane and stored -- 1 KiB per wave-instruction, the stores being the LAST thing in the
         // VMEM queue.
-        if constexpr (MODE == 1 || MODE == 2) {
+        if constexpr (MODE == 1) {
             // slot r of butterfly b is bin (tid + T b) + r N/RL: 8 bytes per lane, 512 contiguous bytes per wave
             const __amdgpu_buffer_rsrc_t rs_spec =
                 make_rsrc(a.spec_out + row * a.spec_stride, (unsigned)N * 8u);
@@ -1613,115 +1602,83 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
 }
 
 // ---------------------------------------------------------------------------
-// Large transforms (N = 65536 ... 1048576, the sizes of Bolidozor.json:45 and Ionozor.json:27).
-// A row no longer fits a CU, so the same Stockham autosort recurrence runs as separate passes
-// of radix 16 (last pass 2..16) over complex scratch rows in HBM: one thread per butterfly,
-//   in :  x[j + k*(N/R)] * w(k*(j mod Ns)/(Ns*R)),   out:  y[(j/Ns)*Ns*R + (j mod Ns) + k*Ns].
-// The first pass reads the samples in place and applies the window, the last one writes
-// |X| fft-shifted.  Twiddles come from one exp(-2 pi i m/N) table (exact entries, no products).
-// Bound: HBM, 16 B per point and pass; not the benchmarked shape (5.9 rows/s is real time there).
+// Large transforms (bins = dec x 32768: 65536 ... 1048576, the station sizes of Bolidozor.json:45 and Ionozor.json:27).
+// A row no longer fits a CU.  Decimation in frequency over the N = 32768 single-pass plan:
+//   X[q + dec k'] = sum_m W_N^(m k') { W_bins^(m q) sum_r W_dec^(r q) w[m + N r] x[m + N r] }
+// dec <= 4: ONE kernel, stft_kernel MODE 3 -- the braces are summed in its window stage (every workgroup reads the
+//   whole row: dec x the loads, from L2), bins leave `dec` floats apart.  HBM sees the algorithmic bytes only.
+// dec >= 8: the strided 4-byte stores of that form cost one 64-byte L2 write request per lane and residue, so three
+//   steps through scratch, every access a run of consecutive elements: fold_kernel (the braces, 8 B per bin),
+//   the N = 32768 kernel on its rows (4 B per bin), interleave_kernel.  30 B of HBM traffic per bin, at copy speed.
 // ---------------------------------------------------------------------------
-template <int R, bool FIRST, bool LAST, int FMT>
-__global__ __launch_bounds__(256) void big_pass_kernel(BigArgs a)
+// ---------------------------------------------------------------------------
+// fold_kernel: first pass of the two-pass form of a large transform (see FoldArgs).  One thread owns two neighbouring
+// columns i, i+1 and walks down the rows of its group: per row it reads the 2 R samples of its columns (16 bytes per
+// block, consecutive lanes consecutive columns), does the radix-R butterfly across the blocks and writes R pairs.
+// Window coefficients and rotations depend on the column only and stay in registers for all rows (R <= 16).
+// Bound: HBM -- hop x 8 B in, 8 B per bin out.
+// ---------------------------------------------------------------------------
+template <int R, int FMT> __global__ __launch_bounds__(256) void fold_kernel(FoldArgs a)
 {
-    const int per_row = a.n / R;                                  // butterflies per row (multiple of 256)
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t row = g / per_row;
-    if (row >= a.rows) return;
-    const int j = (int)(g - row * per_row);
-    v2f v[R];
-    if constexpr (FIRST) {
-        using S = Sample<FMT>;
-        const int64_t s0 = (a.first_row + row) * (int64_t)a.hop;
-        const __amdgpu_buffer_rsrc_t rs =
-            make_rsrc(reinterpret_cast<const char *>(a.iq) + s0 * S::BYTES, (unsigned)a.n * S::BYTES);
-        const v2f gain2 = (v2f){0.0f, a.gain};
+    using S = Sample<FMT>;
+    constexpr bool RES = R <= 16;                                  // rotations resident (R = 32: re-read per row, from L2)
+    const int pair = blockIdx.x * 256 + threadIdx.x;               // columns 2 pair, 2 pair + 1;  2 pair < m
+    const int64_t per = (a.rows + gridDim.y - 1) / gridDim.y;
+    const int64_t r0 = (int64_t)blockIdx.y * per, r1 = r0 + per < a.rows ? r0 + per : a.rows;
+    if (r0 >= r1) return;
+    const int m = a.m;
+    v2f w[R];
+    v4f rot[RES ? R : 1];
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const int n = j + k * per_row;
-            const float w = a.window[n];
-            v[k] = (S::load(rs, n * S::BYTES, 0) + gain2) * (v2f){w, w};
-        }
-    } else {
-        const float2 *in = a.in + row * (int64_t)a.n;
-        const int kk = j & (a.ns - 1);
-        const int step = a.n / (a.ns * R);                        // table stride of this pass
+    for (int r = 0; r < R; ++r) {
+        const float2 t = reinterpret_cast<const float2 *>(a.window + (int64_t)r * m)[pair];
+        w[r] = (v2f){t.x, t.y};
+    }
+    const float4 *rot4 = reinterpret_cast<const float4 *>(a.rot);
+    if constexpr (RES) {
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const float2 x = in[j + k * per_row];
-            v[k] = (v2f){x.x, x.y};
-            if (k > 0) {
-                const float2 t = a.tw[(int64_t)k * kk * step];    // k*kk*step < N
-                v[k] = cmul(v[k], (v2f){t.x, t.y});
-            }
+        for (int q = 1; q < R; ++q) {
+            const float4 t = rot4[(int64_t)q * (m / 2) + pair];
+            rot[q] = (v4f){t.x, t.y, t.z, t.w};
         }
     }
-    dif<R>(v);
-    const int j0 = (j / a.ns) * (a.ns * R) + (j & (a.ns - 1));
-    if constexpr (LAST) {
-        float *out = a.rows_out + row * a.row_stride;
+    const v2f gain2 = (v2f){0.0f, a.gain};
+    const char *iq = reinterpret_cast<const char *>(a.iq);
+    for (int64_t row = r0; row < r1; ++row) {
+        const __amdgpu_buffer_rsrc_t rs =
+            make_rsrc(iq + (a.first_row + row) * (int64_t)a.hop * S::BYTES, (unsigned)m * R * S::BYTES);
+        v2f u[R], v[R];
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const v2f x = v[bitrev<R>(k)];
-            const v2f sq = x * x;
-            out[(j0 + k * a.ns + a.n / 2) & (a.n - 1)] = __builtin_amdgcn_sqrtf(sq.x + sq.y);
+        for (int r = 0; r < R; ++r) {
+            S::load_pair(rs, pair * 2 * S::BYTES, r * m * S::BYTES, u[r], v[r]);
         }
-    } else {
-        float2 *out = a.out + row * (int64_t)a.n;
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const v2f x = v[bitrev<R>(k)];
-            out[j0 + k * a.ns] = make_float2(x.x, x.y);
+        for (int r = 0; r < R; ++r) {
+            if (a.gain != 0.0f) { u[r] = u[r] + gain2; v[r] = v[r] + gain2; }
+            u[r] = u[r] * w[r].xx;
+            v[r] = v[r] * w[r].yy;
+        }
+        dif<R>(u);
+        dif<R>(v);
+        float4 *out = reinterpret_cast<float4 *>(a.out + row * (int64_t)R * m) + pair;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            v2f x = u[bitrev<R>(q)], y = v[bitrev<R>(q)];
+            if (q > 0) {
+                v4f t;
+                if constexpr (RES) t = rot[q];
+                else {
+                    const float4 l = rot4[(int64_t)q * (m / 2) + pair];
+                    t = (v4f){l.x, l.y, l.z, l.w};
+                }
+                x = cmul(x, t.xy);
+                y = cmul(y, t.zw);
+            }
+            out[(int64_t)q * (m / 2)] = make_float4(x.x, x.y, y.x, y.y);
         }
     }
 }
 
-// ---------------------------------------------------------------------------
-// Large transforms in two passes (bins = dec x M, the station sizes of Bolidozor.json:45 and Ionozor.json:27).
-// Pass A: stft_kernel MODE 2, `dec` decimated length-M transforms per row with the single-pass plans
-// (S_r[k'] = sum_m w[r + dec m] x[r + dec m] exp(-2 pi i m k'/M)), spectra to a scratch block small enough to stay in
-// the 256 MiB Infinity Cache.  Pass B, here: X[k' + M q] = sum_r W_dec^(r q) (W_bins^(r k') S_r[k']) -- one thread per
-// k', a radix-dec butterfly in registers, twiddles from one exp(-2 pi i j/bins) table (exact entries), magnitudes out
-// in runs of consecutive k' (coalesced), fft-shifted.  HBM traffic per row: hop*8 in, 8 bins out and in again, 4 bins
-// out -- against 16 B per point and pass for the four or five passes of big_pass_kernel (which remains for the
-// multi-pass FP64 mode's structure and as the fallback below 64 Ki... see launch_transform).
-// ---------------------------------------------------------------------------
-template <int R> __global__ __launch_bounds__(256) void combine_kernel(CombineArgs a)
-{
-    // two consecutive k' per thread: 16-byte loads of sub-spectra and twiddles, 8-byte stores
-    const int per_row = a.m / 2;
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t row = g / per_row;
-    if (row >= a.rows) return;
-    const int k = 2 * (int)(g - row * per_row);
-    const float4 *in = reinterpret_cast<const float4 *>(a.spec + (row * R) * (int64_t)a.m + k);
-    const float4 *tw = reinterpret_cast<const float4 *>(a.tw + k);
-    const int m4 = a.m / 2;                                       // float4 units per sub-spectrum
-    v2f u[R], v[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const float4 x = in[(int64_t)r * m4];
-        u[r] = (v2f){x.x, x.y};
-        v[r] = (v2f){x.z, x.w};
-        if (r > 0) {
-            const float4 t = tw[(int64_t)r * m4];                 // W_bins^(r k'), W_bins^(r (k'+1)): combine-order table
-            u[r] = cmul(u[r], (v2f){t.x, t.y});
-            v[r] = cmul(v[r], (v2f){t.z, t.w});
-        }
-    }
-    dif<R>(u);
-    dif<R>(v);
-    float *out = a.rows_out + row * a.row_stride;
-    const int n = a.m * R;
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-        const v2f x = u[bitrev<R>(q)], y = v[bitrev<R>(q)];
-        const v2f sx = x * x, sy = y * y;
-        const v2f mag = (v2f){__builtin_amdgcn_sqrtf(sx.x + sx.y), __builtin_amdgcn_sqrtf(sy.x + sy.y)};
-        // k even: no wrap inside the pair; write-once rows: non-temporal
-        __builtin_nontemporal_store(mag, reinterpret_cast<v2f *>(out + ((k + q * a.m + n / 2) & (n - 1))));
-    }
-}
 
 // ---------------------------------------------------------------------------
 // Strict precision (ro_stft_config_t::precision = RO_PRECISION_F64): the reference's arithmetic type.  FFTBackend
@@ -2064,21 +2021,11 @@ using Plan256   = Plan<  256,   64,  4,  4,  4, 4, false>;
 template <class PL> static hipError_t launch_fmt(const StftArgs &a, int fmt, hipStream_t s)
 {
     const bool spec = a.spec_out != nullptr;
-    if (a.dec > 1 && a.dif_rot) {                      // a large transform in one kernel (MODE 3)
+    if (a.big_form) {                                  // a large transform in one kernel (MODE 3)
         if constexpr (PL::N == 32768) {
             if (spec) return hipErrorInvalidValue;
             if (fmt == RO_FMT_F32) return launch_plan<PL, RO_FMT_F32, 3>(a, s);
             if (fmt == RO_FMT_I16) return launch_plan<PL, RO_FMT_I16, 3>(a, s);
-        }
-        return hipErrorInvalidValue;
-    }
-    if (a.dec > 1) {                                   // sub-transforms of a large transform: decimated in, spectra out
-        // (not for the 1024-thread N = 32768 plan: with unpaired loads its window coefficients take 32 registers
-        // and it spills; big_split never asks for it)
-        if constexpr (PL::N <= 16384) {
-            if (!spec) return hipErrorInvalidValue;
-            if (fmt == RO_FMT_F32) return launch_plan<PL, RO_FMT_F32, 2>(a, s);
-            if (fmt == RO_FMT_I16) return launch_plan<PL, RO_FMT_I16, 2>(a, s);
         }
         return hipErrorInvalidValue;
     }
@@ -2238,77 +2185,66 @@ bool big_supported(int bins)
     return bins > 32768 && bins <= (1 << 20) && (bins & (bins - 1)) == 0;
 }
 
-int big_radices(int bins, int radices[8])
+// interleave_kernel: [dec][m] -> [m][dec] per stream row through an LDS tile of 256 columns (reads: dec runs of 1 KiB,
+// writes: one run of dec KiB).  Bound: HBM, 4 B per bin each way.
+template <int R> __global__ __launch_bounds__(256) void interleave_kernel(InterleaveArgs a)
 {
-    if (!big_supported(bins)) return 0;
-    int l = 0;
-    while ((1 << l) < bins) ++l;
-    int n = 0;
-    while (l >= 4 + 1 || l == 4) {          // radix 16 while at least one more bit (or exactly 4) remains
-        radices[n++] = 16;
-        l -= 4;
-        if (l < 4) break;
+    __shared__ float tile[R][257];
+    const int j0 = blockIdx.x * 256, t = threadIdx.x;
+    const int64_t row = blockIdx.y;
+    const float *in = a.in + row * (int64_t)R * a.m + j0;
+#pragma unroll
+    for (int q = 0; q < R; ++q) tile[q][t] = __builtin_nontemporal_load(in + (int64_t)q * a.m + t);
+    __syncthreads();
+    float *out = a.out + row * a.row_stride + (int64_t)j0 * R;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int e = t + 256 * i;                                 // element of the tile's output run: column j0 R + e
+        __builtin_nontemporal_store(tile[e % R][e / R], out + e);
     }
-    if (l > 0) radices[n++] = 1 << l;       // last pass: 2, 4 or 8
-    return n;
 }
 
-template <int R, bool FIRST, bool LAST, int FMT> static hipError_t launch_big(const BigArgs &a, hipStream_t s)
-{
-    const int64_t total = a.rows * (int64_t)(a.n / R);
-    const int64_t blocks = (total + 255) / 256;
-    if (blocks > 0x7fffffff) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((big_pass_kernel<R, FIRST, LAST, FMT>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_big_pass(int radix, bool first, bool last, int fmt, const BigArgs &a, hipStream_t s)
+hipError_t launch_interleave(const InterleaveArgs &a, hipStream_t s)
 {
     if (a.rows <= 0) return hipSuccess;
-    if (first && !last && radix == 16)
-        return fmt == RO_FMT_I16 ? launch_big<16, true, false, RO_FMT_I16>(a, s)
-                                 : launch_big<16, true, false, RO_FMT_F32>(a, s);
-    if (!first && !last && radix == 16) return launch_big<16, false, false, RO_FMT_F32>(a, s);
-    if (!first && last) {
-        switch (radix) {
-        case 2:  return launch_big<2, false, true, RO_FMT_F32>(a, s);
-        case 4:  return launch_big<4, false, true, RO_FMT_F32>(a, s);
-        case 8:  return launch_big<8, false, true, RO_FMT_F32>(a, s);
-        case 16: return launch_big<16, false, true, RO_FMT_F32>(a, s);
-        }
-    }
-    return hipErrorInvalidValue;
-}
-
-// bins = dec x sub_bins: radix 16 on top of the single-pass plans where the size allows (radix 32 for 2^20)
-bool big_split(int bins, int *sub_bins, int *dec)
-{
-    if (!big_supported(bins)) return false;
-    // The smallest decimation the single-pass plans allow: phase r of a row reads every dec-th sample, so one of its
-    // wave-loads touches dec times the cache lines of a contiguous one (measured at 65536: 16 x 4096 0.33 us per row
-    // in the first pass, TA-bound).  2^20 would need 32 x 32768 (the one plan without a decimated form: unpaired loads
-    // make it spill) and stays on the multi-pass kernels.
-    const int d = bins / 16384;                                   // 65536 = 4 x 16384 ... 524288 = 32 x 16384
-    if (d > 32) return false;
-    *dec = d;
-    *sub_bins = bins / d;
-    return stft_supported(*sub_bins);
-}
-
-hipError_t launch_combine(const CombineArgs &a, hipStream_t s)
-{
-    if (a.rows <= 0) return hipSuccess;
-    const int64_t blocks = (a.rows * (int64_t)(a.m / 2) + 255) / 256;
-    if (blocks > 0x7fffffff) return hipErrorInvalidValue;
+    if (a.m % 256 != 0 || a.rows > 65535) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)(a.m / 256), (unsigned)a.rows);
     switch (a.dec) {
-    case 2:  hipLaunchKernelGGL(combine_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
-    case 4:  hipLaunchKernelGGL(combine_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
-    case 8:  hipLaunchKernelGGL(combine_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
-    case 16: hipLaunchKernelGGL(combine_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
-    case 32: hipLaunchKernelGGL(combine_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+    case 2:  hipLaunchKernelGGL(interleave_kernel<2>, grid, dim3(256), 0, s, a); break;
+    case 4:  hipLaunchKernelGGL(interleave_kernel<4>, grid, dim3(256), 0, s, a); break;
+    case 8:  hipLaunchKernelGGL(interleave_kernel<8>, grid, dim3(256), 0, s, a); break;
+    case 16: hipLaunchKernelGGL(interleave_kernel<16>, grid, dim3(256), 0, s, a); break;
+    case 32: hipLaunchKernelGGL(interleave_kernel<32>, grid, dim3(256), 0, s, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+template <int R> static hipError_t launch_fold_r(int format, const FoldArgs &a, hipStream_t s)
+{
+    // m / 2 column pairs: m / 512 blocks across; enough row groups down to fill the device a few times over
+    const unsigned bx = (unsigned)(a.m / 512);
+    int64_t groups = (2048 + bx - 1) / bx;
+    if (groups > a.rows) groups = a.rows;
+    const dim3 grid(bx, (unsigned)groups);
+    if (format == RO_FMT_F32) hipLaunchKernelGGL((fold_kernel<R, RO_FMT_F32>), grid, dim3(256), 0, s, a);
+    else if (format == RO_FMT_I16) hipLaunchKernelGGL((fold_kernel<R, RO_FMT_I16>), grid, dim3(256), 0, s, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_fold(int format, const FoldArgs &a, hipStream_t s)
+{
+    if (a.rows <= 0) return hipSuccess;
+    if (a.m % 512 != 0) return hipErrorInvalidValue;
+    switch (a.dec) {
+    case 2:  return launch_fold_r<2>(format, a, s);
+    case 4:  return launch_fold_r<4>(format, a, s);
+    case 8:  return launch_fold_r<8>(format, a, s);
+    case 16: return launch_fold_r<16>(format, a, s);
+    case 32: return launch_fold_r<32>(format, a, s);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 int f64_radices(int bins, int radices[8])

@@ -25,11 +25,9 @@
 // scratch of the two-pass large transforms (sub-spectra between the two kernels), MiB
 // largest bins / 16384 the one-kernel form of the large transforms is used for (see ro_stft_create)
 #ifndef RO_DIF_MAX_DEC
-#define RO_DIF_MAX_DEC 8
+#define RO_DIF_MAX_DEC 4
 #endif
-#ifndef RO_DIF_SUB
-#define RO_DIF_SUB 32768
-#endif
+
 #ifndef RO_SPEC_SCRATCH_MB
 #define RO_SPEC_SCRATCH_MB 2048
 #endif
@@ -100,19 +98,7 @@ std::vector<float2> build_twiddles(int bins)
     return tw;
 }
 
-// exp(-2 pi i m / N) for the multi-pass path, rounded once from long double
-std::vector<float2> build_full_twiddles(int bins)
-{
-    std::vector<float2> tw((size_t)bins);
-    const long double two_pi = 8.0L * atanl(1.0L);
-    for (int m = 0; m < bins; ++m) {
-        const long double ang = -two_pi * (long double)m / (long double)bins;
-        tw[(size_t)m] = make_float2((float)cosl(ang), (float)sinl(ang));
-    }
-    return tw;
-}
-
-// the same table in double, correctly rounded from long double (strict-precision path)
+// exp(-2 pi i m / N) in double, correctly rounded from long double (strict-precision path)
 std::vector<double2> build_full_twiddles_f64(int bins)
 {
     std::vector<double2> tw((size_t)bins);
@@ -191,23 +177,19 @@ struct ro_stft {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     unsigned long long *d_stamps = nullptr;    // diagnostic builds (RO_STAMPS) only
 
-    // large transforms (bins > 32768): full twiddle table + two complex scratch blocks in HBM
-    bool    big = false;
-    float2 *d_tw_big = nullptr;
     unsigned *d_ln_keys = nullptr;     // 16 pairs of min / max keys of ro_stft_ln_tile_resident, used in turn
     unsigned ln_calls = 0;
-    float2 *d_scratch[2] = {nullptr, nullptr};
-    int64_t scratch_rows = 0;
-    // ... in two passes where the size allows (bins = dec x sub_bins): tables of the sub-transform, the window cut
-    // into `dec` decimated tables, one scratch block of sub-spectra
+    // large transforms (bins > 32768 = dec x sub_bins, decimation in frequency on the N = 32768 plan; see ro_stft_create)
+    bool    big = false;
     int     sub_bins = 0, dec = 0;
-    float  *d_window_dec = nullptr;
-    float2 *d_tw_combine = nullptr;    // [dec][sub_bins]: exp(-2 pi i r k' / bins)
-    float2 *d_spec = nullptr;
-    // one-kernel form of the large transforms (decimation in frequency, ro::stft_kernel MODE 3)
-    bool    dif = false;
-    float  *d_window_dif = nullptr;    // [dec][sub_bins]: window block r in the sub-plan's kernel order
-    float2 *d_dif_tw = nullptr;        // exp(-2 pi i j / dec)
+    float2 *d_tw_combine = nullptr;    // [dec][sub_bins]: the rotations exp(-2 pi i q m / bins)
+    bool    dif = false;               // dec <= RO_DIF_MAX_DEC: one kernel sums the row's blocks itself (MODE 3)
+    float  *d_window_dif = nullptr;    // ... [dec][sub_bins]: window block r in the sub-plan's kernel order
+    float2 *d_dif_tw = nullptr;        // ... exp(-2 pi i j / dec)
+    bool    fold = false;              // else fold_kernel to scratch, the N = 32768 kernel on its rows, interleave_kernel
+    float2 *d_spec = nullptr;          // ... the folded sub-rows, [spec_rows][dec][sub_bins] float2
+    float  *d_mag = nullptr;           // ... their magnitudes, [spec_rows][dec][sub_bins]
+    float  *d_ones = nullptr;          // ... a window of ones (the fold has applied the real one)
     int64_t spec_rows = 0;
 
     // tile_ln: partial min / max of the fused epilogue's two tile waves (rows x 4 floats), grown on demand
@@ -409,6 +391,46 @@ int launch_transform(ro_stft *h, const void *d_iq, int format, int64_t first_row
         HIP_TRY(ro::launch_stft(h->bins, format, a, s));
         return RO_OK;
     }
+    if (h->dec > 1 && h->fold) {
+        // three steps through scratch, in chunks that fit it: fold_kernel (8 B per bin), the N = 32768 kernel on its
+        // rows -- no overlap, a window of ones -- (4 B per bin), interleave_kernel into the caller's rows
+        if (!h->d_spec) {
+            h->spec_rows = std::max<int64_t>(1, ((int64_t)RO_SPEC_SCRATCH_MB << 20) / ((int64_t)h->bins * 8));
+            if (h->spec_rows > 65535) h->spec_rows = 65535;
+            HIP_TRY(hipMalloc(&h->d_spec, (size_t)h->spec_rows * h->bins * sizeof(float2)));
+            HIP_TRY(hipMalloc(&h->d_mag, (size_t)h->spec_rows * h->bins * sizeof(float)));
+        }
+        for (int64_t done = 0; done < rows; done += h->spec_rows) {
+            const int64_t n = std::min(h->spec_rows, rows - done);
+            ro::FoldArgs f{};
+            f.iq = d_iq;
+            f.window = h->d_window;
+            f.rot = h->d_tw_combine;
+            f.out = h->d_spec;
+            f.first_row = first_row + done;
+            f.rows = n;
+            f.hop = h->hop;
+            f.m = h->sub_bins;
+            f.dec = h->dec;
+            f.gain = (float)h->cfg.iq_gain;
+            HIP_TRY(ro::launch_fold(format, f, s));
+            ro::StftArgs a = make_stft_args(h, h->d_spec, 0, n * h->dec, h->d_mag, h->sub_bins);
+            a.window = h->d_ones;
+            a.window_k = h->d_ones;
+            a.hop = h->sub_bins;
+            a.gain = 0.0f;
+            HIP_TRY(ro::launch_stft(h->sub_bins, RO_FMT_F32, a, s));
+            ro::InterleaveArgs t{};
+            t.in = h->d_mag;
+            t.out = d_rows + done * row_stride;
+            t.rows = n;
+            t.row_stride = row_stride;
+            t.m = h->sub_bins;
+            t.dec = h->dec;
+            HIP_TRY(ro::launch_interleave(t, s));
+        }
+        return RO_OK;
+    }
     if (h->dec > 1 && h->dif) {
         // one kernel, no scratch: kernel row srow * dec + q makes the bins q + dec k' of stream row srow
         int log2 = 0;
@@ -420,72 +442,11 @@ int launch_transform(ro_stft *h, const void *d_iq, int format, int64_t first_row
         a.dec_log2 = log2;
         a.dif_tw = h->d_dif_tw;
         a.dif_rot = h->d_tw_combine;
+        a.big_form = 1;
         HIP_TRY(ro::launch_stft(h->sub_bins, format, a, s));
         return RO_OK;
     }
-    if (h->dec > 1) {
-        // two passes: `dec` decimated sub-transforms per row (spectra to scratch), then the radix-`dec` combine, in
-        // chunks of up to 2 GiB of sub-spectra (8 B per bin).  Chunks small enough to stay in the 256 MiB Infinity
-        // Cache between the two kernels were measured SLOWER (0.121 / 0.130 / 0.141 / 0.144 of the HBM peak with
-        // 96 / 192 / 768 / 2048 MiB at bins = 65536): two launches per 384 rows cost more than the cache gives back.
-        if (!h->d_spec) {
-            h->spec_rows = std::max<int64_t>(1, ((int64_t)RO_SPEC_SCRATCH_MB << 20) / ((int64_t)h->bins * 8));
-            HIP_TRY(hipMalloc(&h->d_spec, (size_t)h->spec_rows * h->bins * sizeof(float2)));
-        }
-        int log2 = 0;
-        while ((1 << log2) < h->dec) ++log2;
-        for (int64_t done = 0; done < rows; done += h->spec_rows) {
-            const int64_t n = std::min(h->spec_rows, rows - done);
-            ro::StftArgs a = make_stft_args(h, d_iq, first_row + done, n * h->dec, nullptr, 0);
-            a.window = h->d_window_dec;
-            a.window_k = h->d_window_dec;
-            a.spec_out = h->d_spec;
-            a.spec_stride = h->sub_bins;
-            a.dec = h->dec;
-            a.dec_log2 = log2;
-            HIP_TRY(ro::launch_stft(h->sub_bins, format, a, s));
-            ro::CombineArgs c{};
-            c.spec = h->d_spec;
-            c.tw = h->d_tw_combine;
-            c.rows_out = d_rows + done * row_stride;
-            c.rows = n;
-            c.row_stride = row_stride;
-            c.m = h->sub_bins;
-            c.dec = h->dec;
-            HIP_TRY(ro::launch_combine(c, s));
-        }
-        return RO_OK;
-    }
-    if (!h->d_scratch[0]) {
-        h->scratch_rows = std::max<int64_t>(1, ((int64_t)512 << 20) / ((int64_t)h->bins * 8));
-        for (int i = 0; i < 2; ++i)
-            HIP_TRY(hipMalloc(&h->d_scratch[i], (size_t)h->scratch_rows * h->bins * sizeof(float2)));
-    }
-    int radix[8];
-    const int passes = ro::big_radices(h->bins, radix);
-    for (int64_t done = 0; done < rows; done += h->scratch_rows) {
-        const int64_t n = std::min(h->scratch_rows, rows - done);
-        ro::BigArgs b{};
-        b.iq = d_iq;
-        b.window = h->d_window;
-        b.tw = h->d_tw_big;
-        b.first_row = first_row + done;
-        b.rows = n;
-        b.row_stride = row_stride;
-        b.hop = h->hop;
-        b.n = h->bins;
-        b.gain = (float)h->cfg.iq_gain;
-        int ns = 1;
-        for (int p = 0; p < passes; ++p) {
-            b.ns = ns;
-            b.in = h->d_scratch[(p + 1) & 1];
-            b.out = h->d_scratch[p & 1];
-            b.rows_out = d_rows + done * row_stride;
-            HIP_TRY(ro::launch_big_pass(radix[p], p == 0, p == passes - 1, format, b, s));
-            ns *= radix[p];
-        }
-    }
-    return RO_OK;
+    return fail(RO_ERR_STATE, "internal: no transform plan for bins = %d", h->bins);
 }
 
 Batch *acquire_batch(ro_stft *h)
@@ -932,17 +893,24 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
         build_window(cfg->window_kind, h->bins, h->window.data());
     h->big = ro::big_supported(h->bins);
     h->f64 = cfg->precision == RO_PRECISION_F64;
-    if (h->big && !ro::big_split(h->bins, &h->sub_bins, &h->dec)) h->sub_bins = h->dec = 0;
     if (h->big && !h->f64) {
-        // The one-kernel form (ro::stft_kernel MODE 3) reads bins / sub_bins x the row through L2 per output row and
-        // nothing extra through HBM: the largest single-pass plan as its base, and only while that beats the two
-        // passes' trip through HBM.  (Diagnostic builds: RO_BIG_FORM=twopass|dif for A/B runs.)
-        const int sub = RO_DIF_SUB, dec = h->bins / sub;
-        bool dif = dec >= 2 && dec <= RO_DIF_MAX_DEC;
+        // bins = dec x 32768, decimation in frequency on the largest single-pass plan:
+        //   X[q + dec k'] = sum_m W_N^(m k') { W_bins^(m q) sum_r W_dec^(r q) w[m + N r] x[m + N r] }
+        // dec <= RO_DIF_MAX_DEC: ONE kernel (ro::stft_kernel MODE 3) that sums the row's dec blocks itself -- dec x the
+        // row through L2 per output row, nothing extra through HBM (0.27 / 0.19 of the HBM peak at 65536 / 131072;
+        // 0.11 / 0.06 at 262144 / 524288, where its 4-byte stores `dec` floats apart cost an L2 write request each).
+        // Above: fold_kernel writes the braces to scratch (8 B per bin), the N = 32768 kernel transforms those rows,
+        // interleave_kernel puts the bins in place: 0.12 of the peak at every size, i.e. the speed of a copy.
+        // (Diagnostic builds: RO_BIG_FORM=dif|fold for A/B runs.)
+        const int sub = 32768, dec = h->bins / sub;
+        int form = dec <= RO_DIF_MAX_DEC ? 1 : 2;
 #ifdef RO_DIAG_KNOBS
-        if (const char *e = getenv("RO_BIG_FORM")) dif = dec >= 2 && dec <= 32 && std::strcmp(e, "dif") == 0;
+        if (const char *e = getenv("RO_BIG_FORM")) form = std::strcmp(e, "dif") == 0 ? 1 : 2;
 #endif
-        if (dif) { h->dif = true; h->sub_bins = sub; h->dec = dec; }
+        h->dif = form == 1;
+        h->fold = form == 2;
+        h->sub_bins = sub;
+        h->dec = dec;
     }
     const int plan_bins = h->big ? h->sub_bins : h->bins;           // whose stage tables this handle needs (0: none)
     std::vector<float2> tw = plan_bins ? build_twiddles(plan_bins) : std::vector<float2>();
@@ -991,13 +959,7 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
         CREATE_TRY(hipMemcpy(h->d_tw_f64, full.data(), sizeof(double2) * full.size(), hipMemcpyHostToDevice));
     }
     if (h->big && h->dec > 1) {
-        // the window cut into `dec` decimated tables: table r holds w[r + dec m], m < sub_bins
-        std::vector<float> wd((size_t)h->bins);
-        for (int r = 0; r < h->dec; ++r)
-            for (int m = 0; m < h->sub_bins; ++m) wd[(size_t)r * h->sub_bins + m] = h->window[(size_t)r + (size_t)h->dec * m];
-        CREATE_TRY(hipMalloc(&h->d_window_dec, sizeof(float) * wd.size()));
-        CREATE_TRY(hipMemcpy(h->d_window_dec, wd.data(), sizeof(float) * wd.size(), hipMemcpyHostToDevice));
-        // the combine's twiddles in the order it reads them, each rounded once from long double
+        // the rotations W_bins^(q m), [dec][sub_bins], each rounded once from long double
         std::vector<float2> tc((size_t)h->bins);
         const long double two_pi = 8.0L * atanl(1.0L);
         for (int r = 0; r < h->dec; ++r)
@@ -1007,6 +969,11 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
             }
         CREATE_TRY(hipMalloc(&h->d_tw_combine, sizeof(float2) * tc.size()));
         CREATE_TRY(hipMemcpy(h->d_tw_combine, tc.data(), sizeof(float2) * tc.size(), hipMemcpyHostToDevice));
+    }
+    if (h->fold) {
+        std::vector<float> ones((size_t)h->sub_bins, 1.0f);
+        CREATE_TRY(hipMalloc(&h->d_ones, sizeof(float) * ones.size()));
+        CREATE_TRY(hipMemcpy(h->d_ones, ones.data(), sizeof(float) * ones.size(), hipMemcpyHostToDevice));
     }
     if (h->dif) {
         std::vector<float> wk((size_t)h->bins);
@@ -1029,11 +996,6 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
         }
         CREATE_TRY(hipMalloc(&h->d_dif_tw, sizeof(float2) * td.size()));
         CREATE_TRY(hipMemcpy(h->d_dif_tw, td.data(), sizeof(float2) * td.size(), hipMemcpyHostToDevice));
-    }
-    if (h->big) {
-        std::vector<float2> full = build_full_twiddles(h->bins);
-        CREATE_TRY(hipMalloc(&h->d_tw_big, sizeof(float2) * full.size()));
-        CREATE_TRY(hipMemcpy(h->d_tw_big, full.data(), sizeof(float2) * full.size(), hipMemcpyHostToDevice));
     }
 #undef CREATE_TRY
 
@@ -1066,18 +1028,16 @@ extern "C" int ro_stft_destroy(ro_stft_t *h)
         h->ready.pop_front();
     }
     for (Batch *b : h->batch_pool) destroy_batch(b);
-    if (h->d_tw_big) (void)hipFree(h->d_tw_big);
-    if (h->d_window_dec) (void)hipFree(h->d_window_dec);
     if (h->d_tw_combine) (void)hipFree(h->d_tw_combine);
     if (h->d_spec) (void)hipFree(h->d_spec);
     if (h->d_window_dif) (void)hipFree(h->d_window_dif);
+    if (h->d_mag) (void)hipFree(h->d_mag);
+    if (h->d_ones) (void)hipFree(h->d_ones);
     if (h->d_dif_tw) (void)hipFree(h->d_dif_tw);
     if (h->d_tw_f64) (void)hipFree(h->d_tw_f64);
     if (h->d_ln_part) (void)hipFree(h->d_ln_part);
     for (int i = 0; i < 2; ++i)
         if (h->d_scratch_d[i]) (void)hipFree(h->d_scratch_d[i]);
-    for (int i = 0; i < 2; ++i)
-        if (h->d_scratch[i]) (void)hipFree(h->d_scratch[i]);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
