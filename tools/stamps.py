@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU box: run a -DRO_STAMPS=1 build (RO_STFT_LIB) on the C3 shape and print the share of each
+"""GPU box: run a -DRO_STAMPS=1 build (RO_STFT_LIB) on the C3 shape (or: stamps.py BINS OVERLAP ROWS) and print the share of each
 phase of the row loop (s_memtime ticks of wave 0 per workgroup, averaged)."""
 import ctypes as C, importlib, os, sys
 import numpy as np, torch
@@ -8,7 +8,7 @@ ro = importlib.import_module("radio-observer_amd")
 lib = ro.library()
 lib.ro_stft_debug_stamps.restype = C.c_int
 lib.ro_stft_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-bins, overlap, R = 32768, 24576, 16384
+bins, overlap, R = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (32768, 24576, 16384)))
 hop = bins - overlap
 samples = bins + hop * (R - 1)
 iq = torch.randn((samples, 2), device="cuda", dtype=torch.float32)
