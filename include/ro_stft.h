@@ -155,8 +155,9 @@ int     ro_allgather_rows(void *nccl_comm, const void *d_local, int64_t local_ro
 /* ro_stitch_rows for device memory: world device-to-device copies on `stream` */
 int     ro_stitch_rows_device(const void *d_gathered, int64_t total_rows, int world, size_t row_bytes, void *d_out,
                               void *stream);
-/* 1 if `bins` has a kernel in this build: powers of two 256 .. 1048576 (single pass up to
- * 32768, multi-pass through HBM scratch above) */
+/* 1 if `bins` has a kernel in this build: powers of two 256 .. 1048576 (one kernel up to
+ * 131072; above, three kernels through HBM scratch that the handle allocates on first use:
+ * 12 bytes per bin and row for up to 2 GiB / (8 bins) rows at a time) */
 int     ro_bins_supported(int bins);
 
 /* ---- handle --------------------------------------------------------------- */

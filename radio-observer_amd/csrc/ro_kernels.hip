@@ -115,6 +115,15 @@
 #ifndef RO_PIPE_TW1_EARLY
 #define RO_PIPE_TW1_EARLY 0
 #endif
+// N = 32768 pipelined plan, experiment (off): the stage twiddles of both twiddled passes resident in LDS -- {w, w^2},
+// {w^4} per butterfly column, 24 KiB + 768 B behind the exchange image and the scan's histogram -- read from there in
+// front of the butterflies, w^8 and w^16 by squaring: no twiddle loads in the row loop (96 KiB less through L2 per
+// row, six 16-byte loads less in a vmcnt queue that also counts the row's stores, no twiddle registers held across
+// the exchanges).  Measured on one device: 0.986-0.997 ms against 0.966-0.971 without (profiles/r02_ab_attempts.txt,
+// block 10) -- the LDS pipe is the scarcer resource, the L2 reads were not what the row waits for.
+#ifndef RO_PIPE_LDS_TW
+#define RO_PIPE_LDS_TW 0
+#endif
 #ifndef RO_PIPE_RES_TW
 #define RO_PIPE_RES_TW 0
 #endif
@@ -166,7 +175,14 @@ template <class PL> constexpr bool plan_swap32() { return plan_addtid<PL>() && R
 template <class PL> constexpr bool plan_pipe() { return plan_addtid<PL>() && RO_PIPE && PL::T == 1024 && !RO_ABLATE; }
 // dynamic LDS of a plan: the exchange image; behind it, for the pipelined add-TID plan, 1 KiB of histogram for the
 // fused scan's radix select
-template <class PL> constexpr int plan_lds_bytes() { return PL::LDS_BYTES + (plan_pipe<PL>() ? 1024 : 0); }
+template <class PL> constexpr int plan_tw_lds_bytes()
+{
+    return plan_pipe<PL>() && RO_PIPE_LDS_TW ? (PL::NS2 + PL::NS1) * 24 : 0;
+}
+template <class PL> constexpr int plan_lds_bytes()
+{
+    return PL::LDS_BYTES + (plan_pipe<PL>() ? 1024 : 0) + plan_tw_lds_bytes<PL>();
+}
 
 // Paired sample loads: which stage-0 column a thread transforms, and the first sample it fetches.
 // Lanes l, l^1 (default) or l, l+32 (swap32) fetch the SAME two adjacent columns with 16-byte loads, one lane
@@ -1076,6 +1092,34 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
         rtw[2] = unit_lo(PL::PK2, PL::NS2, 0);
         rtw[3] = unit_lo(PL::PK2, PL::NS2, 1);
     }
+    // RO_PIPE_LDS_TW: the tables, filled once (the first barrier of the row loop comes before their first use)
+    constexpr bool LDS_TW = PIPE && RO_PIPE_LDS_TW && !RO_PIPE_RES_TW;
+    float4 *twl_a2 = reinterpret_cast<float4 *>(smem + PL::LDS_BYTES + 1024);          // {w, w^2}, pass 2: NS2 entries
+    float2 *twl_b2 = reinterpret_cast<float2 *>(twl_a2 + PL::NS2);                      // {w^4}
+    float4 *twl_a1 = reinterpret_cast<float4 *>(twl_b2 + PL::NS2);                      // pass 1: NS1 entries
+    float2 *twl_b1 = reinterpret_cast<float2 *>(twl_a1 + PL::NS1);
+    if constexpr (LDS_TW) {
+        static_assert(PL::NS2 == T && PL::NS1 <= T, "one thread per table entry");
+        const float4 *pk = reinterpret_cast<const float4 *>(a.twiddles_k);
+        const float4 u0 = pk[PL::PK2 + tid], u1 = pk[PL::PK2 + PL::NS2 + tid];
+        twl_a2[tid] = u0;
+        twl_b2[tid] = make_float2(u1.x, u1.y);
+        if (tid < PL::NS1) {
+            const float4 s0 = pk[PL::PK1 + tid], s1 = pk[PL::PK1 + PL::NS1 + tid];
+            twl_a1[tid] = s0;
+            twl_b1[tid] = make_float2(s1.x, s1.y);
+        }
+    }
+    // twiddles of a pass from the LDS tables: t = {w, w^2, w^4, w^8, w^16}
+    auto tw_from_lds = [&](v2f (&t)[TW_SET], const float4 *ta, const float2 *tb, int k) {
+        const float4 x = ta[k];
+        const float2 y = tb[k];
+        t[0] = (v2f){x.x, x.y};
+        t[1] = (v2f){x.z, x.w};
+        t[2] = (v2f){y.x, y.y};
+        t[3] = cmul(t[2], t[2]);
+        t[4] = cmul(t[3], t[3]);
+    };
     const float *prev_out = a.rows_out;
     unsigned prev_bytes = 0;
     unsigned touch = 0;                    // destination of the next-row prefetch touches (touch_next)
@@ -1269,13 +1313,13 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
             // that the wait for them does not also cover the stores' acknowledgements -- vmcnt retires in issue order
             // and counts stores.  Measured 0.957-0.974 ms against 0.947-0.957 without: the acknowledgements are not
             // what pass 1 waits for.)
-            if constexpr (!RO_PIPE_RES_TW && RO_PIPE_TW1_EARLY) tw_prefetch<P, T, 32, PL::NS1, PL::TW1, PL::PK1>(tw1, rs_tw, rs_twk, tid);
+            if constexpr (!LDS_TW && !RO_PIPE_RES_TW && RO_PIPE_TW1_EARLY) tw_prefetch<P, T, 32, PL::NS1, PL::TW1, PL::PK1>(tw1, rs_tw, rs_twk, tid);
             dit32_head(v, [&](auto hc) {
                 constexpr int h = decltype(hc)::value;
                 if constexpr (RO_PIPE_WSTORES) store_chunk(4 + h, rs_prev);
                 else { store_chunk(2 * h, rs_prev); store_chunk(2 * h + 1, rs_prev); }
             });
-            if constexpr (!RO_PIPE_RES_TW && !RO_PIPE_TW1_EARLY) tw_prefetch<P, T, 32, PL::NS1, PL::TW1, PL::PK1>(tw1, rs_tw, rs_twk, tid);
+            if constexpr (!LDS_TW && !RO_PIPE_RES_TW && !RO_PIPE_TW1_EARLY) tw_prefetch<P, T, 32, PL::NS1, PL::TW1, PL::PK1>(tw1, rs_tw, rs_twk, tid);
             stamp(2);                               // butterflies 0, levels 0..3 (+ the previous row's read-back and stores)
             wg_sync();                              // every wave has read its part of the image back: LDS is free
             stamp(7);
@@ -1290,6 +1334,7 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
             exchange_tail<1, SWAP32>(smem, v, tid);
             stamp(3);                               // exchange 1
             // ---- pass 1
+            if constexpr (LDS_TW) tw_from_lds(tw1[0], twl_a1, twl_b1, tid & (PL::NS1 - 1));
             if constexpr (RO_PIPE_RES_TW) {
                 tw1[0][0] = rtw[0];
                 tw1[0][1] = cmul(rtw[0], rtw[0]);
@@ -1301,7 +1346,7 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
             // the touch sits behind the butterflies: in front of them hipcc's wait for this pass's twiddles would sit
             // through the touch's HBM miss as well
             touch_next();
-            if constexpr (!RO_PIPE_RES_TW) tw_prefetch<P, T, 32, PL::NS2, PL::TW2, PL::PK2>(tw2, rs_tw, rs_twk, tid);
+            if constexpr (!LDS_TW && !RO_PIPE_RES_TW) tw_prefetch<P, T, 32, PL::NS2, PL::TW2, PL::PK2>(tw2, rs_tw, rs_twk, tid);
             stamp(4);
             wg_sync();                              // exchange 1's y plane has been gathered by everyone
             stamp(11);
@@ -1315,6 +1360,7 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
             exchange_tail<2, SWAP32>(smem, v, tid);
             stamp(5);                               // exchange 2
             // ---- pass 2
+            if constexpr (LDS_TW) tw_from_lds(tw2[0], twl_a2, twl_b2, tid & (PL::NS2 - 1));
             if constexpr (RO_PIPE_RES_TW) {
                 tw2[0][0] = rtw[2];
                 tw2[0][1] = cmul(rtw[2], rtw[2]);
