@@ -67,6 +67,15 @@
 #define RO_PREFETCH_NEXT 2
 #endif
 // LDS exchange of the N = 32768 plan through ds_write_addtid_b32 (1) or plain ds_write_b32 (0)
+// the N = 16384 plan on the add-TID exchange as well (0: the generic ds_write_b32 exchange)
+#ifndef RO_ADDTID_16384
+#define RO_ADDTID_16384 1
+#endif
+// ... and the N = 8192 plan (split planes, tables re-read per row, four workgroups of 256 threads per CU instead of
+// two with window and twiddles resident in 234 VGPRs)
+#ifndef RO_ADDTID_8192
+#define RO_ADDTID_8192 1
+#endif
 #ifndef RO_USE_ADDTID
 #define RO_USE_ADDTID 1
 #endif
@@ -163,12 +172,14 @@ struct Plan {
     static_assert(P % R0 == 0 && P % R1 == 0 && P % R2 == 0 && P % R3 == 0, "radix must divide P");
 };
 
-// the N = 32768 plan exchanges through ds_write_addtid_b32 (see exchange_addtid)
+// the N = 32768 and 16384 plans exchange through ds_write_addtid_b32 (see exchange_addtid): N / 32 "logical threads",
+// one radix-32 butterfly each in the first two stages (T threads run P / 32 of them each: 1024 x 1, 512 x 2 or -- N =
+// 16384 -- 512 x 1), a last stage of radix N / 1024
 template <class PL> constexpr bool plan_addtid()
 {
-    // T threads run the 1024 "logical threads" of the scheme, P / 32 each (1024 x 1 or 512 x 2)
-    return RO_USE_ADDTID && PL::N == 32768 && (PL::T == 1024 || PL::T == 512) && PL::T * (PL::P / 32) == 1024 &&
-           PL::R0 == 32 && PL::R1 == 32 && PL::R2 == 32 && PL::R3 == 1 && PL::SPLIT;
+    return RO_USE_ADDTID && (PL::N == 32768 || (PL::N == 16384 && RO_ADDTID_16384) || (PL::N == 8192 && RO_ADDTID_8192)) &&
+           PL::T * (PL::P / 32) == PL::N / 32 && PL::T % 64 == 0 && PL::R0 == 32 && PL::R1 == 32 &&
+           PL::R2 == PL::N / 1024 && PL::R3 == 1 && PL::SPLIT;
 }
 template <class PL> constexpr bool plan_swap32() { return plan_addtid<PL>() && RO_SWAP32 && RO_PAIRED_LOADS; }
 // the pipelined row loop (RO_PIPE) with the fused scan: 1024-thread add-TID plan, magnitude mode
@@ -290,7 +301,9 @@ __device__ __forceinline__ v2f tw_load(__amdgpu_buffer_rsrc_t tw, int koff, int 
 // that they are issued BEFORE the LDS exchange of the stage and land while the workgroup sits in its barriers.
 constexpr int TW_SET = 7;     // twiddles held per butterfly: R=32: 5, R=16: 6, R<=8: R-1
 
-template <int P, int T, int R, int NS, int OFF, int PK>
+// C8 (radix 8 only): load w, w^2, w^4 and let tw_apply make the other four by multiplication -- 6 registers held per
+// butterfly across the exchange instead of 14 (the N = 8192 add-TID plan has four radix-8 butterflies per thread)
+template <int P, int T, int R, int NS, int OFF, int PK, bool C8 = false>
 __device__ __forceinline__ void tw_prefetch(v2f (&t)[P / R][TW_SET], __amdgpu_buffer_rsrc_t tw,
                                             __amdgpu_buffer_rsrc_t twk, int tid)
 {
@@ -312,6 +325,10 @@ __device__ __forceinline__ void tw_prefetch(v2f (&t)[P / R][TW_SET], __amdgpu_bu
         } else if constexpr (R >= 16) {          // RO_ABLATE & 1: no loads
 #pragma unroll
             for (int c = 0; c < TW_SET; ++c) t[b][c] = tw_load(tw, koff, 0);
+        } else if constexpr (C8 && R == 8) {
+            t[b][0] = tw_load(tw, koff, OFF);
+            t[b][1] = tw_load(tw, koff, OFF + NS);
+            t[b][3] = tw_load(tw, koff, OFF + 3 * NS);
         } else {
 #pragma unroll
             for (int r = 1; r < R; ++r) t[b][r - 1] = tw_load(tw, koff, OFF + (r - 1) * NS);
@@ -321,12 +338,23 @@ __device__ __forceinline__ void tw_prefetch(v2f (&t)[P / R][TW_SET], __amdgpu_bu
 
 // stage twiddles applied up front: x[r] *= w^r, all R-1 powers held (radix <= 8; larger radices go through
 // tw_butterflies' fused forms and only come here in the RO_ABLATE & 8 diagnostic build, where results do not matter)
-template <int P, int R>
+template <int P, int R, bool C8 = false>
 __device__ __forceinline__ void tw_apply(v2f (&v)[P], const v2f (&t)[P / R][TW_SET])
 {
 #pragma unroll
     for (int b = 0; b < P / R; ++b) {
         v2f *x = &v[b * R];
+        if constexpr (C8 && R == 8) {
+            const v2f w1 = t[b][0], w2 = t[b][1], w4 = t[b][3], w3 = cmul(w1, w2);
+            x[1] = cmul(x[1], w1);
+            x[2] = cmul(x[2], w2);
+            x[3] = cmul(x[3], w3);
+            x[4] = cmul(x[4], w4);
+            x[5] = cmul(x[5], cmul(w4, w1));
+            x[6] = cmul(x[6], cmul(w4, w2));
+            x[7] = cmul(x[7], cmul(w4, w3));
+            continue;
+        }
 #pragma unroll
         for (int r = 1; r < R; ++r) x[r] = cmul(x[r], t[b][R <= 8 ? r - 1 : r % 5]);
     }
@@ -336,7 +364,7 @@ __device__ __forceinline__ void tw_apply(v2f (&v)[P], const v2f (&t)[P / R][TW_S
 // ro_fft_device.h).  Radix 16 fuses them into the first level:
 //   A = x[r] w^r (two ops),  a' = A + x[r+R/2] w^(r+R/2) (two FMAs),  b' = 2A - a' (one)
 // five issue slots per pair where twiddling both and then adding / subtracting takes six.
-template <int P, int R>
+template <int P, int R, bool C8 = false>
 __device__ __forceinline__ void tw_butterflies(v2f (&v)[P], const v2f (&t)[P / R][TW_SET])
 {
     if constexpr (R >= 16 && !(RO_ABLATE & 8)) {
@@ -370,7 +398,7 @@ __device__ __forceinline__ void tw_butterflies(v2f (&v)[P], const v2f (&t)[P / R
             else dit_after_first_level<R>(x);
         }
     } else {
-        tw_apply<P, R>(v, t);
+        tw_apply<P, R, C8>(v, t);
         butterflies<P, R>(v);
     }
 }
@@ -519,24 +547,34 @@ template <int ROWB, typename F> __device__ __forceinline__ void addtid_scatter32
                                                   f(31));
 }
 
-// XCH = 1: between stage 0 and 1, XCH = 2: between stage 1 and 2   (N = 32768, T = 1024, radix 32 everywhere)
+// XCH = 1: between stage 0 and 1, XCH = 2: between stage 1 and 2.  TL = N / 32 logical threads (1024 or 512), radix 32
+// in stages 0 and 1, R2 = TL / 32 in stage 2 (32 / R2 butterflies per logical thread).  With S = TL / 32:
+//   after stage 0 (element i = 32 j + r):               image[r*(TL+1) + j]   gather (j'&31)*(TL+1) + (j'>>5) + S r'
+//   after stage 1 (i = (j>>5)*1024 + (j&31) + 32 r):    image[r*TL + j]       gather ((j'>>5) + S b)*TL + (j'&31) + 32 r'
+//                                                                             into slot b R2 + r'  (b < 32 / R2, r' < R2)
 // With swap32 pairing the stage-0 thread at position t of a row holds column (t&~63) + 2(t&31) + ((t>>5)&1), so
-// column j = 32 r' + q sits at 64 (r'>>1) + 16 (r'&1) + 32 (q&1) + (q>>1): still one base + a literal per slot.
+// column c sits at (c&~63) + ((c&63)>>1) + 32 (c&1): column q + S r' at 32 (q&1) + (q>>1) + 64 ((S r')>>6) + ((S r')&63)/2
+// -- still one base + a literal per slot.
 template <int XCH, bool SWAP32, int NB, int T, typename ST>
 __device__ __forceinline__ void exchange_addtid(void *smem, v2f (&v)[32 * NB], int tid, ST sub)
 {
     if constexpr (RO_ABLATE & 4) return;
-    constexpr int ROW = XCH == 1 ? 1025 : 1024;                   // floats per register-slot row of the image
+    constexpr int TL = T * NB, S = TL / 32, R2 = S;
+    constexpr int ROW = XCH == 1 ? TL + 1 : TL;                   // floats per register-slot row of the image
     constexpr bool PERM = XCH == 1 && SWAP32;
+    static_assert(S % 2 == 0 && 32 % R2 == 0, "add-TID exchange: 64 | TL");
     const float *lds = reinterpret_cast<const float *>(smem);
-    // logical thread j = tid + T*b (b < NB) owns registers v[32b .. 32b+31]; everything below is the 1024-thread
-    // scheme written in terms of j
+    // logical thread j = tid + T*b (b < NB) owns registers v[32b .. 32b+31]
     auto wave_bytes = [&](int b) { return (unsigned)__builtin_amdgcn_readfirstlane((tid + T * b) >> 6) * 256u; };
     auto gbase = [&](int b) {
         const int j = tid + T * b, q = j >> 5;
-        return lds + (XCH == 1 ? (j & 31) * 1025 + (PERM ? 32 * (q & 1) + (q >> 1) : q) : (j >> 5) * 1024 + (j & 31));
+        return lds + (XCH == 1 ? (j & 31) * (TL + 1) + (PERM ? 32 * (q & 1) + (q >> 1) : q) : (j >> 5) * TL + (j & 31));
     };
-    auto goff = [](int r) constexpr { return PERM ? 64 * (r >> 1) + 16 * (r & 1) : 32 * r; };
+    // float offset of gather slot r from gbase
+    auto goff = [](int r) constexpr {
+        if (XCH == 1) return PERM ? 64 * ((S * r) >> 6) + (((S * r) & 63) >> 1) : S * r;
+        return (r / R2) * S * TL + 32 * (r % R2);
+    };
     // volatile: keeps the 32 gathers single ds_read_b32 -- merged into ds_read2_b32 they come back as register
     // pairs of one plane and cost a v_mov each to interleave with the other plane (96 VALU ops per row)
     typedef const volatile __attribute__((address_space(3))) float lds_vfloat;
@@ -889,7 +927,13 @@ template <> struct Sample<RO_FMT_I16> {
 #ifndef RO_DIF_WAVES
 #define RO_DIF_WAVES 4
 #endif
-template <class PL, int FMT, int MODE> constexpr int plan_min_waves() { return MODE == 3 ? RO_DIF_WAVES : 1; }
+#ifndef RO_MINW8192
+#define RO_MINW8192 3
+#endif
+template <class PL, int FMT, int MODE> constexpr int plan_min_waves()
+{
+    return MODE == 3 ? RO_DIF_WAVES : (PL::N == 8192 && plan_addtid<PL>()) ? RO_MINW8192 : 1;
+}
 
 template <class PL, int FMT, int MODE>
 __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft_kernel(StftArgs a)
@@ -1058,7 +1102,8 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
     auto win_rsrc = [&](int64_t, bool valid) { return make_rsrc(win_tab, valid ? N * 4 : 0); };
     if constexpr (!DIF) load_window(win_rsrc(row, true), c0{}, cN{});
     // window and twiddle tables resident in registers (see RO_RESIDENT_TABLES)
-    constexpr bool RES = RO_RESIDENT_TABLES && N <= 8192 && !RO_ABLATE;              // twiddles (and window)
+    constexpr bool RES = RO_RESIDENT_TABLES && N <= 8192 && !ADDTID && !RO_ABLATE;   // twiddles (and window)
+    constexpr bool TW8C = ADDTID && PL::R2 == 8;                                     // see tw_prefetch
     // the 512-thread form of the N = 32768 plan has 256 VGPRs per thread: the window stays, the twiddles do not fit
     constexpr bool RESW = RES || (RO_T512_RESW && ADDTID && T == 512 && !RO_ABLATE);
     v2f tw1[PL::R1 > 1 ? P / PL::R1 : 1][TW_SET];
@@ -1504,12 +1549,12 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
         }
         // ---- stage 2
         if constexpr (PL::R2 > 1) {
-            if constexpr (!RES) tw_prefetch<P, T, PL::R2, PL::NS2, PL::TW2, PL::PK2>(tw2, rs_tw, rs_twk, fresh_tid());
+            if constexpr (!RES) tw_prefetch<P, T, PL::R2, PL::NS2, PL::TW2, PL::PK2, TW8C>(tw2, rs_tw, rs_twk, fresh_tid());
             if constexpr (ADDTID) exchange_addtid<2, SWAP32, P / 32, T>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             else exchange<PL, PL::R1, PL::NS1, PL::R2>(smem, v, fresh_tid(), [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             stamp(5);                               // exchange 2
             if constexpr (RO_PREFETCH_NEXT == 3) touch_next();
-            tw_butterflies<P, PL::R2>(v, tw2);
+            tw_butterflies<P, PL::R2, TW8C>(v, tw2);
             stamp(6);                               // twiddles + butterflies 2
 
         }
@@ -1549,19 +1594,21 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
             continue;
         }
         if constexpr (ADDTID) {
-            // slot q of thread `tid` is column tid + 1024 q: byte 4096 q + 4 tid of the LDS image, i.e. the row in
+            // slot q of logical thread j is column j + TL q: byte 4 TL q + 4 j of the LDS image, i.e. the row in
             // natural order, written lane-linearly (ds_write_addtid_b32); the fft-shift moves into the store offsets
+            // (last stage of radix RL < 32: butterfly b2 of the logical thread, output s, is column j + TL (b2 + (32/RL) s))
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 float m[32];
 #pragma unroll
-                for (int r = 0; r < 32; ++r) {
-                    const v2f x = v[32 * b + bitrev<32>(r)];
+                for (int q = 0; q < 32; ++q) {
+                    constexpr int B2 = 32 / RL;
+                    const v2f x = v[32 * b + (q % B2) * RL + bitrev<RL>(q / B2)];
                     const v2f sq = x * x;
-                    m[r] = __builtin_amdgcn_sqrtf(sq.x + sq.y);      // v_sqrt_f32, 1 ulp
+                    m[q] = __builtin_amdgcn_sqrtf(sq.x + sq.y);      // v_sqrt_f32, 1 ulp
                 }
                 const unsigned wave_bytes = (unsigned)__builtin_amdgcn_readfirstlane((tid + T * b) >> 6) * 256u;
-                addtid_scatter32<4096>(wave_bytes, [&](int q) { return m[q]; });
+                addtid_scatter32<TL * 4>(wave_bytes, [&](int q) { return m[q]; });
             }
         } else {
             float *lds_m = reinterpret_cast<float *>(smem);
@@ -2057,7 +2104,7 @@ template <class PL, int FMT, int MODE> static hipError_t launch_plan(const StftA
 //                      N      T   R0  R1  R2  R3  split
 using Plan32768 = Plan<32768, RO_T32768, 32, 32, 32, 1, true>;
 using Plan16384 = Plan<16384,  512, 32, 32, 16, 1, true>;
-using Plan8192  = Plan< 8192,  256, 32, 32,  8, 1, false>;
+using Plan8192  = Plan< 8192,  256, 32, 32,  8, 1, (RO_ADDTID_8192 && RO_USE_ADDTID)>;
 using Plan4096  = Plan< 4096,  256, 16, 16, 16, 1, false>;
 using Plan2048  = Plan< 2048,  128, 16, 16,  8, 1, false>;
 using Plan1024  = Plan< 1024,   64, 16, 16,  4, 1, false>;
