@@ -157,7 +157,11 @@ int     ro_stitch_rows_device(const void *d_gathered, int64_t total_rows, int wo
                               void *stream);
 /* 1 if `bins` has a kernel in this build: powers of two 256 .. 1048576 (one kernel up to
  * 131072; above, three kernels through HBM scratch that the handle allocates on first use:
- * 12 bytes per bin and row for up to 2 GiB / (8 bins) rows at a time) */
+ * 12 bytes per bin and row for up to 2 GiB / (8 bins) rows at a time), and every other EVEN
+ * length 258 .. 524286 (FFTW takes any N, src/FFTBackend.cpp:120; src/BolidRecorder.h:35
+ * suggests 32728) as a chirp-z transform on the power-of-two length M >= 2 bins - 1 (scratch:
+ * 20 M bytes per row for up to 1 GiB / (8 M) rows at a time).  Odd lengths have no defined
+ * result in the reference (src/WaterfallBackend.cpp:489-505 leaves the last column unwritten). */
 int     ro_bins_supported(int bins);
 
 /* ---- handle --------------------------------------------------------------- */

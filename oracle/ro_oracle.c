@@ -260,6 +260,55 @@ int ro_oracle_fft_prepare(int bins)
 static void *fft_alloc(size_t bytes) { return g_fftw.on ? g_fftw.malloc_(bytes) : malloc(bytes); }
 static void fft_free(void *p) { if (g_fftw.on) g_fftw.free_(p); else free(p); }
 
+int ro_oracle_fft_f64(int bins, const double *in, double *out);
+
+/* Lengths that are not a power of two (FFTW takes any N, src/FFTBackend.cpp:120; src/BolidRecorder.h:35 suggests
+ * 32728): Bluestein's identity n k = (n^2 + k^2 - (k - n)^2) / 2 turns the N-point DFT into a circular convolution
+ * of length M >= 2 N - 1 (a power of two), done with the radix-2 transform above, all in double with the chirp
+ * exp(-pi i n^2 / N) from long double and its angle reduced exactly (n^2 mod 2N in integers).  Agrees with the
+ * O(N^2) long-double DFT below to ~1e-13 of the largest bin (tests/test_oracle.py). */
+static int fft_bluestein(int n, const double *in, double *out)
+{
+    int m = 2;
+    while (m < 2 * n - 1) m <<= 1;
+    double *c = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    double *a = (double *)calloc(2 * (size_t)m, sizeof(double)), *fa = (double *)malloc(sizeof(double) * 2 * (size_t)m);
+    double *b = (double *)calloc(2 * (size_t)m, sizeof(double)), *fb = (double *)malloc(sizeof(double) * 2 * (size_t)m);
+    int rc = -2;
+    if (c && a && fa && b && fb) {
+        const long double pi = 4.0L * atanl(1.0L);
+        for (int i = 0; i < n; i++) {
+            const long long r = ((long long)i * i) % (2LL * n);
+            const long double ang = -pi * (long double)r / (long double)n;
+            c[2 * i] = (double)cosl(ang);
+            c[2 * i + 1] = (double)sinl(ang);
+            a[2 * i] = in[2 * i] * c[2 * i] - in[2 * i + 1] * c[2 * i + 1];
+            a[2 * i + 1] = in[2 * i] * c[2 * i + 1] + in[2 * i + 1] * c[2 * i];
+            b[2 * i] = c[2 * i];                      /* conj(c), wrapped around m */
+            b[2 * i + 1] = -c[2 * i + 1];
+            if (i) { b[2 * (m - i)] = b[2 * i]; b[2 * (m - i) + 1] = b[2 * i + 1]; }
+        }
+        rc = ro_oracle_fft_f64(m, a, fa) | ro_oracle_fft_f64(m, b, fb);
+        if (rc == 0) {
+            /* y = IFFT(fa fb) = conj(FFT(conj(fa fb))) / m */
+            for (int i = 0; i < m; i++) {
+                const double re = fa[2 * i] * fb[2 * i] - fa[2 * i + 1] * fb[2 * i + 1];
+                const double im = fa[2 * i] * fb[2 * i + 1] + fa[2 * i + 1] * fb[2 * i];
+                a[2 * i] = re;
+                a[2 * i + 1] = -im;
+            }
+            rc = ro_oracle_fft_f64(m, a, fa);
+            for (int k = 0; k < n && rc == 0; k++) {
+                const double yr = fa[2 * k] / m, yi = -fa[2 * k + 1] / m;
+                out[2 * k] = yr * c[2 * k] - yi * c[2 * k + 1];
+                out[2 * k + 1] = yr * c[2 * k + 1] + yi * c[2 * k];
+            }
+        }
+    }
+    free(c); free(a); free(fa); free(b); free(fb);
+    return rc;
+}
+
 int ro_oracle_fft_f64(int bins, const double *in, double *out)
 {
     if (g_fftw.on) {
@@ -282,6 +331,7 @@ int ro_oracle_fft_f64(int bins, const double *in, double *out)
             }
         return -1;
     }
+    if (bins >= 2 && (bins & (bins - 1)) != 0) return fft_bluestein(bins, in, out);
     const fft_plan_t *p = get_plan(bins);
     if (!p) return -1;
     const int n = bins;

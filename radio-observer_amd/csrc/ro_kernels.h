@@ -120,6 +120,34 @@ struct InterleaveArgs {
     int          m, dec;
 };
 hipError_t launch_interleave(const InterleaveArgs &a, hipStream_t s);
+// the same for rows of float2 (complex spectra of a large transform: bin q + dec j from sub-row q, element j)
+struct Interleave2Args {
+    const float2 *in;          // [rows][dec][m]
+    float2       *out;         // [rows][out_stride >= dec m]
+    int64_t       rows, out_stride;
+    int           m, dec;
+};
+hipError_t launch_interleave2(const Interleave2Args &a, hipStream_t s);
+
+// ---- any even length (FFTW takes any N, src/FFTBackend.cpp:120): Bluestein's chirp-z form of the N-point DFT on top
+// of the power-of-two transforms of length M >= 2 N - 1,
+//   X[k] = c[k] sum_n (x[n] c[n]) conj(c)[k - n],   c[n] = exp(-pi i n^2 / N)
+// i.e. a = x w c (zero-padded to M), A = FFT_M(a), y = IFFT_M(A B) with B = FFT_M(conj(c) wrapped), |X[k]| = |y[k]|.
+// The three pointwise steps; the two transforms are the library's own.
+struct CztArgs {
+    const void   *iq;          // pre: sample 0 of the stream
+    const float2 *cw;          // pre: [n] window[i] * c[i]
+    const float2 *bc;          // mul: [m] conj(B) / M
+    float2       *a;           // pre: out [rows][m];  mul: in/out [rows][m] (in: A, out: conj(A) bc = conj(A B) / M)
+    const float  *mag;         // out: [rows][m] magnitudes of FFT_M(conj(A B) / M), fft-shifted by m / 2 like every row
+    float        *rows_out;    // out: [rows][row_stride], column (k + n/2) mod n = |X[k]|
+    int64_t       first_row, rows, row_stride;
+    int           hop, n, m;
+    float         gain;
+};
+hipError_t launch_czt_pre(int format, const CztArgs &a, hipStream_t s);
+hipError_t launch_czt_mul(const CztArgs &a, hipStream_t s);
+hipError_t launch_czt_out(const CztArgs &a, hipStream_t s);
 bool       big_supported(int bins);               // power of two in (32768, 2^20]
 
 bool       stft_supported(int bins);

@@ -2313,6 +2313,111 @@ hipError_t launch_interleave(const InterleaveArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
+template <int R> __global__ __launch_bounds__(256) void interleave2_kernel(Interleave2Args a)
+{
+    __shared__ float2 tile[R][129];
+    const int j0 = blockIdx.x * 128, t = threadIdx.x;
+    const int64_t row = blockIdx.y;
+    const float2 *in = a.in + row * (int64_t)R * a.m + j0;
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) {
+        const int e = t + 256 * i;                                 // R x 128 elements, 128 per sub-row
+        tile[e >> 7][e & 127] = in[(int64_t)(e >> 7) * a.m + (e & 127)];
+    }
+    __syncthreads();
+    float2 *out = a.out + row * a.out_stride + (int64_t)j0 * R;
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) {
+        const int e = t + 256 * i;
+        out[e] = tile[e % R][e / R];
+    }
+}
+
+hipError_t launch_interleave2(const Interleave2Args &a, hipStream_t s)
+{
+    if (a.rows <= 0) return hipSuccess;
+    if (a.m % 128 != 0 || a.rows > 65535) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)(a.m / 128), (unsigned)a.rows);
+    switch (a.dec) {
+    case 2:  hipLaunchKernelGGL(interleave2_kernel<2>, grid, dim3(256), 0, s, a); break;
+    case 4:  hipLaunchKernelGGL(interleave2_kernel<4>, grid, dim3(256), 0, s, a); break;
+    case 8:  hipLaunchKernelGGL(interleave2_kernel<8>, grid, dim3(256), 0, s, a); break;
+    case 16: hipLaunchKernelGGL(interleave2_kernel<16>, grid, dim3(256), 0, s, a); break;
+    case 32: hipLaunchKernelGGL(interleave2_kernel<32>, grid, dim3(256), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Chirp-z (Bluestein) steps for lengths that are not a power of two; see CztArgs.  Plain streaming kernels, one
+// element per thread: HBM-bound and not the benchmarked shape (every shipped config is a power of two).
+// ---------------------------------------------------------------------------
+template <int FMT> __global__ __launch_bounds__(256) void czt_pre_kernel(CztArgs a)
+{
+    using S = Sample<FMT>;
+    const int i = blockIdx.x * 256 + threadIdx.x;                  // < m
+    const int64_t row = blockIdx.y;
+    v2f x = (v2f){0.0f, 0.0f};
+    if (i < a.n) {
+        const char *iq = reinterpret_cast<const char *>(a.iq);
+        const __amdgpu_buffer_rsrc_t rs =
+            make_rsrc(iq + (a.first_row + row) * (int64_t)a.hop * S::BYTES, (unsigned)a.n * S::BYTES);
+        x = S::load(rs, i * S::BYTES, 0);
+        x.y += a.gain;                                             // src/FFTBackend.cpp:78-79
+        const float2 c = a.cw[i];
+        x = cmul(x, (v2f){c.x, c.y});
+    }
+    a.a[row * (int64_t)a.m + i] = make_float2(x.x, x.y);
+}
+
+__global__ __launch_bounds__(256) void czt_mul_kernel(CztArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = blockIdx.y;
+    float2 *p = a.a + row * (int64_t)a.m + i;
+    const float2 x = *p, b = a.bc[i];
+    *p = make_float2(x.x * b.x + x.y * b.y, x.x * b.y - x.y * b.x);      // conj(x) * b
+}
+
+__global__ __launch_bounds__(256) void czt_out_kernel(CztArgs a)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;                  // output column
+    const int64_t row = blockIdx.y;
+    if (k >= a.n) return;
+    // column k holds bin (k + n/2) mod n (src/WaterfallBackend.cpp:492-505, n even); the length-m transform left bin b
+    // at its own column (b + m/2) mod m
+    const int bin = k >= a.n / 2 ? k - a.n / 2 : k + a.n / 2;
+    a.rows_out[row * a.row_stride + k] = a.mag[row * (int64_t)a.m + ((bin + a.m / 2) & (a.m - 1))];
+}
+
+hipError_t launch_czt_pre(int format, const CztArgs &a, hipStream_t s)
+{
+    if (a.rows <= 0) return hipSuccess;
+    if (a.m % 256 != 0 || a.rows > 65535) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)(a.m / 256), (unsigned)a.rows);
+    if (format == RO_FMT_F32) hipLaunchKernelGGL(czt_pre_kernel<RO_FMT_F32>, grid, dim3(256), 0, s, a);
+    else if (format == RO_FMT_I16) hipLaunchKernelGGL(czt_pre_kernel<RO_FMT_I16>, grid, dim3(256), 0, s, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_czt_mul(const CztArgs &a, hipStream_t s)
+{
+    if (a.rows <= 0) return hipSuccess;
+    if (a.m % 256 != 0 || a.rows > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(czt_mul_kernel, dim3((unsigned)(a.m / 256), (unsigned)a.rows), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_czt_out(const CztArgs &a, hipStream_t s)
+{
+    if (a.rows <= 0) return hipSuccess;
+    if (a.rows > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(czt_out_kernel, dim3((unsigned)((a.n + 255) / 256), (unsigned)a.rows), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 template <int R> static hipError_t launch_fold_r(int format, const FoldArgs &a, hipStream_t s)
 {
     // m / 2 column pairs: m / 512 blocks across; enough row groups down to fill the device a few times over

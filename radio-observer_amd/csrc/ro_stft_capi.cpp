@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -96,6 +97,32 @@ std::vector<float2> build_twiddles(int bins)
         ns *= R;
     }
     return tw;
+}
+
+// in-place forward FFT of a power-of-two length in double (table preparation only: the chirp-z filter)
+void host_fft(std::vector<std::complex<double>> &x)
+{
+    const size_t n = x.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(x[i], x[j]);
+    }
+    const long double two_pi = 8.0L * atanl(1.0L);
+    for (size_t len = 2; len <= n; len <<= 1) {
+        std::vector<std::complex<double>> w(len / 2);
+        for (size_t k = 0; k < len / 2; ++k) {
+            const long double ang = -two_pi * (long double)k / (long double)len;
+            w[k] = std::complex<double>((double)cosl(ang), (double)sinl(ang));
+        }
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const std::complex<double> u = x[i + k], v = x[i + k + len / 2] * w[k];
+                x[i + k] = u + v;
+                x[i + k + len / 2] = u - v;
+            }
+    }
 }
 
 // exp(-2 pi i m / N) in double, correctly rounded from long double (strict-precision path)
@@ -191,6 +218,17 @@ struct ro_stft {
     float  *d_mag = nullptr;           // ... their magnitudes, [spec_rows][dec][sub_bins]
     float  *d_ones = nullptr;          // ... a window of ones (the fold has applied the real one)
     int64_t spec_rows = 0;
+    float2 *d_spec2 = nullptr;         // complex spectra of a large size: the sub-rows' spectra before they are interleaved
+    // lengths that are not a power of two (even 258 .. 524286): Bluestein's chirp-z form on an inner handle of the
+    // power-of-two length czt_m >= 2 bins - 1 (see ro::CztArgs)
+    bool    czt = false;
+    int     czt_m = 0;
+    ro_stft *inner = nullptr;
+    float2 *d_cw = nullptr;            // [bins] window[i] * exp(-pi i i^2 / bins)
+    float2 *d_bc = nullptr;            // [czt_m] conj(FFT_M(conj(chirp), wrapped)) / czt_m
+    float2 *d_czt_a = nullptr, *d_czt_A = nullptr;     // [czt_rows][czt_m] each
+    float  *d_czt_mag = nullptr;                       // [czt_rows][czt_m]
+    int64_t czt_rows = 0;
 
     // tile_ln: partial min / max of the fused epilogue's two tile waves (rows x 4 floats), grown on demand
     float  *d_ln_part = nullptr;
@@ -341,6 +379,108 @@ int ensure_ln_part(ro_stft *h, int64_t rows)
     return RO_OK;
 }
 
+// scratch of the large sizes' scratch form (and of their complex spectra): rows per chunk and the blocks
+int ensure_big_scratch(ro_stft *h, bool mag, bool spec2)
+{
+    if (!h->spec_rows) {
+        h->spec_rows = std::max<int64_t>(1, ((int64_t)RO_SPEC_SCRATCH_MB << 20) / ((int64_t)h->bins * 8));
+        if (h->spec_rows > 65535) h->spec_rows = 65535;
+    }
+    if (!h->d_spec) HIP_TRY(hipMalloc(&h->d_spec, (size_t)h->spec_rows * h->bins * sizeof(float2)));
+    if (mag && !h->d_mag) HIP_TRY(hipMalloc(&h->d_mag, (size_t)h->spec_rows * h->bins * sizeof(float)));
+    if (spec2 && !h->d_spec2) HIP_TRY(hipMalloc(&h->d_spec2, (size_t)h->spec_rows * h->bins * sizeof(float2)));
+    return RO_OK;
+}
+
+// complex spectra of rows [first_row, +rows) of a large size (bins = dec x 32768), bin k at element k of each row:
+// fold_kernel, the N = 32768 kernel in spectra mode on its rows, interleave2_kernel
+int launch_spectra_big(ro_stft *h, const void *d_iq, int format, int64_t first_row, int64_t rows, float2 *d_out,
+                       int64_t out_stride, hipStream_t s)
+{
+    int rc = ensure_big_scratch(h, false, true);
+    if (rc != RO_OK) return rc;
+    for (int64_t done = 0; done < rows; done += h->spec_rows) {
+        const int64_t n = std::min(h->spec_rows, rows - done);
+        ro::FoldArgs f{};
+        f.iq = d_iq;
+        f.window = h->d_window;
+        f.rot = h->d_tw_combine;
+        f.out = h->d_spec;
+        f.first_row = first_row + done;
+        f.rows = n;
+        f.hop = h->hop;
+        f.m = h->sub_bins;
+        f.dec = h->dec;
+        f.gain = (float)h->cfg.iq_gain;
+        HIP_TRY(ro::launch_fold(format, f, s));
+        ro::StftArgs a = make_stft_args(h, h->d_spec, 0, n * h->dec, nullptr, 0);
+        a.window = h->d_ones;
+        a.window_k = h->d_ones;
+        a.hop = h->sub_bins;
+        a.gain = 0.0f;
+        a.spec_out = h->d_spec2;
+        a.spec_stride = h->sub_bins;
+        HIP_TRY(ro::launch_stft(h->sub_bins, RO_FMT_F32, a, s));
+        ro::Interleave2Args t{};
+        t.in = h->d_spec2;
+        t.out = d_out + done * out_stride;
+        t.rows = n;
+        t.out_stride = out_stride;
+        t.m = h->sub_bins;
+        t.dec = h->dec;
+        HIP_TRY(ro::launch_interleave2(t, s));
+    }
+    return RO_OK;
+}
+
+// a length that is not a power of two: chirp-z on the inner handle (see ro::CztArgs), in chunks that fit the scratch
+int launch_transform_czt(ro_stft *h, const void *d_iq, int format, int64_t first_row, int64_t rows, float *d_rows,
+                         int64_t row_stride, hipStream_t s)
+{
+    ro_stft *in = h->inner;
+    const int M = h->czt_m;
+    if (!h->d_czt_a) {
+        h->czt_rows = std::min<int64_t>(65535, std::max<int64_t>(1, ((int64_t)1 << 30) / ((int64_t)M * 8)));
+        HIP_TRY(hipMalloc(&h->d_czt_a, (size_t)h->czt_rows * M * sizeof(float2)));
+        HIP_TRY(hipMalloc(&h->d_czt_A, (size_t)h->czt_rows * M * sizeof(float2)));
+        HIP_TRY(hipMalloc(&h->d_czt_mag, (size_t)h->czt_rows * M * sizeof(float)));
+    }
+    for (int64_t done = 0; done < rows; done += h->czt_rows) {
+        const int64_t n = std::min(h->czt_rows, rows - done);
+        ro::CztArgs c{};
+        c.iq = d_iq;
+        c.cw = h->d_cw;
+        c.bc = h->d_bc;
+        c.a = h->d_czt_a;
+        c.first_row = first_row + done;
+        c.rows = n;
+        c.row_stride = row_stride;
+        c.hop = h->hop;
+        c.n = h->bins;
+        c.m = M;
+        c.gain = (float)h->cfg.iq_gain;
+        HIP_TRY(ro::launch_czt_pre(format, c, s));
+        // A = FFT_M(a): the inner handle's rows are the M-sample blocks of d_czt_a (overlap 0, a window of ones)
+        if (!in->big) {
+            ro::StftArgs a = make_stft_args(in, h->d_czt_a, 0, n, nullptr, 0);
+            a.spec_out = h->d_czt_A;
+            a.spec_stride = M;
+            HIP_TRY(ro::launch_stft(M, RO_FMT_F32, a, s));
+        } else {
+            int rc = launch_spectra_big(in, h->d_czt_a, RO_FMT_F32, 0, n, h->d_czt_A, M, s);
+            if (rc != RO_OK) return rc;
+        }
+        c.a = h->d_czt_A;
+        HIP_TRY(ro::launch_czt_mul(c, s));                          // conj(A B) / M, in place
+        int rc = launch_transform(in, h->d_czt_A, RO_FMT_F32, 0, n, h->d_czt_mag, M, s, nullptr, nullptr, nullptr);
+        if (rc != RO_OK) return rc;
+        c.mag = h->d_czt_mag;
+        c.rows_out = d_rows + done * row_stride;
+        HIP_TRY(ro::launch_czt_out(c, s));
+    }
+    return RO_OK;
+}
+
 // RO_PRECISION_F64: every size as radix-16 passes in double through HBM scratch, in chunks that fit it
 int launch_transform_f64(ro_stft *h, const void *d_iq, int format, int64_t first_row, int64_t rows, float *d_rows,
                          int64_t row_stride, hipStream_t s)
@@ -382,6 +522,7 @@ int launch_transform(ro_stft *h, const void *d_iq, int format, int64_t first_row
                      int64_t row_stride, hipStream_t s, float *d_tile, ro_scan_record_t *d_records, float *d_ln)
 {
     if (h->f64) return launch_transform_f64(h, d_iq, format, first_row, rows, d_rows, row_stride, s);
+    if (h->czt) return launch_transform_czt(h, d_iq, format, first_row, rows, d_rows, row_stride, s);
     if (!h->big) {
         if (d_tile && d_ln && ro::stft_fuses_scan(h->bins)) {
             int rc = ensure_ln_part(h, rows);
@@ -394,11 +535,9 @@ int launch_transform(ro_stft *h, const void *d_iq, int format, int64_t first_row
     if (h->dec > 1 && h->fold) {
         // three steps through scratch, in chunks that fit it: fold_kernel (8 B per bin), the N = 32768 kernel on its
         // rows -- no overlap, a window of ones -- (4 B per bin), interleave_kernel into the caller's rows
-        if (!h->d_spec) {
-            h->spec_rows = std::max<int64_t>(1, ((int64_t)RO_SPEC_SCRATCH_MB << 20) / ((int64_t)h->bins * 8));
-            if (h->spec_rows > 65535) h->spec_rows = 65535;
-            HIP_TRY(hipMalloc(&h->d_spec, (size_t)h->spec_rows * h->bins * sizeof(float2)));
-            HIP_TRY(hipMalloc(&h->d_mag, (size_t)h->spec_rows * h->bins * sizeof(float)));
+        {
+            int rc = ensure_big_scratch(h, true, false);
+            if (rc != RO_OK) return rc;
         }
         for (int64_t done = 0; done < rows; done += h->spec_rows) {
             const int64_t n = std::min(h->spec_rows, rows - done);
@@ -817,7 +956,21 @@ extern "C" int ro_stitch_rows_device(const void *d_gathered, int64_t total_rows,
     return RO_OK;
 }
 
-extern "C" int ro_bins_supported(int bins) { return (ro::stft_supported(bins) || ro::big_supported(bins)) ? 1 : 0; }
+// lengths that are not a power of two run as a chirp-z transform on the power-of-two length M >= 2 bins - 1 <= 2^20.
+// Even lengths only: for an odd size the reference's processFFT leaves the last column of the row unwritten and
+// writes one column twice (src/WaterfallBackend.cpp:489-505, halfSize = size / 2) -- there is no defined result to match.
+static int czt_length(int bins)
+{
+    if (bins < 256 || bins >= (1 << 19) || (bins & 1) || (bins & (bins - 1)) == 0) return 0;
+    int m = 512;
+    while (m < 2 * bins - 1) m <<= 1;
+    return m;
+}
+
+extern "C" int ro_bins_supported(int bins)
+{
+    return (ro::stft_supported(bins) || ro::big_supported(bins) || czt_length(bins) > 0) ? 1 : 0;
+}
 
 // ---------------------------------------------------------------------------
 // handle
@@ -841,8 +994,11 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
         return fail(RO_ERR_INVALID, "unknown precision %d", cfg->precision);
     if (cfg->tile_ln != 0 && cfg->tile_ln != 1) return fail(RO_ERR_INVALID, "tile_ln must be 0 or 1");
     if (cfg->tile_ln && cfg->tile_cols <= 0) return fail(RO_ERR_INVALID, "tile_ln needs a tile (tile_cols > 0)");
-    if (!ro::stft_supported(cfg->bins) && !ro::big_supported(cfg->bins))
-        return fail(RO_ERR_UNSUPPORTED, "bins = %d has no kernel (powers of two 256..1048576)", cfg->bins);
+    if (!ro_bins_supported(cfg->bins))
+        return fail(RO_ERR_UNSUPPORTED, "bins = %d has no kernel (powers of two 256..1048576, other even lengths "
+                                        "258..524286)", cfg->bins);
+    if (czt_length(cfg->bins) && cfg->precision == RO_PRECISION_F64)
+        return fail(RO_ERR_UNSUPPORTED, "RO_PRECISION_F64 is available for power-of-two bins only");
     if (cfg->iq_phase_shift != 0)
         return fail(RO_ERR_UNSUPPORTED, "iq_phase_shift != 0 is undefined behaviour in the reference "
                                         "(src/FFTBackend.cpp:67-71) and is not supported");
@@ -893,6 +1049,8 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
         build_window(cfg->window_kind, h->bins, h->window.data());
     h->big = ro::big_supported(h->bins);
     h->f64 = cfg->precision == RO_PRECISION_F64;
+    h->czt_m = czt_length(h->bins);
+    h->czt = h->czt_m > 0;
     if (h->big && !h->f64) {
         // bins = dec x 32768, decimation in frequency on the largest single-pass plan:
         //   X[q + dec k'] = sum_m W_N^(m k') { W_bins^(m q) sum_r W_dec^(r q) w[m + N r] x[m + N r] }
@@ -912,7 +1070,7 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
         h->sub_bins = sub;
         h->dec = dec;
     }
-    const int plan_bins = h->big ? h->sub_bins : h->bins;           // whose stage tables this handle needs (0: none)
+    const int plan_bins = h->czt ? 0 : h->big ? h->sub_bins : h->bins;   // whose stage tables this handle needs (0: none)
     std::vector<float2> tw = plan_bins ? build_twiddles(plan_bins) : std::vector<float2>();
     if (plan_bins && (int)tw.size() != ro::stft_twiddle_count(plan_bins)) {
         delete h;
@@ -935,7 +1093,7 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
     CREATE_TRY(hipMalloc(&h->d_ln_keys, 16 * 2 * sizeof(unsigned)));
     CREATE_TRY(hipMalloc(&h->d_twiddles, sizeof(float2) * std::max<size_t>(tw.size(), 1)));
     CREATE_TRY(hipMemcpy(h->d_window, h->window.data(), sizeof(float) * h->bins, hipMemcpyHostToDevice));
-    if (!h->big) {
+    if (!h->big && !h->czt) {
         std::vector<float> wk((size_t)h->bins);
         if (!ro::stft_window_layout(h->bins, h->window.data(), wk.data())) {
             ro_stft_destroy(h);
@@ -970,7 +1128,7 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
         CREATE_TRY(hipMalloc(&h->d_tw_combine, sizeof(float2) * tc.size()));
         CREATE_TRY(hipMemcpy(h->d_tw_combine, tc.data(), sizeof(float2) * tc.size(), hipMemcpyHostToDevice));
     }
-    if (h->fold) {
+    if (h->big && h->dec > 1) {
         std::vector<float> ones((size_t)h->sub_bins, 1.0f);
         CREATE_TRY(hipMalloc(&h->d_ones, sizeof(float) * ones.size()));
         CREATE_TRY(hipMemcpy(h->d_ones, ones.data(), sizeof(float) * ones.size(), hipMemcpyHostToDevice));
@@ -996,6 +1154,49 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
         }
         CREATE_TRY(hipMalloc(&h->d_dif_tw, sizeof(float2) * td.size()));
         CREATE_TRY(hipMemcpy(h->d_dif_tw, td.data(), sizeof(float2) * td.size(), hipMemcpyHostToDevice));
+    }
+    if (h->czt) {
+        const int N = h->bins, M = h->czt_m;
+        // the inner handle: length M, overlap 0, a window of ones, no bands / tile
+        {
+            std::vector<float> ones((size_t)M, 1.0f);
+            ro_stft_config_t ic{};
+            ic.struct_size = sizeof ic;
+            ic.bins = M;
+            ic.overlap = 0;
+            ic.sample_rate = cfg->sample_rate;
+            ic.window_kind = RO_WINDOW_CUSTOM;
+            ic.window_table = ones.data();
+            ic.device = cfg->device;
+            ic.spare_cus_per_xcd = cfg->spare_cus_per_xcd;
+            int rc = ro_stft_create(&ic, &h->inner);
+            if (rc != RO_OK) { ro_stft_destroy(h); return rc; }
+        }
+        // chirp c[i] = exp(-pi i i^2 / N), the angle reduced exactly: i^2 mod 2N in integers
+        const long double pi = 4.0L * atanl(1.0L);
+        auto chirp = [&](int64_t i) {
+            const int64_t r = (i * i) % (2 * (int64_t)N);
+            const long double ang = -pi * (long double)r / (long double)N;
+            return std::complex<double>((double)cosl(ang), (double)sinl(ang));
+        };
+        std::vector<float2> cw((size_t)N);
+        for (int i = 0; i < N; ++i) {
+            const std::complex<double> c = chirp(i) * (double)h->window[(size_t)i];
+            cw[(size_t)i] = make_float2((float)c.real(), (float)c.imag());
+        }
+        // B = FFT_M(conj(c) wrapped around M) in double on the host, once; the kernels use conj(B) / M
+        std::vector<std::complex<double>> b((size_t)M, std::complex<double>(0.0, 0.0));
+        b[0] = std::conj(chirp(0));
+        for (int i = 1; i < N; ++i) b[(size_t)i] = b[(size_t)(M - i)] = std::conj(chirp(i));
+        host_fft(b);
+        std::vector<float2> bc((size_t)M);
+        for (int i = 0; i < M; ++i)
+            bc[(size_t)i] = make_float2((float)(b[(size_t)i].real() / M), (float)(-b[(size_t)i].imag() / M));
+        CREATE_TRY(hipSetDevice(cfg->device));
+        CREATE_TRY(hipMalloc(&h->d_cw, sizeof(float2) * cw.size()));
+        CREATE_TRY(hipMemcpy(h->d_cw, cw.data(), sizeof(float2) * cw.size(), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMalloc(&h->d_bc, sizeof(float2) * bc.size()));
+        CREATE_TRY(hipMemcpy(h->d_bc, bc.data(), sizeof(float2) * bc.size(), hipMemcpyHostToDevice));
     }
 #undef CREATE_TRY
 
@@ -1031,6 +1232,13 @@ extern "C" int ro_stft_destroy(ro_stft_t *h)
     if (h->d_tw_combine) (void)hipFree(h->d_tw_combine);
     if (h->d_spec) (void)hipFree(h->d_spec);
     if (h->d_window_dif) (void)hipFree(h->d_window_dif);
+    if (h->inner) (void)ro_stft_destroy(h->inner);
+    if (h->d_cw) (void)hipFree(h->d_cw);
+    if (h->d_bc) (void)hipFree(h->d_bc);
+    if (h->d_czt_a) (void)hipFree(h->d_czt_a);
+    if (h->d_czt_A) (void)hipFree(h->d_czt_A);
+    if (h->d_czt_mag) (void)hipFree(h->d_czt_mag);
+    if (h->d_spec2) (void)hipFree(h->d_spec2);
     if (h->d_mag) (void)hipFree(h->d_mag);
     if (h->d_ones) (void)hipFree(h->d_ones);
     if (h->d_dif_tw) (void)hipFree(h->d_dif_tw);
@@ -1154,9 +1362,12 @@ extern "C" int ro_stft_spectra_resident(ro_stft_t *h, const void *d_iq, int form
     // same argument checks as the magnitude path (d_spectra in the place of d_rows)
     int rc = validate_resident(h, d_iq, format, samples, first_row, rows, d_spectra, stride, nullptr, nullptr);
     if (rc != RO_OK) return rc;
-    if (h->big) return fail(RO_ERR_UNSUPPORTED, "complex spectra are available for bins <= 32768");
+    if (h->czt) return fail(RO_ERR_UNSUPPORTED, "complex spectra are available for power-of-two bins");
     if (h->f64) return fail(RO_ERR_UNSUPPORTED, "complex spectra are float32 only (RO_PRECISION_F32)");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->big)
+        return launch_spectra_big(h, d_iq, format, first_row, rows, reinterpret_cast<float2 *>(d_spectra), stride,
+                                  (hipStream_t)stream);
     ro::StftArgs a = make_stft_args(h, d_iq, first_row, rows, nullptr, 0);
     a.spec_out = reinterpret_cast<float2 *>(d_spectra);
     a.spec_stride = stride;

@@ -65,13 +65,16 @@ def test_window_tables_bit_identical_to_oracle(ro, oracle, bins):
 def test_supported_sizes(ro):
     for b in (256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144, 524288, 1048576):
         assert ro.bins_supported(b)      # 65536 / 524288: Bolidozor.json:45, Ionozor.json:27
-    for b in (0, 100, 128, 255, 1000, 32728, 2097152):
+    for b in (258, 1000, 32728, 100000, 524286):   # any other even length: chirp-z (src/BolidRecorder.h:35 suggests 32728)
+        assert ro.bins_supported(b)
+    # odd lengths: the reference's processFFT leaves a column unwritten (src/WaterfallBackend.cpp:489-505)
+    for b in (0, 100, 128, 255, 254, 1001, 32727, 524290, 2097152):
         assert not ro.bins_supported(b)
 
 
 def test_config_is_validated_before_any_device_work(ro):
     """Argument errors come back as RO_ERR_INVALID / RO_ERR_UNSUPPORTED with or without a GPU."""
-    for kw, code in ((dict(bins=1000), -2), (dict(bins=1024, iq_phase_shift=1), -2),
+    for kw, code in ((dict(bins=1001), -2), (dict(bins=1000, precision=1), -2), (dict(bins=1024, iq_phase_shift=1), -2),
                      (dict(bins=1024, sample_rate=0), -1), (dict(bins=1024, spare_cus_per_xcd=17), -1),
                      (dict(bins=1024, spare_cus_per_xcd=-1), -1), (dict(bins=1024, precision=2), -1)):
         with pytest.raises(ro.StftError) as e:

@@ -49,6 +49,23 @@ def test_spectra_match_oracle(ro, oracle, torch_cuda, bins):
     assert np.abs(shifted - mag).max() <= 2e-6 * mag.max()
 
 
+@pytest.mark.parametrize("bins,nrows", [(65536, 3), (262144, 2)])
+def test_large_spectra_match_oracle(ro, oracle, torch_cuda, bins, nrows):
+    """complex spectra above 32768 (fold + the N = 32768 kernel in spectra mode + interleave), bin k at element k"""
+    rng = np.random.default_rng(bins % 991)
+    overlap = bins // 2
+    hop = bins - overlap
+    iq = add_tone(noise_iq(rng, bins + hop * (nrows - 1)), 7000.0, 5.0)
+    spec, mag, w = spectra_gpu(ro, torch_cuda, iq, bins, overlap)
+    z = iq[:, 0].astype(np.float64) + 1j * iq[:, 1].astype(np.float64)
+    got = spec[..., 0].astype(np.float64) + 1j * spec[..., 1].astype(np.float64)
+    for r in range(nrows):
+        _, want = oracle.row_with_spectrum(z[r * hop:r * hop + bins], w)
+        assert np.abs(got[r] - want).max() <= 1e-5 * np.abs(want).max(), (bins, r)
+    absx = np.abs(got)
+    assert np.abs(np.roll(absx, bins // 2, axis=1) - mag).max() <= 1e-5 * mag.max()
+
+
 def test_spectra_int16_gain_stride_and_range(ro, oracle, torch_cuda):
     bins, overlap = 1024, 512
     rng = np.random.default_rng(3)
@@ -74,9 +91,9 @@ def test_spectra_int16_gain_stride_and_range(ro, oracle, torch_cuda):
         assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
 
 
-def test_spectra_unsupported_above_single_pass(ro, torch_cuda):
+def test_spectra_unsupported_for_chirp_z_lengths(ro, torch_cuda):
     torch = torch_cuda
-    bins = 65536
+    bins = 32728
     d_iq = torch.zeros((bins, 2), dtype=torch.float32, device="cuda")
     spec = torch.empty((1, bins, 2), dtype=torch.float32, device="cuda")
     with ro.Stft(bins=bins, overlap=0) as st:

@@ -94,6 +94,51 @@ def test_large_transform_int16_gain_and_custom_window(ro, oracle, torch_cuda, bi
     assert rel_to_row_max(got, want) <= TOL
 
 
+@pytest.mark.parametrize("bins,overlap,nrows", [(258, 0, 9), (1000, 600, 7), (12000, 9000, 5), (32728, 24546, 5),
+                                                 (100000, 50000, 3), (524286, 262143, 2)])
+def test_lengths_that_are_not_a_power_of_two(ro, oracle, torch_cuda, bins, overlap, nrows):
+    """FFTW takes any N (src/FFTBackend.cpp:120; src/BolidRecorder.h:35 suggests 32728): even lengths run as a
+    chirp-z transform on the power-of-two kernels (M = 512 ... 2^20: single pass, one-kernel large form, scratch form)"""
+    assert ro.bins_supported(bins)
+    rng = np.random.default_rng(bins % 1009)
+    hop = bins - overlap
+    iq = add_tone(noise_iq(rng, bins + (nrows - 1) * hop + 5), 10600.0, 20.0)
+    got = gpu_rows(ro, torch_cuda, iq, bins, overlap)
+    want = oracle.stft(iq, bins, overlap)
+    assert got.shape == want.shape == (nrows, bins)
+    assert np.isfinite(got).all()
+    err = rel_to_row_max(got, want)
+    print("bins=%d rel-to-row-max err %.3g" % (bins, err))
+    assert err <= TOL
+    assert abs(int(got[0].argmax()) - ro.frequency_to_bin(bins, 48000, 10600.0)) <= 1
+
+
+def test_not_a_power_of_two_int16_gain_window_scan_and_tile(ro, oracle, torch_cuda):
+    """the chirp-z path behind the same entry points: WAV frames, I/Q gain, a caller's window, band tile and scan records"""
+    torch = torch_cuda
+    bins, overlap, nrows = 32728, 24546, 6
+    hop = bins - overlap
+    rng = np.random.default_rng(77)
+    i16 = rng.integers(-20000, 20000, size=(bins + (nrows - 1) * hop, 2), dtype=np.int16)
+    w = (0.25 + rng.random(bins)).astype(np.float32)
+    bands = ro.Bands(low_noise=100, noise_width=300, low_detect=16000, detect_width=500, avg_bins=27)
+    d_iq = torch.from_numpy(i16).cuda()
+    d_rows = torch.zeros((nrows, bins), dtype=torch.float32, device="cuda")
+    d_tile = torch.zeros((nrows, 615), dtype=torch.float32, device="cuda")
+    d_recs = torch.zeros((nrows, 3), dtype=torch.float32, device="cuda")
+    with ro.Stft(bins=bins, overlap=overlap, window_table=w, iq_gain=37.5, bands=bands, tile=(20000, 615)) as st:
+        st.run_resident(d_iq, ro.RO_IQ_I16, i16.shape[0], 0, nrows, d_rows, d_tile=d_tile, d_records=d_recs,
+                        stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    rows = d_rows.cpu().numpy()
+    want = oracle.stft(i16.astype(np.float32), bins, overlap, w=w, gain=37.5)
+    assert rel_to_row_max(rows, want) <= TOL
+    assert np.array_equal(d_tile.cpu().numpy(), rows[:, 20000:20615])
+    got = d_recs.cpu().numpy().view(ro.capi.SCAN_DTYPE).reshape(-1)
+    n, p, a = oracle.scan_rows(rows, 100, 300, 16000, 500, 27)
+    assert np.array_equal(got["peak"], p) and np.array_equal(got["noise"], n) and np.array_equal(got["average"], a)
+
+
 @pytest.mark.parametrize("bins,overlap", [(1024, 512), (4096, 2048), (32768, 24576), (32768, 0),
                                            (4096, 4095), (2048, 100), (32768, 32767)])
 def test_overlap_variants(ro, oracle, torch_cuda, bins, overlap):
@@ -210,7 +255,7 @@ def test_resident_shape_checks(ro, torch_cuda):
         st.run_resident(d_iq, ro.RO_IQ_F32, 2048, 0, 3, d_rows)
         torch.cuda.synchronize()
     with pytest.raises(ro.StftError):
-        ro.Stft(bins=1000)
+        ro.Stft(bins=1001)
     with pytest.raises(ro.StftError):
         ro.Stft(bins=1024, iq_phase_shift=3)
 

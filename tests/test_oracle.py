@@ -14,8 +14,17 @@ def test_fft_matches_numpy_and_direct_dft(oracle):
         assert np.abs(got - ref).max() <= 2e-15 * np.abs(ref).max() * np.log2(n) + 1e-300
     x = rng.standard_normal(256) + 1j * rng.standard_normal(256)
     assert np.abs(oracle.dft_direct(x) - oracle.fft(x)).max() < 1e-12
-    with pytest.raises(ValueError):
-        oracle.fft(np.zeros(1000, np.complex128))
+
+
+def test_fft_of_lengths_that_are_not_a_power_of_two(oracle):
+    """FFTW takes any N (src/FFTBackend.cpp:120): the oracle's stand-in is Bluestein over its radix-2 transform"""
+    rng = np.random.default_rng(11)
+    for n in (6, 10, 258, 1000, 3000, 32728):
+        x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        got = oracle.fft(x)
+        assert np.abs(got - np.fft.fft(x)).max() <= 1e-12 * np.abs(got).max()
+        if n <= 1000:
+            assert np.abs(got - oracle.dft_direct(x)).max() <= 1e-12 * np.abs(got).max()
 
 
 def test_fft_is_forward_unnormalised(oracle):
