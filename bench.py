@@ -15,8 +15,9 @@ BolidRecorder's per-row noise/peak/average scan with radio-observer.json's bands
 A "step" = one pass of the hot path over that batch: the fused window->FFT->|X|->shift
 kernel plus the scan kernel, inputs already in HBM.  With N > 1 every rank owns one time
 chunk of R rows (weak scaling, no collective inside the transform) and each step ends with
-the RCCL all-gather of that step's waterfall band tile + scan records -- the stitch the
-reference's FITS writer needs -- overlapped with the next step's compute on a side stream.
+the RCCL gather of that step's waterfall band tile + scan records to rank 0 -- the stitch the
+reference's FITS writer and detector need (--gather all: to every rank) -- overlapped with the
+next step's compute on a side stream.
 
 Prints ONE JSON line on rank 0.
 """
@@ -63,10 +64,13 @@ def parse():
     p.add_argument("--comm", choices=["nccl", "gloo-host"], default="nccl",
                    help="gloo-host: rehearsal mode for 1-GPU boxes -- every rank uses cuda:0 and the gather is "
                         "staged through host memory over gloo (exercises the N>1 control flow, not xGMI)")
-    p.add_argument("--gather", choices=["all", "root", "none"], default="all",
-                   help="N > 1: what ends a step.  all = all-gather of band tile + scan records (every rank stitches); "
-                        "root = gather to rank 0 only (the rank that writes the FITS files); none = compute only -- so a "
-                        "scaling run can report compute and exchange separately")
+    p.add_argument("--gather", choices=["all", "root", "none"], default="root",
+                   help="N > 1: what ends a step.  root (default) = band tile + scan records gathered to rank 0, the one "
+                        "process that stitches -- the reference's FITS writer and detector are one consumer "
+                        "(src/WaterfallBackend.cpp:141-211, src/BolidRecorder.cpp:171-273): 7 direct transfers of 40 MB "
+                        "over 7 xGMI links, where a ring all-gather moves 283 MB through every link (falls back to "
+                        "'all' if the backend refuses the gather); all = all-gather (every rank stitches); none = "
+                        "compute only -- so a scaling run can report compute and exchange separately")
     p.add_argument("--no-strict", action="store_true", help="skip the RO_PRECISION_F64 side measurement")
     p.add_argument("--pmc-traffic", type=float, default=None,
                    help="HBM bytes per launch from a separate rocprofv3 --pmc run (default: profiles/*_traffic.json)")
@@ -234,15 +238,21 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    gather_used = {"mode": a.gather, "note": None}
+
     def all_gather(out, inp):
-        """RCCL all-gather over xGMI (or, --gather root, a gather to rank 0); in rehearsal mode the same exchange
+        """RCCL gather to rank 0 (or, --gather all, all-gather) over xGMI; in rehearsal mode the same exchange
         through host memory."""
         if a.comm == "nccl":
-            if a.gather == "root":
+            if gather_used["mode"] == "root":
                 parts = list(out.view((world,) + tuple(inp.shape)).unbind(0)) if rank == 0 else None
-                dist.gather(inp, parts, dst=0)
-            else:
-                dist.all_gather_into_tensor(out, inp)
+                try:
+                    dist.gather(inp, parts, dst=0)
+                    return
+                except (RuntimeError, NotImplementedError, ValueError) as e:      # same answer on every rank
+                    gather_used["mode"] = "all"
+                    gather_used["note"] = "gather to rank 0 refused by the backend (%s): all-gather instead" % str(e)[:120]
+            dist.all_gather_into_tensor(out, inp)
         else:
             h_in = inp.cpu()
             h_out = torch.empty(out.shape, dtype=out.dtype)
@@ -350,9 +360,10 @@ def main():
                        "input": "float32 I/Q resident in HBM", "output": "float32 rows in HBM",
                        "parallelism": "time-chunk per GPU" + (("; %s of band tile [%d,+%d) + scan records per step, "
                                                                "overlapped with the next step"
-                                                               % (({"all": "all-gather", "root": "gather to rank 0"}[a.gather],)
+                                                               % (({"all": "all-gather", "root": "gather to rank 0"}[gather_used["mode"]],)
                                                                   + tile)) if tile and a.gather != "none" else
-                                                              ("; compute only (--gather none)" if tile else ""))},
+                                                              ("; compute only (--gather none)" if tile else "")),
+                       **({"gather_note": gather_used["note"]} if gather_used["note"] else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": a.pmc_traffic if a.pmc_traffic is not None else pmc_traffic(R),
