@@ -10,7 +10,7 @@ rows = 4096
 rng = np.random.default_rng(0)
 iq = rng.standard_normal((bins + (rows - 1) * hop, 2)).astype(np.float32)
 for cols, name in ((bins, "full rows (128 KiB/row back to the host)"), (2048, "recorder band 9-12 kHz (8 KiB/row)")):
-    with ro.Stft(bins=bins, overlap=overlap, max_batch_rows=256) as st:
+    with ro.Stft(bins=bins, overlap=overlap, max_batch_rows=256, tile=None if cols == bins else (22528, cols)) as st:
         t0 = time.perf_counter()
         got = 0
         for i in range(0, iq.shape[0], 1 << 20):
