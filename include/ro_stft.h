@@ -152,6 +152,13 @@ int     ro_stitch_rows(const void *gathered, int64_t total_rows, int world, size
  * Asynchronous on `stream` (copy into the staging block, then ncclAllGather as bytes). */
 int     ro_allgather_rows(void *nccl_comm, const void *d_local, int64_t local_rows, int64_t total_rows, int world,
                           int rank, size_t row_bytes, void *d_staging, void *d_gathered, void *stream);
+/* The same exchange when only ONE rank consumes the rows -- the reference's FITS writer and detector are one process
+ * (src/WaterfallBackend.cpp:141-211, src/BolidRecorder.cpp:171-273): every rank sends its local_rows x row_bytes
+ * straight to `root` (ncclSend / ncclRecv in one group: world - 1 transfers over world - 1 different links), where
+ * they land at their own place in d_out (total_rows x row_bytes, device; ignored on the other ranks).  No padding,
+ * no stitch.  Asynchronous on `stream`. */
+int     ro_gather_rows(void *nccl_comm, const void *d_local, int64_t local_rows, int64_t total_rows, int world,
+                       int rank, int root, size_t row_bytes, void *d_out, void *stream);
 /* ro_stitch_rows for device memory: world device-to-device copies on `stream` */
 int     ro_stitch_rows_device(const void *d_gathered, int64_t total_rows, int world, size_t row_bytes, void *d_out,
                               void *stream);

@@ -939,6 +939,57 @@ extern "C" int ro_allgather_rows(void *nccl_comm, const void *d_local, int64_t l
     return RO_OK;
 }
 
+// gather to ONE rank, rows landing where they belong: ncclSend / ncclRecv in a group, no padding, no stitch
+extern "C" int ro_gather_rows(void *nccl_comm, const void *d_local, int64_t local_rows, int64_t total_rows, int world,
+                              int rank, int root, size_t row_bytes, void *d_out, void *stream)
+{
+    if (!nccl_comm || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world || total_rows < 0 ||
+        row_bytes == 0 || (local_rows > 0 && !d_local) || (rank == root && total_rows > 0 && !d_out))
+        return fail(RO_ERR_INVALID, "ro_gather_rows: bad arguments");
+    int64_t first = 0, mine = 0;
+    ro_shard_rows(total_rows, world, rank, &first, &mine);
+    if (local_rows != mine)
+        return fail(RO_ERR_INVALID, "ro_gather_rows: rank %d of %d owns %lld of %lld rows, not %lld", rank, world,
+                    (long long)mine, (long long)total_rows, (long long)local_rows);
+    typedef int (*group_fn)(void);
+    typedef int (*send_fn)(const void *, size_t, int, int, void *, hipStream_t);
+    typedef int (*recv_fn)(void *, size_t, int, int, void *, hipStream_t);
+    static group_fn group_start = nullptr, group_end = nullptr;
+    static send_fn send = nullptr;
+    static recv_fn recv = nullptr;
+    if (!recv) {
+        void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (lib) {
+            group_start = (group_fn)dlsym(lib, "ncclGroupStart");
+            group_end = (group_fn)dlsym(lib, "ncclGroupEnd");
+            send = (send_fn)dlsym(lib, "ncclSend");
+            recv = (recv_fn)dlsym(lib, "ncclRecv");
+        }
+        if (!group_start || !group_end || !send || !recv) {
+            recv = nullptr;
+            return fail(RO_ERR_UNSUPPORTED, "librccl (ncclSend / ncclRecv) not found on this host");
+        }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (rank == root && mine > 0)           // the root's own rows: a copy
+        HIP_TRY(hipMemcpyAsync(static_cast<char *>(d_out) + (size_t)first * row_bytes, d_local, (size_t)mine * row_bytes,
+                               hipMemcpyDeviceToDevice, s));
+    int rc = group_start();
+    if (rc == 0 && rank != root && mine > 0) rc = send(d_local, (size_t)mine * row_bytes, /*ncclInt8*/ 0, root, nccl_comm, s);
+    if (rank == root)
+        for (int g = 0; g < world && rc == 0; ++g) {
+            int64_t f = 0, n = 0;
+            ro_shard_rows(total_rows, world, g, &f, &n);
+            if (g != root && n > 0)
+                rc = recv(static_cast<char *>(d_out) + (size_t)f * row_bytes, (size_t)n * row_bytes, 0, g, nccl_comm, s);
+        }
+    const int rc_end = group_end();
+    if (rc != 0 || rc_end != 0) return fail(RO_ERR_HIP, "ncclSend / ncclRecv failed with code %d", rc ? rc : rc_end);
+    return RO_OK;
+}
+
 extern "C" int ro_stitch_rows_device(const void *d_gathered, int64_t total_rows, int world, size_t row_bytes, void *d_out,
                                      void *stream)
 {
