@@ -536,7 +536,7 @@ ro_oracle_stream_t *ro_oracle_stream_create(int bins, int overlap, int sample_ra
                                             int64_t start_sec, int64_t start_usec,
                                             double gain, int raw_capacity_rows)
 {
-    if (!get_plan(bins)) return NULL;
+    if (bins < 2 || (!(bins & (bins - 1)) && !get_plan(bins))) return NULL;     /* (other lengths: fft_bluestein) */
     ro_oracle_stream_t *s = (ro_oracle_stream_t *)calloc(1, sizeof(*s));
     if (!s) return NULL;
     s->bins = bins;

@@ -439,10 +439,10 @@ int launch_transform_czt(ro_stft *h, const void *d_iq, int format, int64_t first
 {
     ro_stft *in = h->inner;
     const int M = h->czt_m;
-    if (!h->d_czt_a) {
+    if (!h->d_czt_mag) {                                            // (each block on its own: a failed call can be retried)
         h->czt_rows = std::min<int64_t>(65535, std::max<int64_t>(1, ((int64_t)1 << 30) / ((int64_t)M * 8)));
-        HIP_TRY(hipMalloc(&h->d_czt_a, (size_t)h->czt_rows * M * sizeof(float2)));
-        HIP_TRY(hipMalloc(&h->d_czt_A, (size_t)h->czt_rows * M * sizeof(float2)));
+        if (!h->d_czt_a) HIP_TRY(hipMalloc(&h->d_czt_a, (size_t)h->czt_rows * M * sizeof(float2)));
+        if (!h->d_czt_A) HIP_TRY(hipMalloc(&h->d_czt_A, (size_t)h->czt_rows * M * sizeof(float2)));
         HIP_TRY(hipMalloc(&h->d_czt_mag, (size_t)h->czt_rows * M * sizeof(float)));
     }
     for (int64_t done = 0; done < rows; done += h->czt_rows) {

@@ -14,6 +14,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    # torch bundles its own libamdhip64: when GPU tests are in the run it has to be the FIRST HIP runtime the process
+    # loads -- a test that loads libro_host.so / libro_stft.so (linked against /opt/rocm's copy) before the first torch
+    # test would leave torch with a second runtime that sees no device
+    if any(it.get_closest_marker("gpu") for it in items):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+
+
 @pytest.fixture(scope="session")
 def ro():
     """The product package (directory name has a hyphen, hence importlib)."""

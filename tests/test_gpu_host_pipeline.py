@@ -17,7 +17,9 @@ def _need_host():
 
 @pytest.mark.parametrize("bins,overlap,chunk,batch", [(1024, 512, 1024, 4), (1024, 512, 4096, 0),
                                                        (4096, 2048, 1000, 3), (2048, 0, 777, 1),
-                                                       (32768, 24576, 4096, 8)])
+                                                       (32768, 24576, 4096, 8),
+                                                       (65536, 49152, 4096, 4),      # Bolidozor.json:45-46
+                                                       (32728, 24546, 1024, 3)])     # src/BolidRecorder.h:35
 def test_stream_rows_times_and_marks(oracle, bins, overlap, chunk, batch):
     """WAVStream hands over 1024 samples per call, RawStream up to 4096, JACK arbitrary counts
     (src/WAVStream.cpp:190, src/RawStream.cpp:32, src/JackFrontend.cpp:35): rows, DataInfo and
