@@ -136,7 +136,7 @@ template <int R> __device__ __forceinline__ void dif(v2f *v)
 
 // ---------------------------------------------------------------------------
 // Decimation-in-time form of the same in-register transform (what the single-pass kernels use; the DIF form above
-// remains for the multi-pass kernels, whose twiddles come from a table per element): same positions and pairs per
+// remains for the fold kernel of the large transforms): same positions and pairs per
 // level as dif<R>, result k again at v[bitrev_R(k)], but the constant twiddle sits BEFORE the butterfly, on the
 // second operand, and is the same for a whole block: block `u` at depth l uses W32^E with E = bitrev_l(u) * (16 >> l),
 // i.e. the two halves of a block with exponent E continue with E/2 and E/2 + 8.  That form fuses:

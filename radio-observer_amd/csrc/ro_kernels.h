@@ -78,7 +78,7 @@ struct ScanArgs {
     int               avg_bins;
 };
 
-// ---- strict precision (RO_PRECISION_F64): the same multi-pass recurrence in double, any supported size
+// ---- strict precision (RO_PRECISION_F64): the Stockham recurrence as separate radix-16 passes in double, any power of two
 struct BigArgsD {
     const void    *iq;         // FIRST pass: sample 0 of the stream
     const float   *window;     // FIRST pass (float32 coefficients, widened like src/FFTBackend.cpp:229-232)
@@ -98,7 +98,7 @@ int        f64_radices(int bins, int radices[8]); // passes of the FP64 path for
 hipError_t launch_f64_pass(int radix, bool first, bool last, int fmt, const BigArgsD &a, hipStream_t s);
 
 // ---- large transforms (bins = dec x 32768), see the note in front of fold_kernel
-// First pass of the two-pass form of a large transform (bins = dec x m, decimation in frequency):
+// First step of the scratch form of a large transform (bins = dec x m, decimation in frequency):
 //   out[(row dec + q) m + i] = W_bins^(i q) sum_r W_dec^(r q) w[i + m r] x[row hop + i + m r],   i < m, q, r < dec
 // every access a run of consecutive i; the N = 32768 kernel then transforms `out`'s rows (no overlap, a window of ones).
 struct FoldArgs {

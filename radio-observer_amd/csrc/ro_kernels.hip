@@ -1705,7 +1705,7 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
 //   the N = 32768 kernel on its rows (4 B per bin), interleave_kernel.  30 B of HBM traffic per bin, at copy speed.
 // ---------------------------------------------------------------------------
 // ---------------------------------------------------------------------------
-// fold_kernel: first pass of the two-pass form of a large transform (see FoldArgs).  One thread owns two neighbouring
+// fold_kernel: first step of the scratch form of a large transform (see FoldArgs).  One thread owns two neighbouring
 // columns i, i+1 and walks down the rows of its group: per row it reads the 2 R samples of its columns (16 bytes per
 // block, consecutive lanes consecutive columns), does the radix-R butterfly across the blocks and writes R pairs.
 // Window coefficients and rotations depend on the column only and stay in registers for all rows (R <= 16).
@@ -1778,7 +1778,7 @@ template <int R, int FMT> __global__ __launch_bounds__(256) void fold_kernel(Fol
 // multiplies double samples by the float window in double (src/FFTBackend.cpp:229-232), runs FFTW's double transform
 // (:117-120, :236) and takes sqrt(re^2 + im^2) in double before narrowing to the float row
 // (src/WaterfallBackend.cpp:492-505).  A row of doubles (512 KiB at N = 32768) does not fit a CU's registers, so this
-// mode runs the multi-pass recurrence of big_pass_kernel for EVERY size, in double: radix-16 passes (the last one 2..16)
+// mode runs the Stockham autosort recurrence as separate passes through HBM for EVERY size, in double: radix-16 passes (the last one 2..16)
 // over two complex-double scratch blocks in HBM, twiddles from one correctly rounded exp(-2 pi i m/N) table, the
 // butterflies' own constants in double.  Bound: HBM at 32 B per point and pass; never the benchmarked shape.  Its
 // rows agree with the oracle's FP64 radix-2 transform to a few 1e-16 of the row maximum, i.e. per bin to ~1e-12 at

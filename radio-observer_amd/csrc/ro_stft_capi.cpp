@@ -23,7 +23,7 @@
 #include "../../include/ro_stft.h"
 #include "ro_kernels.h"
 
-// scratch of the two-pass large transforms (sub-spectra between the two kernels), MiB
+// scratch of the large transforms' scratch form (the folded sub-rows between the kernels), MiB per block
 // largest bins / 16384 the one-kernel form of the large transforms is used for (see ro_stft_create)
 #ifndef RO_DIF_MAX_DEC
 #define RO_DIF_MAX_DEC 4
@@ -347,7 +347,7 @@ ro::ScanArgs make_scan_args(const ro_stft *h, const float *d_rows, int64_t row_s
 }
 
 // window -> FFT -> |X| for rows [first_row, +rows): the single-pass kernel, or for bins > 32768
-// the multi-pass path in chunks that fit the scratch blocks
+// the one-kernel or the scratch form (ro_stft_create), in chunks that fit the scratch blocks
 // d_tile / d_records (either may be null): produced here too, by the transform's own epilogue where the plan fuses them
 // (N = 32768), by tile_kernel / scan_kernel behind it otherwise
 int launch_transform(ro_stft *h, const void *d_iq, int format, int64_t first_row, int64_t rows, float *d_rows,
