@@ -214,6 +214,8 @@ def main():
         OVERLAP = a.overlap if a.overlap is not None else (3 * BINS) // 4
         HOP = BINS - OVERLAP
         ALG_BYTES_PER_ROW = HOP * 8 + BINS * 4
+    # (read by the ROCm runtime when it initialises -- before the first HIP call: dmabuf IPC is what RCCL needs here)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
