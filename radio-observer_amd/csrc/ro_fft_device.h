@@ -88,20 +88,6 @@ constexpr int SEQ_G = RO_SEQ_G;
 
 __device__ __forceinline__ void tie(v2f &x, const v2f &dep) { asm volatile("" : "+v"(x) : "v"(dep)); }
 
-// RO_PRIO_LADDER (experiment, off): a wave lowers its issue priority as it moves through the levels of a pass
-// (3, 2, 1, 0), so that the waves of a SIMD stay within a level of each other instead of running oldest-first.  The
-// idea: SQ counters show 4.3 cycles per VALU instruction in the kernel where four waves issuing together reach 3.1
-// and a wave alone 7.5 (tools/ubench/ubench_valu.hip), i.e. the young waves finish their pass alone.  Measured on
-// one device: 0.981 ms with the ladder, 0.959 ms without (profiles/r02_ab_attempts.txt) -- rejected.
-#ifndef RO_PRIO_LADDER
-#define RO_PRIO_LADDER 0
-#endif
-template <int P> __device__ __forceinline__ void prio()
-{
-    if constexpr (RO_PRIO_LADDER) __builtin_amdgcn_s_setprio(P);
-}
-
-
 // One decimation-in-frequency level of a size-R sub-transform: butterfly I.
 template <int R, int I> __device__ __forceinline__ void dif_bfly(v2f *v, const v2f *&tok)
 {
@@ -309,7 +295,6 @@ __device__ __forceinline__ void fdit_last_pair(v2f *x, v2f g1, v2f (&w)[2], floa
     constexpr int E0 = bitrev_bits<4>(J), E1 = bitrev_bits<4>(8 + J);
     static_assert(E1 == E0 + 1, "blocks J and 8 + J use neighbouring exponents");
     if constexpr (J % 2 == 0) {
-        prio<3 - J / 2>();
         w[0] = mul_w32<E0 & 7>(g1);
         w[1] = mul_w32<E1 & 7>(g1);
     }
@@ -332,13 +317,9 @@ __device__ __forceinline__ void fdit_last_level(v2f *x, v2f g1, F &done, std::in
 __device__ __forceinline__ void fdit32_head(v2f *x, v2f g16, v2f g8, v2f g4, v2f g2)
 {
     const v2f *tok = &x[31];
-    prio<3>();
     fdit_level<0>(x, g16, tok);
-    prio<2>();
     fdit_level<1>(x, g8, tok);
-    prio<1>();
     fdit_level<2>(x, g4, tok);
-    prio<0>();
     fdit_level<3>(x, g2, tok);
 }
 
@@ -361,23 +342,18 @@ __device__ __forceinline__ void dit_level_order(v2f *v, const v2f *&tok, std::in
 template <typename F> __device__ __forceinline__ void dit32_head(v2f *v, F hook)
 {
     const v2f *tok = &v[31];
-    prio<3>();
     dit_level_order<0>(v, tok, std::make_integer_sequence<int, 1>{});
     hook(std::integral_constant<int, 0>{});
-    prio<2>();
     dit_level_order<1>(v, tok, std::make_integer_sequence<int, 2>{});
     hook(std::integral_constant<int, 1>{});
-    prio<1>();
     dit_level_order<2>(v, tok, std::make_integer_sequence<int, 4>{});
     hook(std::integral_constant<int, 2>{});
-    prio<0>();
     dit_level_order<3>(v, tok, std::make_integer_sequence<int, 8>{});
     hook(std::integral_constant<int, 3>{});
 }
 
 template <int J, typename F> __device__ __forceinline__ void dit_last_pair(v2f *x, float &chain, F &done)
 {
-    if constexpr (J % 2 == 0) prio<3 - J / 2>();
     tie(x[2 * J], chain);
     dit_pair<bitrev_bits<4>(J)>(x[2 * J], x[2 * J + 1]);
     tie(x[16 + 2 * J], x[2 * J + 1]);

@@ -43,10 +43,6 @@
 #ifndef RO_WIN_PERM
 #define RO_WIN_PERM 1
 #endif
-// experiment: the 512-thread form of the N = 32768 plan (-DRO_T32768=512) with its window resident in registers
-#ifndef RO_T512_RESW
-#define RO_T512_RESW 0
-#endif
 // Plans with registers to spare (N <= 8192: LDS, not VGPRs, limits their occupancy) keep their window coefficients
 // and stage twiddles in registers for the whole persistent loop instead of re-reading them from L2 for every row --
 // per row only the samples come in and the magnitudes go out (14-35 % faster).  0 = reload per row like N >= 16384,
@@ -90,11 +86,6 @@
 // fused band scan (BolidRecorder::noise/peak/average on the LDS image, two waves) and band tile in the PIPE epilogue
 // how many of the last level's eight butterfly pairs request next-row samples (two 16-byte loads each); the rest
 // of the samples is requested behind the barrier / the fused scan
-// 1: four of the eight image chunks leave from the window stage, four from the first butterflies; 0: all eight from
-// the first butterflies (the window stage is the register peak of the row: samples + all coefficients)
-#ifndef RO_PIPE_WSTORES
-#define RO_PIPE_WSTORES 0
-#endif
 #ifndef RO_PIPE_J
 #define RO_PIPE_J 6
 #endif
@@ -116,25 +107,6 @@
 // share (percent) of the next row's window coefficients that is prefetched across the transform
 #ifndef RO_WIN_EARLY_PCT
 #define RO_WIN_EARLY_PCT 50
-#endif
-// N = 32768 pipelined plan, experiment (off): stage twiddles resident in registers as {w, w^4} per stage (8 VGPRs), the
-// other three powers of a pass (w^2, w^8, w^16) by squaring -- no twiddle loads at all (96 KiB of L2 reads per row).
-// The kernel sits at 127 of its 128 VGPRs: with the eight more hipcc spills 16-28 registers whatever else is given up
-// (early window share 0, fewer sample legs in flight), so the packed table is re-read every row.
-#ifndef RO_PIPE_TW1_EARLY
-#define RO_PIPE_TW1_EARLY 0
-#endif
-// N = 32768 pipelined plan, experiment (off): the stage twiddles of both twiddled passes resident in LDS -- {w, w^2},
-// {w^4} per butterfly column, 24 KiB + 768 B behind the exchange image and the scan's histogram -- read from there in
-// front of the butterflies, w^8 and w^16 by squaring: no twiddle loads in the row loop (96 KiB less through L2 per
-// row, six 16-byte loads less in a vmcnt queue that also counts the row's stores, no twiddle registers held across
-// the exchanges).  Measured on one device: 0.986-0.997 ms against 0.966-0.971 without (profiles/r02_ab_attempts.txt,
-// block 10) -- the LDS pipe is the scarcer resource, the L2 reads were not what the row waits for.
-#ifndef RO_PIPE_LDS_TW
-#define RO_PIPE_LDS_TW 0
-#endif
-#ifndef RO_PIPE_RES_TW
-#define RO_PIPE_RES_TW 0
 #endif
 #ifndef RO_PIPE_WIN_EARLY_PCT
 #define RO_PIPE_WIN_EARLY_PCT 25
@@ -186,14 +158,7 @@ template <class PL> constexpr bool plan_swap32() { return plan_addtid<PL>() && R
 template <class PL> constexpr bool plan_pipe() { return plan_addtid<PL>() && RO_PIPE && PL::T == 1024 && !RO_ABLATE; }
 // dynamic LDS of a plan: the exchange image; behind it, for the pipelined add-TID plan, 1 KiB of histogram for the
 // fused scan's radix select
-template <class PL> constexpr int plan_tw_lds_bytes()
-{
-    return plan_pipe<PL>() && RO_PIPE_LDS_TW ? (PL::NS2 + PL::NS1) * 24 : 0;
-}
-template <class PL> constexpr int plan_lds_bytes()
-{
-    return PL::LDS_BYTES + (plan_pipe<PL>() ? 1024 : 0) + plan_tw_lds_bytes<PL>();
-}
+template <class PL> constexpr int plan_lds_bytes() { return PL::LDS_BYTES + (plan_pipe<PL>() ? 1024 : 0); }
 
 // Paired sample loads: which stage-0 column a thread transforms, and the first sample it fetches.
 // Lanes l, l^1 (default) or l, l+32 (swap32) fetch the SAME two adjacent columns with 16-byte loads, one lane
@@ -1105,7 +1070,7 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
     constexpr bool RES = RO_RESIDENT_TABLES && N <= 8192 && !ADDTID && !RO_ABLATE;   // twiddles (and window)
     constexpr bool TW8C = ADDTID && PL::R2 == 8;                                     // see tw_prefetch
     // the 512-thread form of the N = 32768 plan has 256 VGPRs per thread: the window stays, the twiddles do not fit
-    constexpr bool RESW = RES || (RO_T512_RESW && ADDTID && T == 512 && !RO_ABLATE);
+    constexpr bool RESW = RES;
     v2f tw1[PL::R1 > 1 ? P / PL::R1 : 1][TW_SET];
     v2f tw2[PL::R2 > 1 ? P / PL::R2 : 1][TW_SET];
     v2f tw3[PL::R3 > 1 ? P / PL::R3 : 1][TW_SET];
@@ -1124,47 +1089,6 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
     // 12 -- one of them second-oldest on its SIMD -- the fused scan cost 12 % of the kernel.)
     constexpr int SCAN_WAVE_NOISE = RO_SCAN_W0, SCAN_WAVE_PEAK = RO_SCAN_W1, TILE_WAVE_A = RO_SCAN_W2, TILE_WAVE_B = RO_SCAN_W3;
     constexpr int PIPE_J = RO_PIPE_J;      // butterfly pairs of the last level that request next-row samples (of 8)
-    // RO_PIPE_RES_TW: {w, w^4} of both twiddled passes, loaded once (packed table: unit 0 = {w, w^2}, unit 1 = {w^4, w^8})
-    v2f rtw[4] = {(v2f){1.f, 0.f}, (v2f){1.f, 0.f}, (v2f){1.f, 0.f}, (v2f){1.f, 0.f}};
-    if constexpr (PIPE && RO_PIPE_RES_TW) {
-        auto unit_lo = [&](int pk, int ns, int q) {
-            const int koff = (tid & (ns - 1)) * 16;
-            const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_twk, koff, (pk + q * ns) * 16, 0);
-            return (v2f){__uint_as_float(u.x), __uint_as_float(u.y)};
-        };
-        rtw[0] = unit_lo(PL::PK1, PL::NS1, 0);
-        rtw[1] = unit_lo(PL::PK1, PL::NS1, 1);
-        rtw[2] = unit_lo(PL::PK2, PL::NS2, 0);
-        rtw[3] = unit_lo(PL::PK2, PL::NS2, 1);
-    }
-    // RO_PIPE_LDS_TW: the tables, filled once (the first barrier of the row loop comes before their first use)
-    constexpr bool LDS_TW = PIPE && RO_PIPE_LDS_TW && !RO_PIPE_RES_TW;
-    float4 *twl_a2 = reinterpret_cast<float4 *>(smem + PL::LDS_BYTES + 1024);          // {w, w^2}, pass 2: NS2 entries
-    float2 *twl_b2 = reinterpret_cast<float2 *>(twl_a2 + PL::NS2);                      // {w^4}
-    float4 *twl_a1 = reinterpret_cast<float4 *>(twl_b2 + PL::NS2);                      // pass 1: NS1 entries
-    float2 *twl_b1 = reinterpret_cast<float2 *>(twl_a1 + PL::NS1);
-    if constexpr (LDS_TW) {
-        static_assert(PL::NS2 == T && PL::NS1 <= T, "one thread per table entry");
-        const float4 *pk = reinterpret_cast<const float4 *>(a.twiddles_k);
-        const float4 u0 = pk[PL::PK2 + tid], u1 = pk[PL::PK2 + PL::NS2 + tid];
-        twl_a2[tid] = u0;
-        twl_b2[tid] = make_float2(u1.x, u1.y);
-        if (tid < PL::NS1) {
-            const float4 s0 = pk[PL::PK1 + tid], s1 = pk[PL::PK1 + PL::NS1 + tid];
-            twl_a1[tid] = s0;
-            twl_b1[tid] = make_float2(s1.x, s1.y);
-        }
-    }
-    // twiddles of a pass from the LDS tables: t = {w, w^2, w^4, w^8, w^16}
-    auto tw_from_lds = [&](v2f (&t)[TW_SET], const float4 *ta, const float2 *tb, int k) {
-        const float4 x = ta[k];
-        const float2 y = tb[k];
-        t[0] = (v2f){x.x, x.y};
-        t[1] = (v2f){x.z, x.w};
-        t[2] = (v2f){y.x, y.y};
-        t[3] = cmul(t[2], t[2]);
-        t[4] = cmul(t[3], t[3]);
-    };
     const float *prev_out = a.rows_out;
     unsigned prev_bytes = 0;
     unsigned touch = 0;                    // destination of the next-row prefetch touches (touch_next)
@@ -1300,8 +1224,6 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
                         const auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(e.y), __float_as_uint(o.y), false, false);
                         lo = (v2f){__uint_as_float(rx[0]), __uint_as_float(ry[0])};
                         hi = (v2f){__uint_as_float(rx[1]), __uint_as_float(ry[1])};
-                        // PIPE: chunks 0..3 of the previous row's image leave from here (the rest from stage 0)
-                        if constexpr (PIPE && RO_PIPE_WSTORES) { if ((k & 3) == 3) store_chunk(k >> 2, rs_prev); }
                         continue;
                     }
                     // even lane keeps e in slot k and takes the partner's e (leg H+k) into slot H+k;
@@ -1354,17 +1276,12 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
             static_assert(P == 32 && NB == 1 && SWAP32, "one radix-32 butterfly per thread");
             const unsigned wave_bytes = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6) * 256u;
             // ---- pass 0, levels 0..3; the previous row's image goes out between them.
-            // (RO_PIPE_TW1_EARLY, experiment, off: pass 1's twiddles requested in front of the eight image stores, so
-            // that the wait for them does not also cover the stores' acknowledgements -- vmcnt retires in issue order
-            // and counts stores.  Measured 0.957-0.974 ms against 0.947-0.957 without: the acknowledgements are not
-            // what pass 1 waits for.)
-            if constexpr (!LDS_TW && !RO_PIPE_RES_TW && RO_PIPE_TW1_EARLY) tw_prefetch<P, T, 32, PL::NS1, PL::TW1, PL::PK1>(tw1, rs_tw, rs_twk, tid);
             dit32_head(v, [&](auto hc) {
                 constexpr int h = decltype(hc)::value;
-                if constexpr (RO_PIPE_WSTORES) store_chunk(4 + h, rs_prev);
-                else { store_chunk(2 * h, rs_prev); store_chunk(2 * h + 1, rs_prev); }
+                store_chunk(2 * h, rs_prev);
+                store_chunk(2 * h + 1, rs_prev);
             });
-            if constexpr (!LDS_TW && !RO_PIPE_RES_TW && !RO_PIPE_TW1_EARLY) tw_prefetch<P, T, 32, PL::NS1, PL::TW1, PL::PK1>(tw1, rs_tw, rs_twk, tid);
+            tw_prefetch<P, T, 32, PL::NS1, PL::TW1, PL::PK1>(tw1, rs_tw, rs_twk, tid);
             stamp(2);                               // butterflies 0, levels 0..3 (+ the previous row's read-back and stores)
             wg_sync();                              // every wave has read its part of the image back: LDS is free
             stamp(7);
@@ -1379,19 +1296,11 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
             exchange_tail<1, SWAP32>(smem, v, tid);
             stamp(3);                               // exchange 1
             // ---- pass 1
-            if constexpr (LDS_TW) tw_from_lds(tw1[0], twl_a1, twl_b1, tid & (PL::NS1 - 1));
-            if constexpr (RO_PIPE_RES_TW) {
-                tw1[0][0] = rtw[0];
-                tw1[0][1] = cmul(rtw[0], rtw[0]);
-                tw1[0][2] = rtw[1];
-                tw1[0][3] = cmul(rtw[1], rtw[1]);
-                tw1[0][4] = cmul(tw1[0][3], tw1[0][3]);
-            }
             fdit32_head(v, tw1[0][4], tw1[0][3], tw1[0][2], tw1[0][1]);
             // the touch sits behind the butterflies: in front of them hipcc's wait for this pass's twiddles would sit
             // through the touch's HBM miss as well
             touch_next();
-            if constexpr (!LDS_TW && !RO_PIPE_RES_TW) tw_prefetch<P, T, 32, PL::NS2, PL::TW2, PL::PK2>(tw2, rs_tw, rs_twk, tid);
+            tw_prefetch<P, T, 32, PL::NS2, PL::TW2, PL::PK2>(tw2, rs_tw, rs_twk, tid);
             stamp(4);
             wg_sync();                              // exchange 1's y plane has been gathered by everyone
             stamp(11);
@@ -1405,14 +1314,6 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
             exchange_tail<2, SWAP32>(smem, v, tid);
             stamp(5);                               // exchange 2
             // ---- pass 2
-            if constexpr (LDS_TW) tw_from_lds(tw2[0], twl_a2, twl_b2, tid & (PL::NS2 - 1));
-            if constexpr (RO_PIPE_RES_TW) {
-                tw2[0][0] = rtw[2];
-                tw2[0][1] = cmul(rtw[2], rtw[2]);
-                tw2[0][2] = rtw[3];
-                tw2[0][3] = cmul(rtw[3], rtw[3]);
-                tw2[0][4] = cmul(tw2[0][3], tw2[0][3]);
-            }
             fdit32_head(v, tw2[0][4], tw2[0][3], tw2[0][2], tw2[0][1]);
             stamp(6);
             wg_sync();                              // exchange 2's y plane has been gathered by everyone
