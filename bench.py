@@ -421,7 +421,7 @@ def main():
                 ms64, k64, s64 = st64.time_resident(iq, ro.RO_IQ_F32, samples, 0, r64, rows, 5, d_records=recs[1],
                                                     stream=sptr)
                 torch.cuda.synchronize(dev)
-                entry = {"mode": "RO_PRECISION_F64 (double window multiply, double multi-pass transform through HBM "
+                entry = {"mode": "RO_PRECISION_F64 (double window multiply, double transform in two trips through HBM "
                                  "scratch, double sqrt, one narrowing: the reference's arithmetic type)",
                          "value": r64 / (float(np.mean(ms64[1:])) * 1e-3), "unit": "rows/s", "rows_per_step": r64,
                          "ms_per_step": float(np.mean(ms64[1:])), "dtype": "f64"}

@@ -96,6 +96,8 @@ struct BigArgsD {
 };
 int        f64_radices(int bins, int radices[8]); // passes of the FP64 path for a power of two 256 .. 2^20 (0 = unsupported)
 hipError_t launch_f64_pass(int radix, bool first, bool last, int fmt, const BigArgsD &a, hipStream_t s);
+// two consecutive passes (radix 16 with a.ns, then radix r2) in one kernel through LDS; n >= 4096
+hipError_t launch_f64_pair(int r2, bool first, bool last, int fmt, const BigArgsD &a, hipStream_t s);
 
 // ---- large transforms (bins = dec x 32768), see the note in front of fold_kernel
 // First step of the scratch form of a large transform (bins = dec x m, decimation in frequency):

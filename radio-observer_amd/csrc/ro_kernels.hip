@@ -1781,6 +1781,103 @@ __global__ __launch_bounds__(256) void f64_pass_kernel(BigArgsD a)
         }
     }
 }
+// Two passes of the recurrence in one kernel: pass p (radix 16, sub-length ns) and pass p+1 (radix R2, sub-length 16 ns)
+// share a tile of 16 R2 points -- the R2 butterflies j = (b + k' N/(16 R2 ns)) ns + c of pass p produce exactly the
+// inputs of the 16 butterflies j' = 16 b ns + s ns + c of pass p+1 (s < 16), for every (b, c) -- so a workgroup takes
+// 4096 / (16 R2) neighbouring tiles, runs pass p, transposes through 64 KiB of LDS and runs pass p+1: one trip through
+// HBM (16 B per point each way) instead of two.  Same butterflies, same table entries, same order as f64_pass_kernel
+// twice: bit-identical results.
+template <int R2, bool FIRST, bool LAST, int FMT>
+__global__ __launch_bounds__(256) void f64_pair_kernel(BigArgsD a)
+{
+    constexpr int R1 = 16, TPW = 4096 / (R1 * R2), NB2 = 16 / R2;     // tiles per workgroup; pass-(p+1) butterflies per thread
+    extern __shared__ __attribute__((aligned(16))) char smem_d[];
+    double2 *lds = reinterpret_cast<double2 *>(smem_d);               // [slot s][k'][tile]: 16 x R2 x TPW
+    const int t = threadIdx.x;
+    const int tiles_per_row = a.n / (R1 * R2);
+    const int64_t wg = blockIdx.x;
+    const int64_t row = wg / (tiles_per_row / TPW);
+    const int tile0 = (int)(wg - row * (tiles_per_row / TPW)) * TPW;
+    const int ns = a.ns;
+    {
+        // ---- pass p: thread = butterfly k' of tile tile0 + (t % TPW)
+        const int tl = t % TPW, kp = t / TPW;
+        const int tile = tile0 + tl, b = tile / ns, c = tile - b * ns;
+        const int j = (b + kp * (a.n / (R1 * R2 * ns))) * ns + c;
+        const int per_row = a.n / R1;
+        v2d v[R1];
+        if constexpr (FIRST) {
+            using S = Sample<FMT>;
+            const int64_t s0 = (a.first_row + row) * (int64_t)a.hop;
+            const __amdgpu_buffer_rsrc_t rs =
+                make_rsrc(reinterpret_cast<const char *>(a.iq) + s0 * S::BYTES, (unsigned)a.n * S::BYTES);
+#pragma unroll
+            for (int k = 0; k < R1; ++k) {
+                const int n = j + k * per_row;
+                const double w = (double)a.window[n];
+                const v2f x = S::load(rs, n * S::BYTES, 0);
+                v[k] = (v2d){(double)x.x * w, ((double)x.y + a.gain) * w};       // src/FFTBackend.cpp:78-79, :229-232
+            }
+        } else {
+            const double2 *in = a.in + row * (int64_t)a.n;
+            const int kk = j & (ns - 1);
+            const int step = a.n / (ns * R1);
+#pragma unroll
+            for (int k = 0; k < R1; ++k) {
+                const double2 x = in[j + k * per_row];
+                v[k] = (v2d){x.x, x.y};
+                if (k > 0) {
+                    const double2 w = a.tw[(int64_t)k * kk * step];
+                    v[k] = cmul_d(v[k], (v2d){w.x, w.y});
+                }
+            }
+        }
+        dif_d<R1>(v);
+#pragma unroll
+        for (int k = 0; k < R1; ++k) {
+            const v2d x = v[bitrev<R1>(k)];
+            lds[(k * R2 + kp) * TPW + tl] = make_double2(x.x, x.y);
+        }
+    }
+    __syncthreads();
+    // ---- pass p+1: butterfly u = (s, tile): reads slot s of the tile's R2 pass-p butterflies
+    const int ns2 = ns * R1;
+    const int step2 = a.n / (ns2 * R2);
+#pragma unroll
+    for (int i = 0; i < NB2; ++i) {
+        const int u = t + 256 * i, tl = u % TPW, sl = u / TPW;
+        const int tile = tile0 + tl, b = tile / ns, c = tile - b * ns;
+        const int kk = sl * ns + c;                                   // j' mod (16 ns),  j' = 16 b ns + kk
+        v2d v[R2];
+#pragma unroll
+        for (int k = 0; k < R2; ++k) {
+            const double2 x = lds[(sl * R2 + k) * TPW + tl];
+            v[k] = (v2d){x.x, x.y};
+            if (k > 0) {
+                const double2 w = a.tw[(int64_t)k * kk * step2];
+                v[k] = cmul_d(v[k], (v2d){w.x, w.y});
+            }
+        }
+        dif_d<R2>(v);
+        const int j0 = b * ns2 * R2 + kk;
+        if constexpr (LAST) {
+            float *out = a.rows_out + row * a.row_stride;
+#pragma unroll
+            for (int k = 0; k < R2; ++k) {
+                const v2d x = v[bitrev<R2>(k)];
+                out[(j0 + k * ns2 + a.n / 2) & (a.n - 1)] = (float)sqrt(x.x * x.x + x.y * x.y);   // WaterfallBackend.cpp:492-505
+            }
+        } else {
+            double2 *out = a.out + row * (int64_t)a.n;
+#pragma unroll
+            for (int k = 0; k < R2; ++k) {
+                const v2d x = v[bitrev<R2>(k)];
+                out[j0 + k * ns2] = make_double2(x.x, x.y);
+            }
+        }
+    }
+}
+
 
 // ---------------------------------------------------------------------------
 // band tile: compact copy of columns [first, first+cols) of every row (what the FITS
@@ -2386,6 +2483,38 @@ hipError_t launch_f64_pass(int radix, bool first, bool last, int fmt, const BigA
         case 4:  return launch_f64<4, false, true, RO_FMT_F32>(a, s);
         case 8:  return launch_f64<8, false, true, RO_FMT_F32>(a, s);
         case 16: return launch_f64<16, false, true, RO_FMT_F32>(a, s);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+template <int R2, bool FIRST, bool LAST, int FMT> static hipError_t launch_f64_pair_t(const BigArgsD &a, hipStream_t s)
+{
+    const void *fn = reinterpret_cast<const void *>(&f64_pair_kernel<R2, FIRST, LAST, FMT>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 16);
+    if (e != hipSuccess) return e;
+    const int64_t blocks = a.rows * (int64_t)(a.n / 4096);
+    if (blocks > 0x7fffffff) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((f64_pair_kernel<R2, FIRST, LAST, FMT>), dim3((unsigned)blocks), dim3(256), 4096 * 16, s, a);
+    return hipGetLastError();
+}
+
+// passes p (radix 16, a.ns) and p+1 (radix r2) in one kernel; n >= 4096
+hipError_t launch_f64_pair(int r2, bool first, bool last, int fmt, const BigArgsD &a, hipStream_t s)
+{
+    if (a.rows <= 0) return hipSuccess;
+    if (a.n < 4096) return hipErrorInvalidValue;
+    if (r2 == 16) {
+        if (first && !last)
+            return fmt == RO_FMT_I16 ? launch_f64_pair_t<16, true, false, RO_FMT_I16>(a, s)
+                                     : launch_f64_pair_t<16, true, false, RO_FMT_F32>(a, s);
+        if (!first) return last ? launch_f64_pair_t<16, false, true, RO_FMT_F32>(a, s)
+                                : launch_f64_pair_t<16, false, false, RO_FMT_F32>(a, s);
+    } else if (!first && last) {            // (first && last would be n = 16 r2 < 4096)
+        switch (r2) {
+        case 8: return launch_f64_pair_t<8, false, true, RO_FMT_F32>(a, s);
+        case 4: return launch_f64_pair_t<4, false, true, RO_FMT_F32>(a, s);
+        case 2: return launch_f64_pair_t<2, false, true, RO_FMT_F32>(a, s);
         }
     }
     return hipErrorInvalidValue;

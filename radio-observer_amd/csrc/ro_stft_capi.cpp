@@ -505,14 +505,21 @@ int launch_transform_f64(ro_stft *h, const void *d_iq, int format, int64_t first
         b.hop = h->hop;
         b.n = h->bins;
         b.gain = h->cfg.iq_gain;
-        int ns = 1;
-        for (int p = 0; p < passes; ++p) {
+        // two passes per kernel where the pair fits its LDS tile (radix 16 followed by any radix, bins >= 4096): half
+        // the trips through the scratch blocks
+        int ns = 1, hop_idx = 0;
+        b.rows_out = d_rows + done * row_stride;
+        for (int p = 0; p < passes;) {
+            const bool pair = h->bins >= 4096 && p + 1 < passes && radix[p] == 16;
+            const int last_p = pair ? p + 1 : p;
             b.ns = ns;
-            b.in = h->d_scratch_d[(p + 1) & 1];
-            b.out = h->d_scratch_d[p & 1];
-            b.rows_out = d_rows + done * row_stride;
-            HIP_TRY(ro::launch_f64_pass(radix[p], p == 0, p == passes - 1, format, b, s));
-            ns *= radix[p];
+            b.in = h->d_scratch_d[(hop_idx + 1) & 1];
+            b.out = h->d_scratch_d[hop_idx & 1];
+            if (pair) HIP_TRY(ro::launch_f64_pair(radix[p + 1], p == 0, last_p == passes - 1, format, b, s));
+            else HIP_TRY(ro::launch_f64_pass(radix[p], p == 0, p == passes - 1, format, b, s));
+            for (int q = p; q <= last_p; ++q) ns *= radix[q];
+            p = last_p + 1;
+            ++hop_idx;
         }
     }
     return RO_OK;

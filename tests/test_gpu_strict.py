@@ -57,7 +57,8 @@ def test_c3_carrier_60db_per_bin(ro, oracle, torch_cuda):
 
 
 @pytest.mark.parametrize("bins,overlap", [(256, 128), (512, 0), (1024, 512), (2048, 1536), (4096, 2048),
-                                          (8192, 6144), (16384, 12288), (32768, 0), (65536, 49152), (131072, 65536)])
+                                          (8192, 6144), (16384, 12288), (32768, 0), (65536, 49152), (131072, 65536),
+                                          (1048576, 0)])
 def test_every_size_per_bin(ro, oracle, torch_cuda, bins, overlap):
     rng = np.random.default_rng(bins)
     hop = bins - overlap
