@@ -377,6 +377,7 @@ def main():
                          "scan_kernel_ms": k_scan},
             "device": st.device_name,
             "gpu_ms_per_step_events": gpu_ms_per_step, "step_ms_back_to_back": float(np.mean(ms_all)),
+            "step_ms_median": float(np.median(ms_all)), "step_ms_min": float(np.min(ms_all)),
         }
 
         # ---- device copy bandwidth for context (float32 copy of the row buffer)
@@ -389,6 +390,7 @@ def main():
         e1.record()
         torch.cuda.synchronize(dev)
         out["device_copy_GBs"] = 2 * rows.numel() * 4 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        out["roofline"]["frac_of_device_copy"] = achieved / out["device_copy_GBs"]      # report both
         del c
 
         # ---- parity spot check of this run's output (oracle = checker only)
