@@ -71,6 +71,8 @@ def parse():
                         "over 7 xGMI links, where a ring all-gather moves 283 MB through every link (falls back to "
                         "'all' if the backend refuses the gather); all = all-gather (every rank stitches); none = "
                         "compute only -- so a scaling run can report compute and exchange separately")
+    p.add_argument("--no-legs", action="store_true",
+                   help="N > 1: skip the extra untimed-for-`value` runs with the other --gather modes (config.exchange_legs_rows_per_s)")
     p.add_argument("--no-strict", action="store_true", help="skip the RO_PRECISION_F64 side measurement")
     p.add_argument("--pmc-traffic", type=float, default=None,
                    help="HBM bytes per launch from a separate rocprofv3 --pmc run (default: profiles/*_traffic.json)")
@@ -258,7 +260,7 @@ def main():
         else:
             h_in = inp.cpu()
             h_out = torch.empty(out.shape, dtype=out.dtype)
-            if a.gather == "root":
+            if gather_used["mode"] == "root":
                 parts = list(h_out.view((world,) + tuple(h_in.shape)).unbind(0)) if rank == 0 else None
                 dist.gather(h_in, parts, dst=0)
             else:
@@ -301,7 +303,7 @@ def main():
                 stream.wait_event(comm_done[b])            # tile buffer b is free again
             st.run_resident(iq, ro.RO_IQ_F32, samples, 0, R, rows, d_tile=tiles[b], d_records=recs[b],
                             stream=sptr)
-            if a.gather == "none":
+            if gather_used["mode"] == "none":
                 return
             ready = torch.cuda.Event()
             ready.record(stream)
@@ -333,10 +335,37 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     gpu_ms_per_step = ev_a.elapsed_time(ev_b) / a.steps
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if a.comm == "nccl" else "cpu")
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev if a.comm == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return float(t.item())
+
+    if world > 1:
+        dt = max_over_ranks(dt)
+
+    # ---- N > 1, OUTSIDE the timed region of `value`: the same K steps with the other ways of ending a step, so that
+    # one run separates compute from exchange (all-gather as north_star words it, gather to rank 0, compute only)
+    legs = None
+    if world > 1 and a.gather != "none" and not a.no_legs:
+        main_mode = gather_used["mode"]
+        legs = {main_mode: R * world * a.steps / dt}
+        for mode in ("all", "root", "none"):
+            if mode in legs:
+                continue
+            gather_used["mode"] = mode
+            try:
+                for i in range(max(a.warmup, 2)):
+                    step(i)
+                fence()
+                t1 = time.perf_counter()
+                for i in range(a.steps):
+                    step(i)
+                fence()
+                if gather_used["mode"] == mode:                 # (a refused gather has fallen back: not a leg of its own)
+                    legs[mode] = R * world * a.steps / max_over_ranks(time.perf_counter() - t1)
+            except Exception as e:                              # never lose the main line to a side measurement
+                legs[mode] = "failed: %s" % str(e)[:100]
+        gather_used["mode"] = main_mode
 
     # ---- kernel durations with HIP events on the launch stream (same launches as the timed loop)
     ms_all, k_stft, k_scan = st.time_resident(iq, ro.RO_IQ_F32, samples, 0, R, rows, max(a.steps, 5),
@@ -363,9 +392,10 @@ def main():
                        "parallelism": "time-chunk per GPU" + (("; %s of band tile [%d,+%d) + scan records per step, "
                                                                "overlapped with the next step"
                                                                % (({"all": "all-gather", "root": "gather to rank 0"}[gather_used["mode"]],)
-                                                                  + tile)) if tile and a.gather != "none" else
+                                                                  + tile)) if tile and gather_used["mode"] != "none" else
                                                               ("; compute only (--gather none)" if tile else "")),
-                       **({"gather_note": gather_used["note"]} if gather_used["note"] else {})},
+                       **({"gather_note": gather_used["note"]} if gather_used["note"] else {}),
+                       **({"exchange_legs_rows_per_s": legs} if legs else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": a.pmc_traffic if a.pmc_traffic is not None else pmc_traffic(R),
