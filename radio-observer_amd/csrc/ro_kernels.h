@@ -160,6 +160,8 @@ int        stft_packed_twiddle_count(int bins);   // float4 units of StftArgs::t
 bool       stft_pack_twiddles(int bins, const float2 *tw, float4 *out);
 bool       stft_window_layout(int bins, const float *w, float *out);   // host: bins floats -> bins floats
 hipError_t launch_stft(int bins, int fmt, const StftArgs &a, hipStream_t s);
+// the N = 32768 magnitude-row kernel with the fused scan / tile epilogue (ro_stft32k.hip); launch_stft routes to it
+hipError_t launch_stft32k(int fmt, const StftArgs &a, hipStream_t s);
 hipError_t launch_scan(const ScanArgs &a, hipStream_t s);
 hipError_t launch_tile(const TileArgs &a, hipStream_t s);
 hipError_t launch_ln_tile(const LnArgs &a, hipStream_t s);

@@ -113,6 +113,11 @@
 #define RO_WIN_CHUNK 2
 #endif
 
+// N = 32768 magnitude rows run on ro_stft32k.hip's kernel (1); 0 = the round-2 pipelined loop of stft_kernel (A/B builds)
+#ifndef RO_USE_K32
+#define RO_USE_K32 1
+#endif
+
 namespace ro {
 
 // ---------------------------------------------------------------------------
@@ -1767,6 +1772,11 @@ template <class PL> static hipError_t launch_fmt(const StftArgs &a, int fmt, hip
         }
         return hipErrorInvalidValue;
     }
+#if RO_USE_K32
+    if constexpr (PL::N == 32768) {
+        if (!spec) return launch_stft32k(fmt, a, s);               // magnitude rows: ro_stft32k.hip
+    }
+#endif
     if (fmt == RO_FMT_F32) return spec ? launch_plan<PL, RO_FMT_F32, 1>(a, s) : launch_plan<PL, RO_FMT_F32, 0>(a, s);
     if (fmt == RO_FMT_I16) return spec ? launch_plan<PL, RO_FMT_I16, 1>(a, s) : launch_plan<PL, RO_FMT_I16, 0>(a, s);
     return hipErrorInvalidValue;
@@ -1774,7 +1784,7 @@ template <class PL> static hipError_t launch_fmt(const StftArgs &a, int fmt, hip
 
 bool stft_fuses_scan(int bins)
 {
-    return bins == 32768 && plan_pipe<Plan32768>() && RO_FUSE_SCAN;
+    return bins == 32768 && (RO_USE_K32 || (plan_pipe<Plan32768>() && RO_FUSE_SCAN));
 }
 
 bool stft_supported(int bins)
