@@ -12,6 +12,12 @@
 #define RO_STORE_AUX 2
 #endif
 
+// 0 only in tests/test_isa_cpu.py's negative build: the wait states behind the 16-byte stores left out, to show that
+// the test sees the hazard they cover
+#ifndef RO_STORE_NOP
+#define RO_STORE_NOP 1
+#endif
+
 namespace ro {
 
 // Buffer-descriptor helpers.  All global traffic of the STFT kernel goes through
@@ -44,12 +50,19 @@ __device__ __forceinline__ void buf_store_f4(float x0, float x1, float x2, float
     u32x4 t = {__float_as_uint(x0), __float_as_uint(x1), __float_as_uint(x2), __float_as_uint(x3)};
     __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, RO_STORE_AUX);
     // A 16-byte store goes on reading its data registers after it has issued: a VALU write to them in the next two
-    // wait states changes what the last lanes store.  hipcc pads that hazard only for stores without an SGPR soffset
-    // (and counts the empty asm statements of the scheduling leash as wait states); with the soffset form used here
-    // and the registers recycled at once by the butterflies around the pipelined stores, one row in ten left with
-    // lanes 12..15 of every 16 carrying the NEXT values of those registers.  The asm keeps the four registers alive
-    // across two real wait states.
+    // wait states changes what the last lanes store.  The rule is the ISA guide's table of software-inserted wait states
+    // ("VMEM store of more than 64 bits followed by a write of the VGPRs holding its data": 1 wait state, 2 on gfx940 and
+    // later), which EXEMPTS buffer stores whose offset comes from an SGPR; hipcc implements both the rule and the
+    // exemption (GCNHazardRecognizer::createsVALUHazard / checkVALUHazardsHelper, VALUWaitStates = 2 with gfx940
+    // instructions) and counts every inline-asm statement -- the empty ones of the scheduling leash included -- as a
+    // wait state.  What was observed here departs from the exemption: with the SGPR-soffset form used for every row
+    // store and the data registers recycled at once by the butterflies around the pipelined stores, one row in ten left
+    // with lanes 12..15 of every 16 carrying the NEXT values of those registers; two real wait states behind the store
+    // ended it.  The asm keeps the four registers alive across them; tests/test_isa_cpu.py checks the emitted ISA of
+    // every kernel for the pattern (and that it would see it: a build without this s_nop is red).
+#if RO_STORE_NOP
     asm volatile("s_nop 1" ::"v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w));
+#endif
 }
 
 // value of lane (quad_perm) of the same register, DPP: no LDS, full-rate VALU

@@ -86,7 +86,21 @@ template <int M> __device__ __forceinline__ v2f mul_w32(v2f d)
 #endif
 constexpr int SEQ_G = RO_SEQ_G;
 
-__device__ __forceinline__ void tie(v2f &x, const v2f &dep) { asm volatile("" : "+v"(x) : "v"(dep)); }
+// RO_TIE_SCHED = 1: the leash is a scheduling barrier for VALU instructions (memory and scalar instructions may still
+// cross it) instead of an empty asm statement.  hipcc (ROCm 7.2) assumes that ANY inline asm result may be a
+// "dst_sel-forwarded" value on gfx950 and puts an s_nop 0 in front of the next VALU instruction that reads it -- and
+// another one in front of the asm when its input comes from a packed op: ~300 s_nop per row and wave in the butterflies.
+#ifndef RO_TIE_SCHED
+#define RO_TIE_SCHED 0
+#endif
+__device__ __forceinline__ void tie(v2f &x, const v2f &dep)
+{
+#if RO_TIE_SCHED
+    __builtin_amdgcn_sched_barrier(0x4 | 0x10 | 0x80);
+#else
+    asm volatile("" : "+v"(x) : "v"(dep));
+#endif
+}
 
 // One decimation-in-frequency level of a size-R sub-transform: butterfly I.
 template <int R, int I> __device__ __forceinline__ void dif_bfly(v2f *v, const v2f *&tok)
@@ -153,9 +167,15 @@ __device__ __forceinline__ v2f cmadd_mi(v2f x, v2f w, v2f acc)
 }
 
 // (a, b) <- (a + W32^E b, a - W32^E b)
+// diagnostic builds only: -DRO_FFT_NO_BFLY=1 removes the butterflies' arithmetic (dependence chains stay) to price it
+#ifndef RO_FFT_NO_BFLY
+#define RO_FFT_NO_BFLY 0
+#endif
 template <int E> __device__ __forceinline__ void dit_pair(v2f &a, v2f &b)
 {
-    if constexpr (E == 0) {
+    if constexpr (RO_FFT_NO_BFLY) {
+        return;
+    } else if constexpr (E == 0) {
         const v2f s = a + b;
         b = a - b;
         a = s;
@@ -230,9 +250,11 @@ template <int L, int U, int I> __device__ __forceinline__ void fdit_bfly(v2f *x,
     constexpr int S = 32 >> L, E = bitrev_bits<L>(U) * (16 >> L), base = U * S;
     v2f &a = x[base + I], &b = x[base + I + S / 2];
     if constexpr (I % SEQ_G == 0) tie(a, *tok);
-    const v2f s = (E >= 8) ? cmadd_mi(b, tw[E & 7], a) : cmadd(b, tw[E & 7], a);
-    b = __builtin_elementwise_fma(a, (v2f){2.0f, 2.0f}, -s);
-    a = s;
+    if constexpr (!RO_FFT_NO_BFLY) {
+        const v2f s = (E >= 8) ? cmadd_mi(b, tw[E & 7], a) : cmadd(b, tw[E & 7], a);
+        b = __builtin_elementwise_fma(a, (v2f){2.0f, 2.0f}, -s);
+        a = s;
+    }
     tok = &b;
 }
 
@@ -274,11 +296,19 @@ __device__ __forceinline__ void fdit32(v2f *x, v2f g16, v2f g8, v2f g4, v2f g2, 
 // fdit32 with a hook into its last level: that level's 16 butterflies (x[2U], x[2U+1]) run in the order
 // U = 0, 8, 1, 9, ... and done(j) is called after the pair (j, 8 + j): x[2j], x[2j+1], x[16+2j], x[17+2j] are final
 // then (bins bitrev32 of those positions) and their registers free for whatever the caller loads into them next.
-__device__ __forceinline__ void tie(v2f &x, float dep) { asm volatile("" : "+v"(x) : "v"(dep)); }
+__device__ __forceinline__ void tie(v2f &x, float dep)
+{
+#if RO_TIE_SCHED
+    __builtin_amdgcn_sched_barrier(0x4 | 0x10 | 0x80);
+#else
+    asm volatile("" : "+v"(x) : "v"(dep));
+#endif
+}
 
 // one last-level butterfly (a, b) <- (a + W32^E g1 b, a - W32^E g1 b), the product w = W32^(E & 7) g1 given
 template <int E> __device__ __forceinline__ void fdit_last_bfly(v2f &a, v2f &b, v2f w)
 {
+    if constexpr (RO_FFT_NO_BFLY) return;
     const v2f s = (E >= 8) ? cmadd_mi(b, w, a) : cmadd(b, w, a);
     b = __builtin_elementwise_fma(a, (v2f){2.0f, 2.0f}, -s);
     a = s;
@@ -314,13 +344,21 @@ __device__ __forceinline__ void fdit_last_level(v2f *x, v2f g1, F &done, std::in
 }
 
 // fdit32 in two parts: levels 0..3, then the last level with the hook (the caller may branch between them)
-__device__ __forceinline__ void fdit32_head(v2f *x, v2f g16, v2f g8, v2f g4, v2f g2)
+template <typename F> __device__ __forceinline__ void fdit32_head(v2f *x, v2f g16, v2f g8, v2f g4, v2f g2, F hook)
 {
     const v2f *tok = &x[31];
     fdit_level<0>(x, g16, tok);
+    hook(std::integral_constant<int, 0>{});
     fdit_level<1>(x, g8, tok);
+    hook(std::integral_constant<int, 1>{});
     fdit_level<2>(x, g4, tok);
+    hook(std::integral_constant<int, 2>{});
     fdit_level<3>(x, g2, tok);
+    hook(std::integral_constant<int, 3>{});
+}
+__device__ __forceinline__ void fdit32_head(v2f *x, v2f g16, v2f g8, v2f g4, v2f g2)
+{
+    fdit32_head(x, g16, g8, g4, g2, [](auto) {});
 }
 
 template <typename F> __device__ __forceinline__ void fdit32_last(v2f *x, v2f g1, F done)

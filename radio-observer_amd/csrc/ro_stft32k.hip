@@ -34,14 +34,25 @@
 //   image:       slot k2 of that thread = bin k0 + 32 k1 + 1024 k2 -> cell(k2, w, l')
 //                (the rotation by 4 (w >> 1) makes the 16-byte-per-lane read-back of the row conflict-free)
 // tools/r3/emu32k.py restates these maps with numpy and checks them against numpy's FFT and for bank conflicts.
+#ifndef RO_K32_ABLATE
+#define RO_K32_ABLATE 0
+#endif
+#if RO_K32_ABLATE & 8
+#define RO_FFT_NO_BFLY 1
+#endif
+// the butterflies' scheduling leash as a scheduling barrier, not an empty asm statement (see tie() in ro_fft_device.h):
+// 240 fewer s_nop per row and wave, 7 VGPRs fewer, the same bits
+#ifndef RO_TIE_SCHED
+#define RO_TIE_SCHED 1
+#endif
 #include "ro_kernels.h"
 #include "ro_fft_device.h"
 #include "ro_device_util.h"
 
 #include <mutex>
 
-// Diagnostic only: -DRO_STAMPS32K=1 accumulates s_memtime deltas per phase of the row loop (wave 0 and wave 15 of
-// every workgroup) into StftArgs::stamps.  Never timed, never shipped.
+// Diagnostic only: -DRO_STAMPS32K=1 accumulates s_memtime deltas per phase of the row loop (every wave of every
+// workgroup) into StftArgs::stamps.  Never timed, never shipped.
 #ifndef RO_STAMPS32K
 #define RO_STAMPS32K 0
 #endif
@@ -52,6 +63,26 @@
 // share (percent) of the next row's window coefficients requested right behind the window stage
 #ifndef RO_K32_WIN_EARLY_PCT
 #define RO_K32_WIN_EARLY_PCT 25
+#endif
+
+// Diagnostic builds only (tools/ab_build.sh): RO_K32_ABLATE bits remove one kind of memory traffic to price it (1: no
+// twiddle loads, 2: no window loads, 4: no LDS exchanges, 8: no butterflies (-DRO_FFT_NO_BFLY), 16: no row stores;
+// results are wrong by design); RO_K32_PRIO tries wave priorities
+// between exchange 1 and the image (1: by progress -- 3, 2, 1, 0 through the four butterfly phases; 2: static, youngest
+// wave of a SIMD highest).
+#ifndef RO_K32_ABLATE
+#define RO_K32_ABLATE 0
+#endif
+#ifndef RO_K32_PRIO
+#define RO_K32_PRIO 0
+#endif
+// the next row's last sample legs and window coefficients are requested in front of the image-complete barrier by
+// every wave that does not scan (1), or behind the scan by all (0)
+#ifndef RO_K32_EARLY_LOADS
+#define RO_K32_EARLY_LOADS 1
+#endif
+#ifndef RO_K32_TW1_SCALAR
+#define RO_K32_TW1_SCALAR 1
 #endif
 
 namespace ro {
@@ -162,6 +193,7 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
         constexpr int first = decltype(first_c)::value, last = decltype(last_c)::value;
 #pragma unroll
         for (int k = first; k < last; k += 2) {
+            if constexpr (RO_K32_ABLATE & 2) { w4[k / 2] = (v4f){0.5f, 0.25f, 0.5f, 0.25f}; continue; }
             const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_win, tid * 16, (k / 2) * T * 16, 0);
             w4[k / 2] = (v4f){__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
         }
@@ -180,6 +212,7 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
         constexpr int PK = decltype(pk_c)::value, NS = decltype(ns_c)::value;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
+            if constexpr (RO_K32_ABLATE & 1) { t[2 * q] = (v2f){0.6f, 0.8f}; if (q < 2) t[2 * q + 1] = (v2f){0.8f, 0.6f}; continue; }
             const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_twk, k * 16, (PK + q * NS) * 16, 0);
             t[2 * q] = (v2f){__uint_as_float(u.x), __uint_as_float(u.y)};
             if (q < 2) t[2 * q + 1] = (v2f){__uint_as_float(u.z), __uint_as_float(u.w)};
@@ -206,14 +239,36 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
     // chunk q of the image: bins 4 m .. 4 m + 3 of segment r = 4 q + (tid >> 8), m = tid & 255, sit in the territories of
     // waves 2 (m & 7) and 2 (m & 7) + 1 (two lanes each); out as 1 KiB per wave-instruction; bin k leaves for column
     // (k + N/2) mod N (src/WaterfallBackend.cpp:492-505)
+    // (ONE register holds the thread's chunk-0 address for the whole kernel; laundered per chunk, else hipcc keeps all
+    // eight chunk addresses alive through the row -- and recomputed from tid per chunk it cost ~100 VALU ops per row)
+    int rb_base = RQ * (tid >> 8) + 128 * (tid & 7) + ((((tid & 255) >> 3) - 4 * (tid & 7)) & 31);
     auto store_chunk = [&](int q, const __amdgpu_buffer_rsrc_t &rs) {
-        int lt = tid;
-        asm volatile("" : "+v"(lt));            // (else hipcc keeps the eight chunk addresses alive through the whole row)
-        const int m = lt & 255;
-        const float *p = lds + RQ * (lt >> 8) + 128 * (m & 7) + (((m >> 3) - 4 * (m & 7)) & 31) + 4 * RQ * q;
+        int rb = rb_base;
+        asm volatile("" : "+v"(rb));
+        const float *p = lds + rb + 4 * RQ * q;
         const float x0 = p[0], x1 = p[32], x2 = p[64], x3 = p[96];
-        buf_store_f4(x0, x1, x2, x3, rs, tid * 16, ((q * T * 4 + N / 2) & (N - 1)) * 4);
+        if constexpr (RO_K32_ABLATE & 16) asm volatile("" ::"v"(x0), "v"(x1), "v"(x2), "v"(x3));
+        else buf_store_f4(x0, x1, x2, x3, rs, tid * 16, ((q * T * 4 + N / 2) & (N - 1)) * 4);
     };
+    auto prio = [&](auto pc) {
+        constexpr int P = decltype(pc)::value;
+        if constexpr (RO_K32_PRIO == 1) __builtin_amdgcn_s_setprio(P);
+    };
+    // RO_K32_PRIO 3 / 4: one step per butterfly LEVEL (3: passes 1 and 2, 4: pass 0 as well): level n of the row runs at
+    // priority 3 - (n mod 4), so a wave that is a level behind outranks the waves ahead of it
+    auto lprio = [&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+        if constexpr (RO_K32_PRIO == 4 || (RO_K32_PRIO == 3 && n >= 5)) __builtin_amdgcn_s_setprio(3 - (n & 3));
+    };
+    if constexpr (RO_K32_PRIO == 2) {
+        if (wave >= 12) __builtin_amdgcn_s_setprio(3);
+        else if (wave >= 8) __builtin_amdgcn_s_setprio(2);
+        else if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    }
+    using p0 = std::integral_constant<int, 0>;
+    using p1 = std::integral_constant<int, 1>;
+    using p2 = std::integral_constant<int, 2>;
+    using p3 = std::integral_constant<int, 3>;
 
     const unsigned ma = (unsigned)wave * (4u * RQ), mb = ma + 4032u;      // exchange 1: M0 of the even / odd slots
     const unsigned mc = (unsigned)wave * 256u, md = mc + (unsigned)HB;    // own territory: M0 of rows < 16 / >= 16
@@ -258,12 +313,33 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
         stamp(0);
 
         // ---- pass 0, levels 0..3; the previous row's image goes out between them (LDS read-back + 16-byte stores)
+        lprio(std::integral_constant<int, 0>{});
         dit32_head(v, [&](auto hc) {
             constexpr int h = decltype(hc)::value;
             store_chunk(2 * h, rs_prev);
             store_chunk(2 * h + 1, rs_prev);
+            lprio(std::integral_constant<int, h + 1>{});
         });
-        {
+        if constexpr (RO_K32_TW1_SCALAR) {
+            // pass-1 twiddles depend on k0 only -- two values per wave: scalar loads (the scalar cache, not the vector
+            // memory pipe, which at this point is busy with the row's samples) and one select per register
+            int lt = tid;
+            asm volatile("" : "+v"(lt));
+            const bool odd = (lt >> 4) & 1;
+            const float4 *tk = a.twiddles_k + 2 * wave;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                v4f e, o;                                   // units q * 32 + k0 for the wave's even and odd k0
+                asm volatile("s_load_dwordx4 %0, %2, %3\n\t"
+                             "s_load_dwordx4 %1, %2, %4\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&s"(e), "=&s"(o)
+                             : "s"(tk), "n"(q * 32 * 16), "n"(q * 32 * 16 + 16)
+                             : "memory");
+                tw1[2 * q] = (v2f){odd ? o.x : e.x, odd ? o.y : e.y};
+                if (q < 2) tw1[2 * q + 1] = (v2f){odd ? o.z : e.z, odd ? o.w : e.w};
+            }
+        } else {
             int lt = tid;
             asm volatile("" : "+v"(lt));
             tw_load(tw1, 2 * wave + ((lt >> 4) & 1), std::integral_constant<int, 0>{}, std::integral_constant<int, 32>{});
@@ -274,7 +350,7 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
         // ---- pass 0, last level: the x plane of exchange 1 leaves as the pairs finish
         dit32_last(v, [&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            x1_write_pair<bitrev<32>(2 * j)>(ma, mb, v[2 * j].x, v[16 + 2 * j].x, v[2 * j + 1].x, v[17 + 2 * j].x);
+            if constexpr (!(RO_K32_ABLATE & 4)) x1_write_pair<bitrev<32>(2 * j)>(ma, mb, v[2 * j].x, v[16 + 2 * j].x, v[2 * j + 1].x, v[17 + 2 * j].x);
             return v[17 + 2 * j].y;
         });
         stamp(3);
@@ -289,21 +365,24 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
             __builtin_amdgcn_s_barrier();                                // (b)
             asm volatile("" ::: "memory");
 #pragma unroll
-            for (int b = 0; b < 32; ++b) v[b].x = g1[off(b)];
+            for (int b = 0; b < 32; ++b) if constexpr (!(RO_K32_ABLATE & 4)) v[b].x = g1[off(b)];
             wg_sync();                                                   // (c) everyone has its x: the plane may go
-            x1_write_plane(ma, mb, [&](int k0) { return v[bitrev<32>(k0)].y; });
+            if constexpr (!(RO_K32_ABLATE & 4)) x1_write_plane(ma, mb, [&](int k0) { return v[bitrev<32>(k0)].y; });
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                // (d)
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int i = 0; i < 16; ++i) {                               // in the order level 0 of pass 1 pairs them
+                if constexpr (RO_K32_ABLATE & 4) continue;
                 v[i].y = g1[off(i)];
                 v[i + 16].y = g1[off(i + 16)];
             }
         }
         stamp(4);
         // ---- pass 1.  From here to the completed image the wave is on its own.
-        fdit32_head(v, tw1[4], tw1[3], tw1[2], tw1[1]);
+        prio(p3{});
+        lprio(std::integral_constant<int, 5>{});
+        fdit32_head(v, tw1[4], tw1[3], tw1[2], tw1[1], [&](auto hc) { lprio(std::integral_constant<int, 6 + decltype(hc)::value>{}); });
         touch_next();
         int k1p, kbp;                                                    // this thread in pass 2: (k0 = 2 wave + kbp, k1 = k1p)
         {
@@ -314,9 +393,10 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
             tw_load(tw2, 2 * wave + kbp + 32 * k1p, std::integral_constant<int, 96>{}, std::integral_constant<int, 1024>{});
         }
         stamp(5);
+        prio(p2{});
         fdit32_last(v, tw1[0], [&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            own_write_pair<bitrev<32>(2 * j)>(mc, md, v[2 * j].x, v[16 + 2 * j].x, v[2 * j + 1].x, v[17 + 2 * j].x);
+            if constexpr (!(RO_K32_ABLATE & 4)) own_write_pair<bitrev<32>(2 * j)>(mc, md, v[2 * j].x, v[16 + 2 * j].x, v[2 * j + 1].x, v[17 + 2 * j].x);
             return v[17 + 2 * j].y;
         });
         stamp(6);
@@ -327,18 +407,22 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
             auto off = [](int s) constexpr { return (s >> 1) + 32 * (s & 1); };
             asm volatile("" ::: "memory");
 #pragma unroll
-            for (int s = 0; s < 32; ++s) v[s].x = g2[off(s)];
+            for (int s = 0; s < 32; ++s) if constexpr (!(RO_K32_ABLATE & 4)) v[s].x = g2[off(s)];
             asm volatile("" ::: "memory");
-            own_write_plane(mc, md, [&](int k1) { return v[bitrev<32>(k1)].y; });
+            if constexpr (!(RO_K32_ABLATE & 4)) own_write_plane(mc, md, [&](int k1) { return v[bitrev<32>(k1)].y; });
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
+                if constexpr (RO_K32_ABLATE & 4) continue;
                 v[i].y = g2[off(i)];
                 v[i + 16].y = g2[off(i + 16)];
             }
         }
         stamp(7);
         // ---- pass 2
-        fdit32_head(v, tw2[4], tw2[3], tw2[2], tw2[1]);
+        prio(p1{});
+        lprio(std::integral_constant<int, 10>{});
+        fdit32_head(v, tw2[4], tw2[3], tw2[2], tw2[1], [&](auto hc) { lprio(std::integral_constant<int, 11 + decltype(hc)::value>{}); });
+        prio(p0{});
         stamp(8);
         {
             // Last level with the epilogue folded in.  After butterflies (j, 8 + j) x[2j], x[2j+1], x[16+2j], x[17+2j]
@@ -365,79 +449,100 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
             });
             asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // the last square roots: see above
             own_write_pair<bitrev<32>(14)>(mc, md, pm0, pm1, pm16, pm17);
-            stamp(9);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the add-TID image writes (hipcc does not count them)
-            wg_sync();                                            // (e) the image of this row is complete
-            stamp(10);
-            // BolidRecorder's per-row scan on the image (src/BolidRecorder.cpp:121-132, :313-347) by waves 0 and 1 --
-            // the oldest wave of two SIMDs, which the arbiter serves first -- while the others go on to the next row's
-            // window stage; waves 2 and 3 cut the band tile.  Everything derived from the lane number and the band
-            // limits is laundered through empty asm: otherwise hipcc hoists those loop invariants in front of the row
-            // loop, where they sit in VGPRs of all 16 waves for the whole row.
-            {
-                int lane = tid & 63;
-                asm volatile("" : "+v"(lane));
-                const ImageRow img{lds};
-                if (a.records != nullptr && wave < 2) {
-                    int low_noise = a.low_noise, noise_width = a.noise_width, low_detect = a.low_detect;
-                    int detect_width = a.detect_width, avg_bins = a.avg_bins;
-                    asm volatile("" : "+s"(low_noise), "+s"(noise_width), "+s"(low_detect), "+s"(detect_width), "+s"(avg_bins));
-                    if (wave == 0) {
-                        unsigned *hist = reinterpret_cast<unsigned *>(smem + IMAGE_BYTES);
-                        // bands up to 512 columns (the shipped configs: 409 / 410) keep their keys in registers
-                        const float nz = noise_width <= 512 ? scan_noise<8>(img, low_noise, noise_width, hist, lane)
-                                                            : scan_noise<0>(img, low_noise, noise_width, hist, lane);
-                        if (lane == 0) a.records[row].noise = nz;
-                    } else {
-                        const int pk = scan_peak<8>(img, low_detect, detect_width, lane);
-                        const float av = scan_average(img, low_detect + pk - avg_bins / 2, avg_bins, N, lane);
-                        if (lane == 0) {
-                            a.records[row].peak = pk;
-                            a.records[row].average = av;
-                        }
-                    }
-                }
-                if (a.tile_out != nullptr && (wave == 2 || wave == 3)) {
-                    int tile_cols = a.tile_cols, tile_first = a.tile_first;
-                    asm volatile("" : "+s"(tile_cols), "+s"(tile_first));
-                    const int half = ((tile_cols + 127) >> 7) << 6;            // first wave's share, whole 64s
-                    const int c0 = wave == 2 ? 0 : half;
-                    const int c1 = wave == 2 ? (half < tile_cols ? half : tile_cols) : tile_cols;
-                    float *dst = a.tile_out + row * (int64_t)tile_cols;
-                    if (a.ln_out == nullptr) {
-                        for (int c = c0 + lane; c < c1; c += 64) dst[c] = img(tile_first + c);
-                    } else {
-                        // the viewer's log image of the tile (fits2png:46) and this wave's share of the row's min /
-                        // max over the non-zero pixels (:476-477), while the magnitudes are still in LDS
-                        float *ldst = a.ln_out + row * (int64_t)tile_cols;
-                        unsigned kmin = 0xffffffffu, kmax = 0u;
-                        for (int c = c0 + lane; c < c1; c += 64) {
-                            const float x = img(tile_first + c);
-                            const float l = logf(x);
-                            dst[c] = x;
-                            ldst[c] = l;
-                            if (x != 0.f) {
-                                const unsigned key = order_key(l);
-                                kmin = min(kmin, key);
-                                kmax = max(kmax, key);
+            // The legs the last level did not request and the rest of the window coefficients.  The waves reach this
+            // point up to ~6k cycles apart (the oldest wave of a SIMD first) and then wait for the barrier: whoever is
+            // not about to scan asks NOW, so the memory pipe works through most of the next row's 384 KiB while the
+            // younger waves are still in their butterflies, instead of starting behind the barrier with all 16 waves
+            // in its queue.  (The two scanning waves need these registers for their band.)
+            // who has work on the image behind the barrier: waves 0, 1 scan, waves 2, 3 cut the band tile
+            const bool image_work = RO_K32_EARLY_LOADS ? ((a.records != nullptr && wave < 2) ||
+                                                          (a.tile_out != nullptr && (wave == 2 || wave == 3)))
+                                                       : true;
+            auto late_loads = [&]() {
+#pragma unroll
+                for (int k = 2 * RO_K32_PIPE_J; k < H; ++k)
+                    S::load_pair(rs_next, po, k * (N / 32) * S::BYTES, v[k], v[H + k]);
+                load_window(win_rsrc(has_next), cE{}, cN{});
+            };
+            auto image_complete = [&]() {
+                stamp(9);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the add-TID image writes (hipcc does not count them)
+                wg_sync();                                            // (e) the image of this row is complete
+                stamp(10);
+            };
+            if (!image_work) {
+                // (its own branch, barrier included: with one barrier for both paths hipcc keeps the registers of these
+                // loads live across the scan code and spills)
+                late_loads();
+                image_complete();
+            } else {
+                image_complete();
+                // BolidRecorder's per-row scan on the image (src/BolidRecorder.cpp:121-132, :313-347) by waves 0 and 1 --
+                // the oldest wave of two SIMDs, which the arbiter serves first -- while the others go on to the next row's
+                // window stage; waves 2 and 3 cut the band tile.  Everything derived from the lane number and the band
+                // limits is laundered through empty asm: otherwise hipcc hoists those loop invariants in front of the row
+                // loop, where they sit in VGPRs of all 16 waves for the whole row.
+                {
+                    int lane = tid & 63;
+                    asm volatile("" : "+v"(lane));
+                    const ImageRow img{lds};
+                    if (a.records != nullptr && wave < 2) {
+                        int low_noise = a.low_noise, noise_width = a.noise_width, low_detect = a.low_detect;
+                        int detect_width = a.detect_width, avg_bins = a.avg_bins;
+                        asm volatile("" : "+s"(low_noise), "+s"(noise_width), "+s"(low_detect), "+s"(detect_width), "+s"(avg_bins));
+                        if (wave == 0) {
+                            unsigned *hist = reinterpret_cast<unsigned *>(smem + IMAGE_BYTES);
+                            // bands up to 512 columns (the shipped configs: 409 / 410) keep their keys in registers
+                            const float nz = noise_width <= 512 ? scan_noise<8>(img, low_noise, noise_width, hist, lane)
+                                                                : scan_noise<0>(img, low_noise, noise_width, hist, lane);
+                            if (lane == 0) a.records[row].noise = nz;
+                        } else {
+                            const int pk = scan_peak<8>(img, low_detect, detect_width, lane);
+                            const float av = scan_average(img, low_detect + pk - avg_bins / 2, avg_bins, N, lane);
+                            if (lane == 0) {
+                                a.records[row].peak = pk;
+                                a.records[row].average = av;
                             }
                         }
-                        kmin = wave_min_u32(kmin);
-                        kmax = wave_max_u32(kmax);
-                        if (lane == 0) {
-                            float *part = a.ln_part + row * 4 + (wave == 2 ? 0 : 2);
-                            part[0] = kmin == 0xffffffffu ? __builtin_inff() : key_to_float(kmin);
-                            part[1] = kmax == 0u ? -__builtin_inff() : key_to_float(kmax);
+                    }
+                    if (a.tile_out != nullptr && (wave == 2 || wave == 3)) {
+                        int tile_cols = a.tile_cols, tile_first = a.tile_first;
+                        asm volatile("" : "+s"(tile_cols), "+s"(tile_first));
+                        const int half = ((tile_cols + 127) >> 7) << 6;            // first wave's share, whole 64s
+                        const int c0 = wave == 2 ? 0 : half;
+                        const int c1 = wave == 2 ? (half < tile_cols ? half : tile_cols) : tile_cols;
+                        float *dst = a.tile_out + row * (int64_t)tile_cols;
+                        if (a.ln_out == nullptr) {
+                            for (int c = c0 + lane; c < c1; c += 64) dst[c] = img(tile_first + c);
+                        } else {
+                            // the viewer's log image of the tile (fits2png:46) and this wave's share of the row's min /
+                            // max over the non-zero pixels (:476-477), while the magnitudes are still in LDS
+                            float *ldst = a.ln_out + row * (int64_t)tile_cols;
+                            unsigned kmin = 0xffffffffu, kmax = 0u;
+                            for (int c = c0 + lane; c < c1; c += 64) {
+                                const float x = img(tile_first + c);
+                                const float l = logf(x);
+                                dst[c] = x;
+                                ldst[c] = l;
+                                if (x != 0.f) {
+                                    const unsigned key = order_key(l);
+                                    kmin = min(kmin, key);
+                                    kmax = max(kmax, key);
+                                }
+                            }
+                            kmin = wave_min_u32(kmin);
+                            kmax = wave_max_u32(kmax);
+                            if (lane == 0) {
+                                float *part = a.ln_part + row * 4 + (wave == 2 ? 0 : 2);
+                                part[0] = kmin == 0xffffffffu ? __builtin_inff() : key_to_float(kmin);
+                                part[1] = kmax == 0u ? -__builtin_inff() : key_to_float(kmax);
+                            }
                         }
                     }
                 }
+                late_loads();
             }
-            // the legs the last level did not request, then the rest of the window coefficients
-#pragma unroll
-            for (int k = 2 * RO_K32_PIPE_J; k < H; ++k)
-                S::load_pair(rs_next, po, k * (N / 32) * S::BYTES, v[k], v[H + k]);
         }
-        load_window(win_rsrc(has_next), cE{}, cN{});
         stamp(11);
         prev_out = a.rows_out + row * a.row_stride;
         prev_bytes = N * 4;
@@ -455,8 +560,8 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
         }
     }
     if constexpr (RO_STAMPS32K) {
-        if (a.stamps && (tid == 0 || tid == 960))
-            for (int k = 0; k < 16; ++k) a.stamps[(blockIdx.x * 2 + (tid != 0)) * 16 + k] = st_acc[k];
+        if (a.stamps && (tid & 63) == 0)
+            for (int k = 0; k < 16; ++k) a.stamps[(blockIdx.x * 16 + wave) * 16 + k] = st_acc[k];
     }
 }
 

@@ -13,20 +13,28 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "radio-observer_amd", "csrc", "ro_kernels.hip")
+SOURCES = [os.path.join(ROOT, "radio-observer_amd", "csrc", f) for f in ("ro_kernels.hip", "ro_stft32k.hip")]
+
+
+def compile_isa(dirname, sources, extra=()):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    text = ""
+    for src in sources:
+        out = os.path.join(str(dirname), os.path.basename(src) + ".s")
+        cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-S", "--cuda-device-only",
+               *extra, src, "-o", out]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        text += open(out).read()
+    return text
 
 
 @pytest.fixture(scope="module")
 def isa(tmp_path_factory):
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        pytest.skip("no hipcc on this box")
-    out = tmp_path_factory.mktemp("isa") / "ro_kernels.s"
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-S", "--cuda-device-only",
-           SRC, "-o", str(out)]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
-    return open(out).read()
+    """the ISA of every kernel of the product library (both device sources, the flags of build.py)"""
+    return compile_isa(tmp_path_factory.mktemp("isa"), SOURCES)
 
 
 def kernels(text):
@@ -58,6 +66,7 @@ def test_lds_traffic_between_consecutive_barriers(isa):
     stft = [k for k in ks if "stft_kernel" in k]
     # 8 plans x 2 sample formats x {magnitudes, spectra} + the one-kernel large transform on the N = 32768 plan x 2 formats
     assert len(stft) == 34
+    assert len([k for k in ks if "stft32k_kernel" in k]) == 2
     for name, body in ks.items():
         seen, lds = False, False
         for i, line in enumerate(body):
@@ -66,6 +75,10 @@ def test_lds_traffic_between_consecutive_barriers(isa):
                 seen, lds = True, False
             elif re.search(r"\bds_(read|write|add)|buffer_load.*\blds\b", line):
                 lds = True
+            elif re.match(r"\s+s_c?branch", line):
+                # a branch between two barriers (stft32k_kernel's image-complete barrier sits in both arms of "has work
+                # on the image or not"): what follows in the text is not what follows in time
+                seen = False
 
 
 def test_addtid_writes_are_waited_for_before_the_barrier(isa):
@@ -84,3 +97,101 @@ def test_addtid_writes_are_waited_for_before_the_barrier(isa):
             elif "s_barrier" in line:
                 assert not pending, "s_barrier after un-waited ds_write_addtid_b32 in %s at +%d" % (name, i)
     assert checked > 0
+
+
+# ---------------------------------------------------------------------------
+# Hazards that hipcc does not pad for us
+# ---------------------------------------------------------------------------
+def _regs(tok):
+    """VGPR numbers named by an operand like v12 or v[12:15]"""
+    m = re.fullmatch(r"v(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    return set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()
+
+
+def _instr(line):
+    """(mnemonic, operand list) of an instruction line, or None for labels / comments / directives"""
+    m = re.match(r"^\s+([a-z][a-z0-9_]*)\s*(.*)$", line)
+    if not m or line.lstrip().startswith((";", ".")):
+        return None
+    ops = [t.strip() for t in re.split(r",\s*(?![^\[]*\])", m.group(2).split(";")[0].strip()) if t.strip()]
+    return m.group(1), ops
+
+
+def _valu_defs(mn, ops):
+    """VGPRs a VALU instruction writes"""
+    if not mn.startswith("v_") or not ops:
+        return set()
+    if mn.startswith(("v_cmp", "v_readlane", "v_readfirstlane")):
+        return set()
+    d = _regs(ops[0])
+    if mn.startswith(("v_permlane32_swap", "v_permlane16_swap", "v_swap")) and len(ops) > 1:
+        d |= _regs(ops[1])
+    return d
+
+
+def wide_store_hazards(text):
+    """every 12/16-byte store whose data registers a VALU instruction overwrites within the next two wait states
+    (ro_device_util.h, buf_store_f4): [(kernel, line offset, store, writer)]"""
+    bad, stores = [], 0
+    for name, body in kernels(text).items():
+        for i, line in enumerate(body):
+            ins = _instr(line)
+            if not ins or not re.match(r"(buffer|global|flat|scratch)_store_dwordx[34]$", ins[0]):
+                continue
+            stores += 1
+            data = _regs(ins[1][1] if ins[0].startswith(("global", "flat", "scratch")) else ins[1][0])
+            assert data, line
+            waited, j = 0, i + 1
+            while waited < 2 and j < len(body):
+                nxt = _instr(body[j])
+                j += 1
+                if not nxt:
+                    continue
+                if _valu_defs(*nxt) & data:
+                    bad.append((name, i, line.strip(), body[j - 1].strip()))
+                    break
+                waited += int(nxt[1][0], 0) + 1 if nxt[0] == "s_nop" else 1
+    return bad, stores
+
+
+def test_no_valu_write_to_store_data_within_two_wait_states(isa):
+    bad, stores = wide_store_hazards(isa)
+    assert stores > 100           # the row stores of every plan, fold / interleave / FP64 / chirp-z kernels
+    assert not bad, bad[:5]
+
+
+def test_the_store_hazard_check_sees_an_unguarded_build(tmp_path):
+    """the same kernels without buf_store_f4's wait states: the check above must go red on them, or it proves nothing"""
+    text = compile_isa(tmp_path, SOURCES[1:], extra=("-DRO_STORE_NOP=0",))
+    bad, stores = wide_store_hazards(text)
+    assert stores >= 16 and bad, "no hazard found in the unguarded build of stft32k_kernel (%d stores)" % stores
+
+
+def test_square_roots_are_not_stored_to_lds_straight_away(isa):
+    """v_sqrt_f32 runs in the transcendental pipe and the add-TID writes that take its result sit in inline asm, where
+    hipcc pads nothing: the kernels keep at least four wait states between the two (image writes one pair late)."""
+    checked = 0
+    for name, body in kernels(isa).items():
+        last_sqrt = {}                      # VGPR -> wait states since the v_sqrt_f32 that wrote it
+        for line in body:
+            ins = _instr(line)
+            if not ins:
+                continue
+            mn, ops = ins
+            step = int(ops[0], 0) + 1 if mn == "s_nop" else 1
+            if mn == "ds_write_addtid_b32":
+                for r in _regs(ops[0].split()[0]):
+                    if r in last_sqrt:
+                        checked += 1
+                        assert last_sqrt[r] >= 4, "%s: v%d stored %d wait states after its v_sqrt_f32" % (name, r, last_sqrt[r])
+            for r in list(last_sqrt):
+                last_sqrt[r] += step
+            for r in _valu_defs(mn, ops):
+                last_sqrt.pop(r, None)
+            if mn.startswith("v_sqrt_f32"):
+                for r in _regs(ops[0]):
+                    last_sqrt[r] = 0
+    assert checked >= 64

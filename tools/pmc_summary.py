@@ -4,7 +4,7 @@ per kernel name.  usage: pmc_summary.py <prof dir>"""
 import csv, glob, os, sys, collections
 d = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(d, "pmc_*", "*", "*_counter_collection.csv")):
+for f in glob.glob(os.path.join(d, "p*", "*", "*_counter_collection.csv")):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"][:60]
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))

@@ -24,18 +24,32 @@ torch.cuda.synchronize()
 lib.ro_stft_debug_stamps(st._h, None, 0)          # allocate; from now on the kernel records
 run()
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    run()
+e1.record()
+torch.cuda.synchronize()
+kernel_us = e0.elapsed_time(e1) * 1000.0 / 20
 buf = np.zeros(4096 * 16, dtype=np.uint64)
 lib.ro_stft_debug_stamps(st._h, buf.ctypes.data_as(C.c_void_p), buf.size)
-a = buf.reshape(-1, 16)[:512].astype(np.float64)
+a = buf.reshape(256, 16, 16).astype(np.float64)          # [workgroup][wave][stamp]
 names = ["window (+sample / window wait)", "pass 0 levels 0-3 + old image out", "barrier a (image free)",
          "pass 0 last level + x writes", "exchange 1 rest (barriers b, c, d)", "pass 1 levels 0-3 (+touch, tw2 loads)",
          "pass 1 last level + x writes", "exchange 2 (no barrier)", "pass 2 levels 0-3",
          "pass 2 last level + mags + loads", "wait + barrier e (image complete)", "scan / tile + late loads"]
-for which, label in ((0, "wave 0"), (1, "wave 15")):
-    w = a[which::2]
-    w = w[w[:, 15] > 0]
-    per_row = w[:, :12].sum(0) / w[:, 15].sum()
-    tot = per_row.sum()
-    print("%s (scan fused: %s): workgroups %d, rows/wg %.1f, ticks/row %.0f" % (label, scan, len(w), w[:, 15].mean(), tot))
-    for n, t in zip(names, per_row):
-        print("  %-42s %8.0f ticks  %5.1f %%" % (n, t, 100 * t / tot))
+rows_wg = a[:, 0, 15].mean()
+per = a[:, :, :12].sum(0) / a[:, :, 15].sum(0)[:, None]          # [wave][stamp] ticks per row
+tot = per.sum(1)
+print("scan fused: %s; workgroups 256, rows/wg/launch %.1f, ticks/row %.0f; launch %.1f us -> %.2f us/row, clock ~ %.2f GHz" % (
+    scan, rows_wg, tot.mean(), kernel_us, kernel_us / rows_wg, tot.mean() * rows_wg / kernel_us / 1000.0))
+print("per wave, ticks per row: e->a work = scan/late loads + window + pass 0 head; a wait; a->d; d->e work; e wait")
+for w in range(16):
+    ea = per[w, 11] + per[w, 0] + per[w, 1]
+    print("  wave %2d  e->a %6.0f (scan/late %5.0f window %5.0f head %5.0f)  wait a %5.0f  a->d %5.0f  d->e %6.0f  wait e %5.0f" % (
+        w, ea, per[w, 11], per[w, 0], per[w, 1], per[w, 2], per[w, 3] + per[w, 4], per[w, 5:10].sum(), per[w, 10]))
+if "--brief" not in sys.argv:
+    for w in (0, 1, 15):
+        print("wave %d" % w)
+        for n, t in zip(names, per[w]):
+            print("  %-42s %8.0f ticks  %5.1f %%" % (n, t, 100 * t / tot[w]))
