@@ -219,8 +219,10 @@ int ro_ln_levels(const float *ln, int64_t count, float mn, float mx, uint8_t *le
  * (src/FFTBackend.cpp:236) and hands to the protected hook FFTBackend::processFFT(const fftw_complex *data,
  * int size, DataInfo, int rawMark) (src/FFTBackend.h:104) -- bin k of row r at d_spectra[r * stride + k] as
  * {float re, float im}, unshifted (k = 0 is DC), unnormalised, after gain and window like the magnitude path.
- * Same kernels with a different last step; rows x stride x 8 bytes are written.  bins <= 32768 only
- * (RO_ERR_UNSUPPORTED above).  Asynchronous on `stream`. */
+ * Same kernels with a different last step; rows x stride x 8 bytes are written.  Every size the handle supports:
+ * one kernel up to 32768 bins, fold + transform + interleave through the handle's scratch above (power-of-two bins,
+ * float32: RO_ERR_UNSUPPORTED for chirp-z lengths and for RO_PRECISION_F64 handles).  Asynchronous on `stream`; one launch in flight per handle
+ * above 32768 bins (the scratch is the handle's). */
 int ro_stft_spectra_resident(ro_stft_t *h, const void *d_iq, int format, int64_t samples,
                              int64_t first_row, int64_t rows,
                              float *d_spectra /* rows x stride x {re, im} */, int64_t stride, void *stream);

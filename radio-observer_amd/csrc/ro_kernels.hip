@@ -20,105 +20,46 @@
 #include <mutex>
 #include <type_traits>
 
-// Diagnostic builds only (tools/ablate.sh): -DRO_ABLATE=<bits> removes one phase of the
-// STFT kernel to price it.  1: no twiddle loads, 2: no window loads, 4: no LDS exchange,
-// 8: no butterflies, 16: no row stores, 32: no sample loads.  Results are wrong by design.
-#ifndef RO_ABLATE
-#define RO_ABLATE 0
-#endif
-// Diagnostic only: -DRO_STAMPS=1 accumulates s_memtime deltas per phase of the row loop and
-// lets lane 0 of wave 0 of every workgroup write them to StftArgs::stamps (9 x u64 per
-// workgroup + row count).  Never timed, never shipped: the fences change the overlaps.
+// The ONE diagnostic switch of this file.  A -DRO_DIAG=1 build (tools/ab_build.sh) may set RO_STAMPS=1 (s_memtime
+// deltas per phase of the row loop, written to StftArgs::stamps by lane 0 of wave 0 of every workgroup; never timed:
+// the fences change the overlaps) and gets the run-time knobs of launch_plan (RO_SLOTS, RO_STAGGER, RO_PREFETCH).
+// The product build has neither.  (Round 1 and 2's other build-time switches -- ablations, the exchange and load
+// variants -- are gone: what they measured is in profiles/r01_ablation.txt and r02_ab_attempts.txt, and the choices
+// they settled are the constants below.)
+#ifdef RO_DIAG
 #ifndef RO_STAMPS
 #define RO_STAMPS 0
 #endif
-// 16-byte sample loads shared by lane pairs (see load_row); 0 = one 8-byte load per sample
-#ifndef RO_PAIRED_LOADS
-#define RO_PAIRED_LOADS 1
-#endif
-// window coefficients in the kernel's own order (16-byte loads, see stft_window_layout); 0 = natural table, 8-byte loads
-#ifndef RO_WIN_PERM
-#define RO_WIN_PERM 1
-#endif
-// Plans with registers to spare (N <= 8192: LDS, not VGPRs, limits their occupancy) keep their window coefficients
-// and stage twiddles in registers for the whole persistent loop instead of re-reading them from L2 for every row --
-// per row only the samples come in and the magnitudes go out (14-35 % faster).  0 = reload per row like N >= 16384,
-// where the row itself fills the registers.
-#ifndef RO_RESIDENT_TABLES
-#define RO_RESIDENT_TABLES 1
-#endif
-// N = 32768 plan: lanes l and l+32 share their sample columns and trade halves with v_permlane32_swap_b32
-// (1 VALU op per register) instead of lanes l and l^1 with a DPP move + select (2 ops); needs RO_USE_ADDTID
-#ifndef RO_SWAP32
-#define RO_SWAP32 1
-#endif
-// The hop new samples of the workgroup's NEXT row are touched (one dword per 128-byte line, value unused) well
-// before the epilogue asks for them: they come from HBM, every other byte of the row from L2, and that one miss
-// latency sat on the critical path of every row.  Where: 1 = after the window stage, 2 = after the first exchange
-// (default: nothing queues behind the misses there; measured 5 % faster than 1), 3 = after the second; 0 = never.
-#ifndef RO_PREFETCH_NEXT
-#define RO_PREFETCH_NEXT 2
-#endif
-// LDS exchange of the N = 32768 plan through ds_write_addtid_b32 (1) or plain ds_write_b32 (0)
-// the N = 16384 plan on the add-TID exchange as well (0: the generic ds_write_b32 exchange)
-#ifndef RO_ADDTID_16384
-#define RO_ADDTID_16384 1
-#endif
-// ... and the N = 8192 plan (split planes, tables re-read per row, four workgroups of 256 threads per CU instead of
-// two with window and twiddles resident in 234 VGPRs)
-#ifndef RO_ADDTID_8192
-#define RO_ADDTID_8192 1
-#endif
-#ifndef RO_USE_ADDTID
-#define RO_USE_ADDTID 1
-#endif
-// N = 32768 plan, software-pipelined row loop (1): the next row's sample / window loads are issued from inside the
-// LAST butterfly level of the current row, each into the registers whose magnitudes have just gone to the LDS image,
-// and the image leaves for HBM (LDS read-back + 16-byte stores) from inside the NEXT row's window stage and first
-// butterflies.  The memory pipe (about 9k cycles per row for 448 KiB at ~56 B/clk/CU) then runs beside the VALU
-// instead of in an epilogue of its own where all 16 waves sat in its queue.  0 = the round-1 epilogue.
-#ifndef RO_PIPE
-#define RO_PIPE 1
-#endif
-// fused band scan (BolidRecorder::noise/peak/average on the LDS image, two waves) and band tile in the PIPE epilogue
-// how many of the last level's eight butterfly pairs request next-row samples (two 16-byte loads each); the rest
-// of the samples is requested behind the barrier / the fused scan
-#ifndef RO_PIPE_J
-#define RO_PIPE_J 6
-#endif
-#ifndef RO_SCAN_W0
-#define RO_SCAN_W0 0
-#define RO_SCAN_W1 1
-#define RO_SCAN_W2 2
-#define RO_SCAN_W3 3
-#endif
-#ifndef RO_FUSE_SCAN
-#define RO_FUSE_SCAN 1
-#endif
-// threads per workgroup of the N = 32768 plan: 1024 (32 points per thread) or 512 (64 points: every thread runs two
-// of the scheme's 1024 "logical threads"; same bits, 5 % slower -- 2 waves per SIMD -- and its 256 VGPRs still do not
-// hold window + twiddles resident, which was the point of trying it)
-#ifndef RO_T32768
-#define RO_T32768 1024
-#endif
-// share (percent) of the next row's window coefficients that is prefetched across the transform
-#ifndef RO_WIN_EARLY_PCT
-#define RO_WIN_EARLY_PCT 50
-#endif
-#ifndef RO_PIPE_WIN_EARLY_PCT
-#define RO_PIPE_WIN_EARLY_PCT 25
-#endif
-// window coefficients in flight per chunk (two chunks are outstanding)
-#ifndef RO_WIN_CHUNK
-#define RO_WIN_CHUNK 2
-#endif
-
-// N = 32768 magnitude rows run on ro_stft32k.hip's kernel (1); 0 = the round-2 pipelined loop of stft_kernel (A/B builds)
-#ifndef RO_USE_K32
-#define RO_USE_K32 1
+#define RO_DIAG_KNOBS 1
+#else
+#define RO_STAMPS 0
 #endif
 
 namespace ro {
+
+// 16-byte sample loads shared by lane pairs (see load_row) instead of one 8-byte load per sample
+constexpr bool RO_PAIRED_LOADS = true;
+// window coefficients in the kernel's own order (16-byte loads, see stft_window_layout) instead of the natural table
+constexpr bool RO_WIN_PERM = true;
+// Plans with registers to spare (N <= 4096: LDS, not VGPRs, limits their occupancy) keep their window coefficients
+// and stage twiddles in registers for the whole persistent loop instead of re-reading them from L2 for every row --
+// per row only the samples come in and the magnitudes go out (14-35 % faster).
+constexpr bool RO_RESIDENT_TABLES = true;
+// add-TID plans: lanes l and l+32 share their sample columns and trade halves with v_permlane32_swap_b32 (1 VALU op
+// per register) instead of lanes l and l^1 with a DPP move + select (2 ops)
+constexpr bool RO_SWAP32 = true;
+// The hop new samples of the workgroup's NEXT row are touched (one dword per 128-byte line, value unused) well
+// before the epilogue asks for them: they come from HBM, every other byte of the row from L2, and that one miss
+// latency sat on the critical path of every row.  Where: 1 = after the window stage, 2 = after the first exchange
+// (nothing queues behind the misses there; measured 5 % faster than 1), 3 = after the second.
+constexpr int RO_PREFETCH_NEXT = 2;
+// the N = 32768 (complex spectra and the one-kernel large transform; magnitude rows run on ro_stft32k.hip), 16384 and
+// 8192 plans exchange through ds_write_addtid_b32 (8192: split planes, tables re-read per row, four workgroups of 256
+// threads per CU instead of two with window and twiddles resident in 234 VGPRs)
+constexpr bool RO_USE_ADDTID = true, RO_ADDTID_16384 = true, RO_ADDTID_8192 = true;
+// share (percent) of the next row's window coefficients that is prefetched across the transform (the 1024-thread plan
+// has registers for a quarter only)
+constexpr int RO_WIN_EARLY_PCT = 50;
 
 // ---------------------------------------------------------------------------
 // plan
@@ -156,11 +97,8 @@ template <class PL> constexpr bool plan_addtid()
            PL::R2 == PL::N / 1024 && PL::R3 == 1 && PL::SPLIT;
 }
 template <class PL> constexpr bool plan_swap32() { return plan_addtid<PL>() && RO_SWAP32 && RO_PAIRED_LOADS; }
-// the pipelined row loop (RO_PIPE) with the fused scan: 1024-thread add-TID plan, magnitude mode
-template <class PL> constexpr bool plan_pipe() { return plan_addtid<PL>() && RO_PIPE && PL::T == 1024 && !RO_ABLATE; }
-// dynamic LDS of a plan: the exchange image; behind it, for the pipelined add-TID plan, 1 KiB of histogram for the
-// fused scan's radix select
-template <class PL> constexpr int plan_lds_bytes() { return PL::LDS_BYTES + (plan_pipe<PL>() ? 1024 : 0); }
+// dynamic LDS of a plan: the exchange image
+template <class PL> constexpr int plan_lds_bytes() { return PL::LDS_BYTES; }
 
 // Paired sample loads: which stage-0 column a thread transforms, and the first sample it fetches.
 // Lanes l, l^1 (default) or l, l+32 (swap32) fetch the SAME two adjacent columns with 16-byte loads, one lane
@@ -181,7 +119,6 @@ template <class PL> __host__ __device__ constexpr int plan_pair_off(int tid)
 // ---------------------------------------------------------------------------
 template <int P, int R> __device__ __forceinline__ void butterflies(v2f (&v)[P])
 {
-    if constexpr (RO_ABLATE & 8) return;
 #pragma unroll
     for (int b = 0; b < P / R; ++b) {
         dit<R>(&v[b * R]);
@@ -190,7 +127,6 @@ template <int P, int R> __device__ __forceinline__ void butterflies(v2f (&v)[P])
 
 __device__ __forceinline__ v2f tw_load(__amdgpu_buffer_rsrc_t tw, int koff, int entry)
 {
-    if constexpr (RO_ABLATE & 1) return (v2f){0.7f, 0.7f};
     return buf_load_f2(tw, koff, entry * 8);
 }
 
@@ -212,7 +148,7 @@ __device__ __forceinline__ void tw_prefetch(v2f (&t)[P / R][TW_SET], __amdgpu_bu
 #pragma unroll
     for (int b = 0; b < P / R; ++b) {
         const int koff = ((tid + T * b) & (NS - 1)) * 8;
-        if constexpr (R >= 16 && !(RO_ABLATE & 1)) {
+        if constexpr (R >= 16) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(twk, koff * 2, (PK + q * NS) * 16, 0);
@@ -223,9 +159,6 @@ __device__ __forceinline__ void tw_prefetch(v2f (&t)[P / R][TW_SET], __amdgpu_bu
                 else if (q == 1) { t[b][2] = lo; t[b][3] = hi; }
                 else { t[b][4] = lo; if constexpr (R == 16) t[b][5] = hi; }
             }
-        } else if constexpr (R >= 16) {          // RO_ABLATE & 1: no loads
-#pragma unroll
-            for (int c = 0; c < TW_SET; ++c) t[b][c] = tw_load(tw, koff, 0);
         } else if constexpr (C8 && R == 8) {
             t[b][0] = tw_load(tw, koff, OFF);
             t[b][1] = tw_load(tw, koff, OFF + NS);
@@ -238,7 +171,7 @@ __device__ __forceinline__ void tw_prefetch(v2f (&t)[P / R][TW_SET], __amdgpu_bu
 }
 
 // stage twiddles applied up front: x[r] *= w^r, all R-1 powers held (radix <= 8; larger radices go through
-// tw_butterflies' fused forms and only come here in the RO_ABLATE & 8 diagnostic build, where results do not matter)
+// tw_butterflies' fused forms)
 template <int P, int R, bool C8 = false>
 __device__ __forceinline__ void tw_apply(v2f (&v)[P], const v2f (&t)[P / R][TW_SET])
 {
@@ -268,7 +201,7 @@ __device__ __forceinline__ void tw_apply(v2f (&v)[P], const v2f (&t)[P / R][TW_S
 template <int P, int R, bool C8 = false>
 __device__ __forceinline__ void tw_butterflies(v2f (&v)[P], const v2f (&t)[P / R][TW_SET])
 {
-    if constexpr (R >= 16 && !(RO_ABLATE & 8)) {
+    if constexpr (R >= 16) {
 #pragma unroll
         for (int b = 0; b < P / R; ++b) {
             v2f *x = &v[b * R];
@@ -352,7 +285,6 @@ template <class PL, int RA, int NS, int RB, typename ST>
 __device__ __forceinline__ void exchange(void *smem, v2f (&v)[PL::P], int tid, ST sub)
 {
     constexpr int N = PL::N, P = PL::P, T = PL::T;
-    if constexpr (RO_ABLATE & 4) return;
     if constexpr (PL::SPLIT) {
         float *lds = reinterpret_cast<float *>(smem);
         lds_scatter<P, T, RA, NS>(lds, v, tid, [](v2f e) { return e.x; });
@@ -421,7 +353,6 @@ template <int ROWB, typename F> __device__ __forceinline__ void addtid_scatter32
 template <int XCH, bool SWAP32, int NB, int T, typename ST>
 __device__ __forceinline__ void exchange_addtid(void *smem, v2f (&v)[32 * NB], int tid, ST sub)
 {
-    if constexpr (RO_ABLATE & 4) return;
     constexpr int TL = T * NB, S = TL / 32, R2 = S;
     constexpr int ROW = XCH == 1 ? TL + 1 : TL;                   // floats per register-slot row of the image
     constexpr bool PERM = XCH == 1 && SWAP32;
@@ -477,57 +408,6 @@ __device__ __forceinline__ void exchange_addtid(void *smem, v2f (&v)[32 * NB], i
     sub(3);
 }
 
-// The same exchange in pieces, for the pipelined row loop: the x-plane scatter is issued by the caller from inside the
-// last butterfly level of the finished stage (scatter_x_pair, four slots per pair of butterflies, so the LDS writes run
-// beside the VALU instead of behind it); exchange_tail does the rest and ends WITHOUT a barrier behind its y-plane
-// gather -- the caller places that barrier after levels 0..3 of the next stage, right in front of the next LDS writes,
-// and the gathers return in the order the first level consumes them (slot i, i + 16), so the butterflies start while
-// the gather is still coming in.
-template <int XCH> constexpr int addtid_row_bytes() { return (XCH == 1 ? 1025 : 1024) * 4; }
-// M0 for slots 16..31 (see addtid_scatter32): M0 and the offset field hold 16 bits each
-template <int ROWB> constexpr int addtid_hb() { return (31 * ROWB - 65532 + 3) / 4 * 4; }
-
-// slots of the four registers a last-level pair (j, 8 + j) finishes: 2j -> q, 16+2j -> q+1, 2j+1 -> q+16, 17+2j -> q+17
-template <int ROWB, int J>
-__device__ __forceinline__ void addtid_write_pair(unsigned wave_bytes, float s_q, float s_q1, float s_q16, float s_q17)
-{
-    constexpr int q = bitrev<32>(2 * J), HB = addtid_hb<ROWB>();
-    static_assert(q % 2 == 0 && q < 16 && bitrev<32>(2 * J + 1) == q + 16 && bitrev<32>(16 + 2 * J) == q + 1 &&
-                  bitrev<32>(17 + 2 * J) == q + 17, "slot algebra");
-    static_assert(HB + 3840 <= 65532 && 31 * ROWB - HB <= 65535 && 16 * ROWB - HB >= 0, "M0 / offset split");
-    addtid_write4<ROWB * q, ROWB * (q + 1), ROWB * (q + 16) - HB, ROWB * (q + 17) - HB>(wave_bytes, wave_bytes + HB, s_q,
-                                                                                        s_q1, s_q16, s_q17);
-}
-
-template <int XCH, bool SWAP32>
-__device__ __forceinline__ void exchange_tail(void *smem, v2f (&v)[32], int tid)
-{
-    constexpr int ROW = XCH == 1 ? 1025 : 1024;
-    constexpr bool PERM = XCH == 1 && SWAP32;
-    const float *lds = reinterpret_cast<const float *>(smem);
-    const unsigned wave_bytes = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6) * 256u;
-    const int q = tid >> 5;
-    const float *gb = lds + (XCH == 1 ? (tid & 31) * 1025 + (PERM ? 32 * (q & 1) + (q >> 1) : q) : (tid >> 5) * 1024 + (tid & 31));
-    auto goff = [](int r) constexpr { return PERM ? 64 * (r >> 1) + 16 * (r & 1) : 32 * r; };
-    typedef const volatile __attribute__((address_space(3))) float lds_vfloat;
-    lds_vfloat *gv = (lds_vfloat *)gb;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the caller's x-plane scatter
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int r = 0; r < 32; ++r) v[r].x = gv[goff(r)];
-    wg_sync();
-    addtid_scatter32<ROW * 4>(wave_bytes, [&](int s) { return v[bitrev<32>(s)].y; });
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {                                // the order level 0 of the next stage pairs them
-        v[i].y = gv[goff(i)];
-        v[i + 16].y = gv[goff(i + 16)];
-    }
-}
-
 // ---------------------------------------------------------------------------
 // the STFT kernel
 // ---------------------------------------------------------------------------
@@ -541,12 +421,7 @@ __device__ __forceinline__ void exchange_tail(void *smem, v2f (&v)[32], int tid)
 // (below).
 // waves per SIMD the register allocation must leave room for.  MODE 3 wants two of its 512-thread workgroups on a CU
 // (4 waves per SIMD, 128 VGPRs): one sums its blocks -- loads -- while the other runs its butterflies.
-#ifndef RO_DIF_WAVES
-#define RO_DIF_WAVES 4
-#endif
-#ifndef RO_MINW8192
-#define RO_MINW8192 3
-#endif
+constexpr int RO_DIF_WAVES = 4, RO_MINW8192 = 3;
 template <class PL, int FMT, int MODE> constexpr int plan_min_waves()
 {
     return MODE == 3 ? RO_DIF_WAVES : (PL::N == 8192 && plan_addtid<PL>()) ? RO_MINW8192 : 1;
@@ -632,16 +507,14 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
 #pragma unroll
                 for (int k = 0; k < H; ++k) {
                     v2f &lo = v[R0 * b + k], &hi = v[R0 * b + H + k];
-                    if constexpr ((RO_ABLATE & 32) != 0) { lo = (v2f){1.0f + k, 0.5f}; hi = (v2f){0.25f, 2.0f + k}; }
-                    else S::load_pair(rs, po, k * (N / R0) * S::BYTES, lo, hi);
+                    S::load_pair(rs, po, k * (N / R0) * S::BYTES, lo, hi);
                 }
             }
         } else {
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 // slot i: butterfly i / R0, leg i % R0 of stage 0
-                if constexpr (RO_ABLATE & 32) v[i] = (v2f){(float)(tid + i), 1.0f};
-                else v[i] = S::load(rs, (tid + T * (i / R0)) * S::BYTES, (i % R0) * (N / R0) * S::BYTES);
+                v[i] = S::load(rs, (tid + T * (i / R0)) * S::BYTES, (i % R0) * (N / R0) * S::BYTES);
             }
         }
     };
@@ -681,26 +554,21 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
 #pragma unroll
                 for (int k = first; k < last; k += 2) {
                     v4f &d = w4[b * (NW / 2) + k / 2];
-                    if constexpr (RO_ABLATE & 2) d = (v4f){0.5f, 0.5f, 0.5f, 0.5f};
-                    else {
-                        const u32x4 t =
-                            __builtin_amdgcn_raw_buffer_load_b128(rs_win, (tid + T * b) * 16, (k / 2) * TL * 16, 0);
-                        d = (v4f){__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
-                    }
+                    const u32x4 t =
+                        __builtin_amdgcn_raw_buffer_load_b128(rs_win, (tid + T * b) * 16, (k / 2) * TL * 16, 0);
+                    d = (v4f){__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
                 }
             }
         } else if constexpr (PAIRED) {
             static_assert(NB == 1 || WPERM, "several logical threads need the kernel-order window table");
 #pragma unroll
             for (int k = first; k < last; ++k) {
-                if constexpr (RO_ABLATE & 2) w[k] = (v2f){0.5f, 0.5f};
-                else w[k] = buf_load_f2(rs_win, pair_off(0) * 4, k * (N / R0) * 4);
+                w[k] = buf_load_f2(rs_win, pair_off(0) * 4, k * (N / R0) * 4);
             }
         } else {
 #pragma unroll
             for (int i = first; i < last; ++i) {
-                if constexpr (RO_ABLATE & 2) w[i] = 0.5f;
-                else w[i] = buf_load_f(rs_win, tid * 4, (T * (i / R0) + (i % R0) * (N / R0)) * 4);
+                w[i] = buf_load_f(rs_win, tid * 4, (T * (i / R0) + (i % R0) * (N / R0)) * 4);
             }
         }
     };
@@ -711,7 +579,7 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
     // (the pipelined plan has fewer registers to spare -- the fused scan's two waves keep their band in registers
     // while the next row's samples are already landing: a quarter; with half, hipcc parks one coefficient quad in
     // scratch for the whole row)
-    constexpr int NW_EARLY = DIF ? 0 : ((NW * (plan_pipe<PL>() ? RO_PIPE_WIN_EARLY_PCT : RO_WIN_EARLY_PCT)) / 100) & ~1;
+    constexpr int NW_EARLY = DIF ? 0 : ((NW * (N == 32768 ? 25 : RO_WIN_EARLY_PCT)) / 100) & ~1;
     using c0 = std::integral_constant<int, 0>;
     using cE = std::integral_constant<int, NW_EARLY>;
     using cN = std::integral_constant<int, NW>;
@@ -719,7 +587,7 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
     auto win_rsrc = [&](int64_t, bool valid) { return make_rsrc(win_tab, valid ? N * 4 : 0); };
     if constexpr (!DIF) load_window(win_rsrc(row, true), c0{}, cN{});
     // window and twiddle tables resident in registers (see RO_RESIDENT_TABLES)
-    constexpr bool RES = RO_RESIDENT_TABLES && N <= 8192 && !ADDTID && !RO_ABLATE;   // twiddles (and window)
+    constexpr bool RES = RO_RESIDENT_TABLES && N <= 8192 && !ADDTID;   // twiddles (and window)
     constexpr bool TW8C = ADDTID && PL::R2 == 8;                                     // see tw_prefetch
     // the 512-thread form of the N = 32768 plan has 256 VGPRs per thread: the window stays, the twiddles do not fit
     constexpr bool RESW = RES;
@@ -732,31 +600,8 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
         if constexpr (PL::R3 > 1) tw_prefetch<P, T, PL::R3, PL::NS3, PL::TW3, PL::PK3>(tw3, rs_tw, rs_twk, tid);
     }
 
-    // PIPE: the image of the row before this one (LDS, natural order) and where it goes; 0 bytes = nothing to store
-    constexpr bool PIPE = plan_pipe<PL>() && MODE == 0;
-    constexpr bool FUSE = PIPE && RO_FUSE_SCAN;
-    // Who runs the fused scan and cuts the tile: waves 0..3, the OLDEST wave of each SIMD (waves are dealt to the SIMDs
-    // cyclically and the arbiter serves the oldest first).  In-kernel stamps show wave 0 reaching the barrier in front
-    // of the first exchange ~4.6k cycles before the last wave does: that slack pays for the scan.  (With waves 3, 6, 9,
-    // 12 -- one of them second-oldest on its SIMD -- the fused scan cost 12 % of the kernel.)
-    constexpr int SCAN_WAVE_NOISE = RO_SCAN_W0, SCAN_WAVE_PEAK = RO_SCAN_W1, TILE_WAVE_A = RO_SCAN_W2, TILE_WAVE_B = RO_SCAN_W3;
-    constexpr int PIPE_J = RO_PIPE_J;      // butterfly pairs of the last level that request next-row samples (of 8)
-    const float *prev_out = a.rows_out;
-    unsigned prev_bytes = 0;
     unsigned touch = 0;                    // destination of the next-row prefetch touches (touch_next)
-    // chunk q of the image: 16 bytes per lane from LDS, out as 1 KiB per wave-instruction; column k leaves for
-    // (k + N/2) mod N (src/WaterfallBackend.cpp:492-505)
-    auto store_chunk = [&](int q, const __amdgpu_buffer_rsrc_t &rs) {
-        // (chunks 4..7 lie past the 64 KiB an LDS offset field reaches: without the empty asm hipcc keeps four more
-        // loop-invariant address registers alive through the whole row instead of one add per chunk)
-        int lt = tid;
-        asm volatile("" : "+v"(lt));
-        const float4 x = reinterpret_cast<const float4 *>(smem)[lt + T * q];
-        buf_store_f4(x.x, x.y, x.z, x.w, rs, tid * 16, ((q * T * 4 + N / 2) & (N - 1)) * 4);
-    };
-
     for (;;) {
-        const __amdgpu_buffer_rsrc_t rs_prev = make_rsrc(prev_out, prev_bytes);
         // ---- stage 0: window.  Coefficients arrive in chunks of WIN_CHUNK, two chunks in
         // flight, so the stage peaks at 2P + 2*WIN_CHUNK VGPRs (+P while a row waits to be stored).
         // ---- stage 0: window (coefficients and samples were requested a whole epilogue ago)
@@ -915,176 +760,6 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
         if constexpr (RO_PREFETCH_NEXT == 1) touch_next();
         stamp(0);                                   // window multiply (+ wait for samples)
 
-        if constexpr (PIPE) {
-            // =====================================================================================================
-            // The pipelined row (N = 32768, 1024 threads).  Every stage is cut in front of its last butterfly level:
-            //   levels 0..3 | barrier (everyone is done reading LDS) | last level, whose finished pairs go straight
-            //   to LDS (x plane of the next exchange, or the magnitude image) while the other pairs are still being
-            //   computed | rest of the exchange.
-            // Around the row boundary: the next row's samples are requested from inside the last level of the last
-            // pass, each into the registers whose magnitudes have just gone to the image; the image leaves for HBM
-            // (LDS read-back + 16-byte stores) from inside the next row's first butterflies.
-            // =====================================================================================================
-            static_assert(P == 32 && NB == 1 && SWAP32, "one radix-32 butterfly per thread");
-            const unsigned wave_bytes = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6) * 256u;
-            // ---- pass 0, levels 0..3; the previous row's image goes out between them.
-            dit32_head(v, [&](auto hc) {
-                constexpr int h = decltype(hc)::value;
-                store_chunk(2 * h, rs_prev);
-                store_chunk(2 * h + 1, rs_prev);
-            });
-            tw_prefetch<P, T, 32, PL::NS1, PL::TW1, PL::PK1>(tw1, rs_tw, rs_twk, tid);
-            stamp(2);                               // butterflies 0, levels 0..3 (+ the previous row's read-back and stores)
-            wg_sync();                              // every wave has read its part of the image back: LDS is free
-            stamp(7);
-            // ---- pass 0, last level: x plane of exchange 1 as the pairs finish
-            dit32_last(v, [&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                addtid_write_pair<addtid_row_bytes<1>(), j>(wave_bytes, v[2 * j].x, v[16 + 2 * j].x, v[2 * j + 1].x,
-                                                            v[17 + 2 * j].x);
-                return v[17 + 2 * j].y;
-            });
-            stamp(10);
-            exchange_tail<1, SWAP32>(smem, v, tid);
-            stamp(3);                               // exchange 1
-            // ---- pass 1
-            fdit32_head(v, tw1[0][4], tw1[0][3], tw1[0][2], tw1[0][1]);
-            // the touch sits behind the butterflies: in front of them hipcc's wait for this pass's twiddles would sit
-            // through the touch's HBM miss as well
-            touch_next();
-            tw_prefetch<P, T, 32, PL::NS2, PL::TW2, PL::PK2>(tw2, rs_tw, rs_twk, tid);
-            stamp(4);
-            wg_sync();                              // exchange 1's y plane has been gathered by everyone
-            stamp(11);
-            fdit32_last(v, tw1[0][0], [&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                addtid_write_pair<addtid_row_bytes<2>(), j>(wave_bytes, v[2 * j].x, v[16 + 2 * j].x, v[2 * j + 1].x,
-                                                            v[17 + 2 * j].x);
-                return v[17 + 2 * j].y;
-            });
-            stamp(12);
-            exchange_tail<2, SWAP32>(smem, v, tid);
-            stamp(5);                               // exchange 2
-            // ---- pass 2
-            fdit32_head(v, tw2[0][4], tw2[0][3], tw2[0][2], tw2[0][1]);
-            stamp(6);
-            wg_sync();                              // exchange 2's y plane has been gathered by everyone
-            stamp(13);
-            {
-                // Last level with the epilogue folded in.  After butterflies (j, 8 + j) x[2j], x[2j+1], x[16+2j],
-                // x[17+2j] are final = bins tid + 1024 q for q = qj, qj+16, qj+1, qj+17 (qj = bitrev32(2j)): their
-                // magnitudes go to the natural-order LDS image (byte 4096 q + 4 tid, add-TID), and the four freed
-                // registers receive legs 2j, 2j+1 of the NEXT row's samples -- for j < PIPE_J; the last legs are
-                // requested behind the scan (they are also the last ones the window stage asks for), whose two waves
-                // would not fit the 128 VGPRs with all 64 of them in flight.
-                const __amdgpu_buffer_rsrc_t rs_next = row_rsrc(has_next ? next : row, has_next);   // zero-sized after the last row
-                const int po = pair_off(0) * S::BYTES;
-                // The image writes of pair j are issued one pair late (from done(j + 1), the last ones behind the
-                // level): v_sqrt_f32 runs in the transcendental pipe and hipcc pads no hazards in front of inline asm.
-                float pm0 = 0.f, pm1 = 0.f, pm16 = 0.f, pm17 = 0.f;
-                fdit32_last(v, tw2[0][0], [&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    auto mag = [](v2f x) { const v2f sq = x * x; return __builtin_amdgcn_sqrtf(sq.x + sq.y); };
-                    const float m0 = mag(v[2 * j]), m16 = mag(v[2 * j + 1]);
-                    const float m1 = mag(v[16 + 2 * j]), m17 = mag(v[17 + 2 * j]);
-                    if constexpr (j > 0) addtid_write_pair<4096, (j > 0 ? j - 1 : 0)>(wave_bytes, pm0, pm1, pm16, pm17);
-                    pm0 = m0; pm1 = m1; pm16 = m16; pm17 = m17;
-                    if constexpr (j < PIPE_J) {
-                        // the loads may not start before these magnitudes exist (fake dependence; no instruction)
-                        const int pj = after(po, m17);
-                        S::load_pair(rs_next, pj, (2 * j) * (N / R0) * S::BYTES, v[2 * j], v[H + 2 * j]);
-                        S::load_pair(rs_next, pj, (2 * j + 1) * (N / R0) * S::BYTES, v[2 * j + 1], v[H + 2 * j + 1]);
-                    }
-                    return m17;                                  // the next pair of butterflies is chained behind this
-                });
-                stamp(14);
-                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // the last square roots: see above
-                addtid_write_pair<4096, 7>(wave_bytes, pm0, pm1, pm16, pm17);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the add-TID image writes (hipcc does not count them)
-                wg_sync();                                            // the image of this row is complete
-                stamp(15);
-                if constexpr (FUSE) {
-                    // BolidRecorder's per-row scan on the image (src/BolidRecorder.cpp:121-132, :313-347) by waves 0
-                    // and 1 while the others go on to the next row's window stage; the image stays until the barrier
-                    // in front of the next LDS writes.  Waves 2 and 3 cut the band tile.
-                    // Everything derived from the lane number and the band limits is laundered through empty asm:
-                    // otherwise hipcc hoists those loop invariants in front of the row loop, where they sit in VGPRs
-                    // of all 16 waves for the whole row.
-                    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-                    int lane = tid & 63;
-                    asm volatile("" : "+v"(lane));
-                    const ImageRow<N> img{reinterpret_cast<const float *>(smem)};
-                    if (a.records != nullptr && (wave == SCAN_WAVE_NOISE || wave == SCAN_WAVE_PEAK)) {
-                        int low_noise = a.low_noise, noise_width = a.noise_width, low_detect = a.low_detect;
-                        int detect_width = a.detect_width, avg_bins = a.avg_bins;
-                        asm volatile("" : "+s"(low_noise), "+s"(noise_width), "+s"(low_detect), "+s"(detect_width),
-                                     "+s"(avg_bins));
-                        if (wave == SCAN_WAVE_NOISE) {
-                            unsigned *hist = reinterpret_cast<unsigned *>(smem + PL::LDS_BYTES);
-                            // bands up to 512 columns (the shipped configs: 409 / 410) keep their keys in registers
-                            const float nz = noise_width <= 512 ? scan_noise<8>(img, low_noise, noise_width, hist, lane)
-                                                                : scan_noise<0>(img, low_noise, noise_width, hist, lane);
-                            if (lane == 0) a.records[row].noise = nz;
-                        } else {
-                            const int pk = scan_peak<8>(img, low_detect, detect_width, lane);
-                            const float av = scan_average(img, low_detect + pk - avg_bins / 2, avg_bins, N, lane);
-                            if (lane == 0) {
-                                a.records[row].peak = pk;
-                                a.records[row].average = av;
-                            }
-                        }
-                    }
-                    if (a.tile_out != nullptr && (wave == TILE_WAVE_A || wave == TILE_WAVE_B)) {
-                        int tile_cols = a.tile_cols, tile_first = a.tile_first;
-                        asm volatile("" : "+s"(tile_cols), "+s"(tile_first));
-                        const int half = ((tile_cols + 127) >> 7) << 6;            // first wave's share, whole 64s
-                        const int c0 = wave == TILE_WAVE_A ? 0 : half;
-                        const int c1 = wave == TILE_WAVE_A ? (half < tile_cols ? half : tile_cols) : tile_cols;
-                        float *dst = a.tile_out + row * (int64_t)tile_cols;
-                        if (a.ln_out == nullptr) {
-                            for (int c = c0 + lane; c < c1; c += 64) dst[c] = img(tile_first + c);
-                        } else {
-                            // the viewer's log image of the tile (fits2png:46) and this wave's share of the row's
-                            // min / max over the non-zero pixels (:476-477), while the magnitudes are still in LDS
-                            float *ldst = a.ln_out + row * (int64_t)tile_cols;
-                            unsigned kmin = 0xffffffffu, kmax = 0u;
-                            for (int c = c0 + lane; c < c1; c += 64) {
-                                const float x = img(tile_first + c);
-                                const float l = logf(x);
-                                dst[c] = x;
-                                ldst[c] = l;
-                                if (x != 0.f) {
-                                    const unsigned key = order_key(l);
-                                    kmin = min(kmin, key);
-                                    kmax = max(kmax, key);
-                                }
-                            }
-                            kmin = wave_min_u32(kmin);
-                            kmax = wave_max_u32(kmax);
-                            if (lane == 0) {
-                                float *part = a.ln_part + row * 4 + (wave == TILE_WAVE_A ? 0 : 2);
-                                part[0] = kmin == 0xffffffffu ? __builtin_inff() : key_to_float(kmin);
-                                part[1] = kmax == 0u ? -__builtin_inff() : key_to_float(kmax);
-                            }
-                        }
-                    }
-                }
-                // the legs the last level did not request, then the rest of the window coefficients (behind the scan,
-                // whose waves need the registers; they have the window stage's first legs to land)
-#pragma unroll
-                for (int k = 2 * PIPE_J; k < H; ++k)
-                    S::load_pair(rs_next, po, k * (N / R0) * S::BYTES, v[k], v[H + k]);
-            }
-            if constexpr (!RESW) load_window(win_rsrc(has_next ? next : row, has_next), cE{}, cN{});
-            stamp(8);
-            prev_out = a.rows_out + row * a.row_stride;
-            prev_bytes = N * 4;
-            st_acc[9] += 1;
-            if (!has_next) break;
-            row = next;
-            continue;
-        }
-
         butterflies<P, R0>(v);
         if constexpr (PL::R1 > 1 && !RES) tw_prefetch<P, T, PL::R1, PL::NS1, PL::TW1, PL::PK1>(tw1, rs_tw, rs_twk, fresh_tid());
         stamp(2);                                   // butterflies 0
@@ -1216,8 +891,7 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
 #pragma unroll
             for (int q = 0; q < P / 4; ++q) {
                 const float4 x = lds_m4[tid + T * q];
-                if constexpr (RO_ABLATE & 16) asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
-                else if constexpr (ADDTID)      // natural-order image: column k leaves for (k + N/2) mod N
+                if constexpr (ADDTID)      // natural-order image: column k leaves for (k + N/2) mod N
                     buf_store_f4(x.x, x.y, x.z, x.w, rs_out, tid * 16, ((q * T * 4 + N / 2) & (N - 1)) * 4);
                 else buf_store_f4(x.x, x.y, x.z, x.w, rs_out, tid * 16, q * T * 16);
                 // two reads in flight at most: hoisting all P/4 of them would need P more VGPRs
@@ -1231,15 +905,6 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
         st_acc[9] += 1;
         if (!has_next) break;
         row = next;
-    }
-    if constexpr (PIPE) {
-        // the last row's image (complete: the loop ends behind its barrier); nothing overwrites LDS any more
-        const __amdgpu_buffer_rsrc_t rs_last = make_rsrc(prev_out, prev_bytes);
-#pragma unroll
-        for (int q = 0; q < P / 4; ++q) {
-            store_chunk(q, rs_last);
-            if (q & 1) asm volatile("" ::: "memory");
-        }
     }
     if constexpr (RO_STAMPS) {
         if (a.stamps && tid == 0)
@@ -1752,7 +1417,7 @@ template <class PL, int FMT, int MODE> static hipError_t launch_plan(const StftA
 }
 
 //                      N      T   R0  R1  R2  R3  split
-using Plan32768 = Plan<32768, RO_T32768, 32, 32, 32, 1, true>;
+using Plan32768 = Plan<32768, 1024, 32, 32, 32, 1, true>;    // complex spectra and MODE 3 only
 using Plan16384 = Plan<16384,  512, 32, 32, 16, 1, true>;
 using Plan8192  = Plan< 8192,  256, 32, 32,  8, 1, (RO_ADDTID_8192 && RO_USE_ADDTID)>;
 using Plan4096  = Plan< 4096,  256, 16, 16, 16, 1, false>;
@@ -1772,19 +1437,20 @@ template <class PL> static hipError_t launch_fmt(const StftArgs &a, int fmt, hip
         }
         return hipErrorInvalidValue;
     }
-#if RO_USE_K32
     if constexpr (PL::N == 32768) {
         if (!spec) return launch_stft32k(fmt, a, s);               // magnitude rows: ro_stft32k.hip
+        if (fmt == RO_FMT_F32) return launch_plan<PL, RO_FMT_F32, 1>(a, s);
+        if (fmt == RO_FMT_I16) return launch_plan<PL, RO_FMT_I16, 1>(a, s);
+    } else {
+        if (fmt == RO_FMT_F32) return spec ? launch_plan<PL, RO_FMT_F32, 1>(a, s) : launch_plan<PL, RO_FMT_F32, 0>(a, s);
+        if (fmt == RO_FMT_I16) return spec ? launch_plan<PL, RO_FMT_I16, 1>(a, s) : launch_plan<PL, RO_FMT_I16, 0>(a, s);
     }
-#endif
-    if (fmt == RO_FMT_F32) return spec ? launch_plan<PL, RO_FMT_F32, 1>(a, s) : launch_plan<PL, RO_FMT_F32, 0>(a, s);
-    if (fmt == RO_FMT_I16) return spec ? launch_plan<PL, RO_FMT_I16, 1>(a, s) : launch_plan<PL, RO_FMT_I16, 0>(a, s);
     return hipErrorInvalidValue;
 }
 
 bool stft_fuses_scan(int bins)
 {
-    return bins == 32768 && (RO_USE_K32 || (plan_pipe<Plan32768>() && RO_FUSE_SCAN));
+    return bins == 32768;               // stft32k_kernel (ro_stft32k.hip)
 }
 
 bool stft_supported(int bins)

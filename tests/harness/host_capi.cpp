@@ -1,5 +1,6 @@
-// host_capi.cpp -- plain-C harness over the host mirror, for the ctypes tests only
-// (tests/test_ring.py, tests/test_gpu_host_pipeline.py).  Not part of the product ABI.
+// host_capi.cpp -- plain-C harness over the product's host-side C++ objects (radio-observer_amd/host/, linked as
+// libro_host.so), for the ctypes tests (tests/test_ring.py, tests/test_host_cpu.py, tests/test_gpu_host_pipeline.py)
+// and bench.py's streaming leg.  Test infrastructure: not part of the product, not in its libraries.
 #include <cstring>
 #include <vector>
 

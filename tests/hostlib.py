@@ -1,10 +1,10 @@
-"""ctypes access to the product's host-side C++ mirror (radio-observer_amd/host/libro_host.so),
-used by the CPU tests.  Returns None when it has not been built yet."""
+"""ctypes access to the product's host-side C++ mirror (radio-observer_amd/host/libro_host.so) through the test-only
+harness library tests/harness/libro_host_harness.so, which links it.  Returns None when it has not been built yet."""
 import ctypes as C
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PATH = os.environ.get("RO_HOST_LIB") or os.path.join(ROOT, "radio-observer_amd", "host", "libro_host.so")
+PATH = os.environ.get("RO_HOST_LIB") or os.path.join(ROOT, "tests", "harness", "libro_host_harness.so")
 _lib = False
 
 

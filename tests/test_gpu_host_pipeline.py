@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _need_host():
-    assert host_library() is not None, "radio-observer_amd/host/libro_host.so missing: run __graft_entry__.build()"
+    assert host_library() is not None, "tests/harness/libro_host_harness.so missing: run __graft_entry__.build()"
 
 
 @pytest.mark.parametrize("bins,overlap,chunk,batch", [(1024, 512, 1024, 4), (1024, 512, 4096, 0),

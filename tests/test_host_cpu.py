@@ -13,7 +13,7 @@ from hostlib import BolidEvent, host_library
 @pytest.fixture(scope="module")
 def H():
     L = host_library()
-    assert L is not None, "radio-observer_amd/host/libro_host.so missing: run __graft_entry__.build()"
+    assert L is not None, "tests/harness/libro_host_harness.so missing: run __graft_entry__.build()"
     L.ro_host_frontend_run.restype = C.c_void_p
     L.ro_host_frontend_run.argtypes = [C.c_int, C.c_char_p, C.c_int64, C.c_int, C.c_int64, C.c_int64]
     for n, rt in (("free", None), ("ok", C.c_int), ("calls", C.c_int), ("started", C.c_int),

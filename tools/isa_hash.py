@@ -15,7 +15,7 @@ def funcs(path):
             continue
         if cur:
             if l.startswith('.Lfunc_end'):
-                body = re.sub(r'\.LBB\d+_\d+', 'L', ''.join(buf))
+                body = re.sub(r'(\.L[A-Za-z_]*|\bBB)\d+(_\d+)?', 'L', ''.join(buf))
                 d[cur] = hashlib.md5(body.encode()).hexdigest()
                 cur = None
             else:
