@@ -13,11 +13,15 @@ rows out), sigma=1 Gaussian noise + CW carrier 30 sigma at +10.6 kHz; every step
 BolidRecorder's per-row noise/peak/average scan with radio-observer.json's bands.
 
 A "step" = one pass of the hot path over that batch: the fused window->FFT->|X|->shift
-kernel plus the scan kernel, inputs already in HBM.  With N > 1 every rank owns one time
-chunk of R rows (weak scaling, no collective inside the transform) and each step ends with
-the RCCL gather of that step's waterfall band tile + scan records to rank 0 -- the stitch the
-reference's FITS writer and detector need (--gather all: to every rank) -- overlapped with the
-next step's compute on a side stream.
+kernel with the band scan in its epilogue, inputs already in HBM.  With N > 1 every rank owns
+one time chunk of R rows (weak scaling, no collective inside the transform) and each step ends
+with the RCCL all-gather of that step's waterfall band tile + scan records -- the stitch
+north_star names (--gather root: to rank 0 only, the one consumer the reference has;
+--gather none: compute only; a run reports all three) -- overlapped with the next step's
+compute on a side stream.  --workload c5 is BASELINE config 5 itself: ONE fixed 8-hour stream
+(168 747 rows) split over the ranks by ro_shard_rows (strong scaling), every rank generating
+its own slice from a counter-based generator, rank 0 hashing the stitched band + records so
+that an N-rank run can be compared with the 1-rank run bit for bit.
 
 Prints ONE JSON line on rank 0.
 """
@@ -64,13 +68,22 @@ def parse():
     p.add_argument("--comm", choices=["nccl", "gloo-host"], default="nccl",
                    help="gloo-host: rehearsal mode for 1-GPU boxes -- every rank uses cuda:0 and the gather is "
                         "staged through host memory over gloo (exercises the N>1 control flow, not xGMI)")
-    p.add_argument("--gather", choices=["all", "root", "none"], default="root",
-                   help="N > 1: what ends a step.  root (default) = band tile + scan records gathered to rank 0, the one "
-                        "process that stitches -- the reference's FITS writer and detector are one consumer "
+    p.add_argument("--gather", choices=["all", "root", "none"], default="all",
+                   help="N > 1: what ends a step inside the timed region of `value`.  all (default) = the RCCL all-gather "
+                        "of band tile + scan records north_star and BASELINE's config 5 name (every rank stitches); root = "
+                        "gathered to rank 0 only, the one process that stitches in the reference "
                         "(src/WaterfallBackend.cpp:141-211, src/BolidRecorder.cpp:171-273): 7 direct transfers of 40 MB "
-                        "over 7 xGMI links, where a ring all-gather moves 283 MB through every link (falls back to "
-                        "'all' if the backend refuses the gather); all = all-gather (every rank stitches); none = "
-                        "compute only -- so a scaling run can report compute and exchange separately")
+                        "over 7 xGMI links, where a ring all-gather moves 283 MB through every link; none = compute "
+                        "only.  The other two are measured after the timed region (config.exchange_legs_rows_per_s).")
+    p.add_argument("--exchange", choices=["torch", "capi"], default="torch",
+                   help="who moves the bytes: torch.distributed (default) or the product's own C-ABI exchange "
+                        "(ro_allgather_rows / ro_gather_rows on an ncclComm_t created before the timed loop)")
+    p.add_argument("--workload", choices=["c3", "c5"], default="c3",
+                   help="c3 (default): R rows per GPU and step, weak scaling; c5: BASELINE config 5, one fixed stream of "
+                        "--c5-seconds split over the ranks by ro_shard_rows, strong scaling, hash of the stitched result")
+    p.add_argument("--c5-seconds", type=float, default=8 * 3600.0, help="length of the c5 stream (default 8 h)")
+    p.add_argument("--no-streaming", action="store_true", help="skip the drop-in (Backend::process) streaming leg")
+    p.add_argument("--stream-seconds", type=float, default=2.5, help="timed length of the streaming leg")
     p.add_argument("--no-legs", action="store_true",
                    help="N > 1: skip the extra untimed-for-`value` runs with the other --gather modes (config.exchange_legs_rows_per_s)")
     p.add_argument("--no-strict", action="store_true", help="skip the RO_PRECISION_F64 side measurement")
@@ -208,6 +221,59 @@ def pmc_traffic(rows):
     return per_row * rows
 
 
+def streaming_leg(seconds, max_batch_rows):
+    """rows/s and GB/s of the C++ host mirror's Backend::process path (tests/harness drives it; test infrastructure)"""
+    lib = os.path.join(ROOT, "tests", "harness", "libro_host_harness.so")
+    if not os.path.exists(lib):
+        return {"error": "tests/harness/libro_host_harness.so is missing: run __graft_entry__.build()"}
+    H = ctypes.CDLL(lib)
+    H.ro_host_stream_bench.restype = ctypes.c_int
+    H.ro_host_stream_bench.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                       ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    stats = (ctypes.c_double * 8)()
+    block = 4096
+    rc = H.ro_host_stream_bench(BINS, OVERLAP, FS, block, seconds, max_batch_rows, 2 * (BINS // block) + 64, stats)
+    if rc != 0:
+        return {"error": "ro_host_stream_bench returned %d" % rc}
+    secs, smp, rws = stats[0], stats[1], stats[2]
+    return {"value": rws / secs, "unit": "rows/s", "seconds": secs, "rows": int(rws), "samples": int(smp),
+            "samples_per_s": smp / secs, "real_time_factor": smp / secs / FS,
+            "GBs_in_as_delivered": smp * 16 / secs / 1e9,           # struct Complex = two doubles (src/Backend.h:26-29)
+            "GBs_rows_out": rws * BINS * 4 / secs / 1e9,
+            "process_calls": int(stats[3]), "samples_per_call": block, "rows_per_kernel_launch": int(stats[4]),
+            "ms_per_process_call_mean": stats[5], "ms_per_process_call_max": stats[6], "events_fired": int(stats[7]),
+            "path": "FrontendDriver::process -> HipWaterfallBackend::process (ro_stft_push RO_IQ_F64 -> pinned staging -> "
+                    "H2D -> kernels -> D2H of full rows -> ro_stft_fetch) -> RingBuffer2D -> BolidRecorder::update; "
+                    "startStream (handle creation) and the warm-up calls are outside the timed region, endStream inside"}
+
+
+class RcclComm:
+    """an ncclComm_t of this job's ranks for the product's own exchange (--exchange capi): created through ctypes on
+    librccl, the unique id travelling over the torch.distributed group that already exists"""
+
+    class Uid(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    def __init__(self, dist, world, rank):
+        self.rccl = ctypes.CDLL("librccl.so.1")
+        uid = RcclComm.Uid()
+        if rank == 0:
+            assert self.rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+        box = [ctypes.string_at(ctypes.byref(uid), 128) if rank == 0 else None]      # (all 128 bytes, NULs included)
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        ctypes.memmove(ctypes.byref(uid), box[0], 128)
+        self.comm = ctypes.c_void_p()
+        self.rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, RcclComm.Uid, ctypes.c_int]
+        rc = self.rccl.ncclCommInitRank(ctypes.byref(self.comm), world, uid, rank)
+        if rc != 0:
+            raise RuntimeError("ncclCommInitRank failed with code %d" % rc)
+
+    def close(self):
+        self.rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        self.rccl.ncclCommDestroy(self.comm)
+
+
 def main():
     a = parse()
     global BINS, OVERLAP, HOP, ALG_BYTES_PER_ROW
@@ -216,14 +282,23 @@ def main():
         OVERLAP = a.overlap if a.overlap is not None else (3 * BINS) // 4
         HOP = BINS - OVERLAP
         ALG_BYTES_PER_ROW = HOP * 8 + BINS * 4
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Whatever needs a compiler or a child process happens BEFORE this process touches the GPU (a fork + exec from a
+    # process that holds a device is a hazard on this pool): the -O0 twin of the oracle for the cpu_baseline_O0 leg.
+    o0_lib, o0_err = os.path.join(ROOT, "oracle", "libro_oracle_O0.so"), None
+    if world == 1 and not a.no_cpu_baseline and not os.path.exists(o0_lib):
+        try:
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libro_oracle_O0.so"],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        except Exception as e:                               # no compiler on the box: the leg says so
+            o0_err = str(e)[:200]
     # (read by the ROCm runtime when it initialises -- before the first HIP call: dmabuf IPC is what RCCL needs here)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus %d must be started by torch.distributed.run with %d ranks"
@@ -232,90 +307,118 @@ def main():
         sys.exit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
     if a.comm == "gloo-host":
         local_rank = 0
+        if a.exchange == "capi" and world > 1:
+            sys.exit("--exchange capi needs one GPU per rank (RCCL refuses two ranks on one device): use --comm nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if a.comm == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    gather_used = {"mode": a.gather, "note": None}
-
-    def all_gather(out, inp):
-        """RCCL gather to rank 0 (or, --gather all, all-gather) over xGMI; in rehearsal mode the same exchange
-        through host memory."""
-        if a.comm == "nccl":
-            if gather_used["mode"] == "root":
-                parts = list(out.view((world,) + tuple(inp.shape)).unbind(0)) if rank == 0 else None
-                try:
-                    dist.gather(inp, parts, dst=0)
-                    return
-                except (RuntimeError, NotImplementedError, ValueError) as e:      # same answer on every rank
-                    gather_used["mode"] = "all"
-                    gather_used["note"] = "gather to rank 0 refused by the backend (%s): all-gather instead" % str(e)[:120]
-            dist.all_gather_into_tensor(out, inp)
-        else:
-            h_in = inp.cpu()
-            h_out = torch.empty(out.shape, dtype=out.dtype)
-            if gather_used["mode"] == "root":
-                parts = list(h_out.view((world,) + tuple(h_in.shape)).unbind(0)) if rank == 0 else None
-                dist.gather(h_in, parts, dst=0)
-            else:
-                dist.all_gather_into_tensor(h_out, h_in)
-            out.copy_(h_out)
-
     ro = importlib.import_module("radio-observer_amd")
-    R = a.rows
-    samples = BINS + HOP * (R - 1)
+    sh = ro.sharding()
     bands = make_bands(ro)
     snap_lo = ro.frequency_to_bin(BINS, FS, JSON_SNAPSHOT[0])
     snap_hi = ro.frequency_to_bin(BINS, FS, JSON_SNAPSHOT[1])
-    tile = (snap_lo, snap_hi - snap_lo) if world > 1 else None
+    c5 = a.workload == "c5"
+    tile = (snap_lo, snap_hi - snap_lo) if (world > 1 or c5) else None
+    exchanging = world > 1 or (c5 and a.exchange == "capi")       # (a one-rank communicator still runs the C-ABI calls)
 
-    iq = synth_iq(torch, samples, 0xC3 + rank, dev)       # this rank's time chunk
+    # ---- this rank's input and its place in the job
+    if c5:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import util as tutil                                   # the counter-based C5 generator (test infrastructure)
+        total_samples = int(a.c5_seconds * FS)
+        R_total = ro.row_count(total_samples, BINS, OVERLAP)
+        first_row, R = ro.shard_rows(R_total, world, rank)
+        s0, samples = ro.shard_samples(first_row, R, BINS, OVERLAP)
+        iq = tutil.c5_slice(torch, s0, samples, total_samples=total_samples, device=dev)
+        R_max = ro.shard_max_rows(R_total, world)
+    else:
+        R = a.rows
+        R_total, R_max, first_row = R * world, R, R * rank
+        samples = BINS + HOP * (R - 1)
+        # (every rank its own noise: weak scaling measures rate, not a result; --workload c5 is the comparable one)
+        iq = synth_iq(torch, samples, 0xC3 + rank, dev)
     rows = torch.empty((R, BINS), dtype=torch.float32, device=dev)
     recs = [torch.zeros((R, 3), dtype=torch.float32, device=dev) for _ in range(2)]   # ro_scan_record_t = 12 B
-    # N > 1: the STFT kernel of the large plans owns every register of the CUs it runs on, so the all-gather's
+    # N > 1: the STFT kernel of the large plans owns every register of the CUs it runs on, so the exchange's
     # kernels (side stream) would only run between two of its launches; one CU per XCD is left to them
     st = ro.Stft(bins=BINS, overlap=OVERLAP, sample_rate=FS, device=local_rank, bands=bands, tile=tile,
                  window=ro.RO_WINDOW_HANN if a.window == "hann" else ro.RO_WINDOW_NUTTALL,
                  spare_cus_per_xcd=1 if world > 1 else 0)
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
+    L = ro.library()
 
-    gather = None
-    if world > 1:
+    tiles = g_tiles = g_recs = stage = comm_stream = None
+    comm_done = [None, None]
+    rccl = None
+    if tile:
         tcols = tile[1]
         tiles = [torch.empty((R, tcols), dtype=torch.float32, device=dev) for _ in range(2)]
-        g_tiles = [torch.empty((world * R, tcols), dtype=torch.float32, device=dev) for _ in range(2)]
-        g_recs = [torch.empty((world * R, 3), dtype=torch.float32, device=dev) for _ in range(2)]
+    if exchanging:
+        g_tiles = [torch.empty((world * R_max, tcols), dtype=torch.float32, device=dev) for _ in range(2)]
+        g_recs = [torch.empty((world * R_max, 3), dtype=torch.float32, device=dev) for _ in range(2)]
         comm_stream = torch.cuda.Stream(device=dev)
-        comm_done = [None, None]
-        gather = True
+        if a.exchange == "capi":
+            rccl = RcclComm(dist, world, rank)
+            stage = [torch.empty((R_max, max(tcols, 3)), dtype=torch.float32, device=dev) for _ in range(2)]
+
+    mode = {"now": a.gather if exchanging else "none", "note": None}
+
+    def exchange(out, inp, cols, b, which):
+        """one buffer (band tile or records) of this step: all-gather, or gather to rank 0.  `out` = world x R_max rows
+        as an equal-block all-gather leaves them (root mode on rank 0 with the C ABI: R_total rows, already in place)"""
+        cptr = comm_stream.cuda_stream
+        if a.exchange == "capi":
+            if mode["now"] == "all":
+                rc = L.ro_allgather_rows(rccl.comm, ctypes.c_void_p(inp.data_ptr()), R, R_total, world, rank, cols * 4,
+                                         ctypes.c_void_p(stage[which].data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                         ctypes.c_void_p(cptr))
+            else:
+                rc = L.ro_gather_rows(rccl.comm, ctypes.c_void_p(inp.data_ptr()), R, R_total, world, rank, 0, cols * 4,
+                                      ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(cptr))
+            if rc != 0:
+                raise RuntimeError("C-ABI exchange failed: %s" % L.ro_last_error())
+            return
+        send = sh.pad_block(inp, R_total, world) if c5 else inp
+        if a.comm == "nccl":
+            if mode["now"] == "root":
+                parts = list(out.view((world,) + tuple(send.shape)).unbind(0)) if rank == 0 else None
+                dist.gather(send, parts, dst=0)
+            else:
+                dist.all_gather_into_tensor(out, send)
+        else:                                                   # rehearsal: the same exchange through host memory
+            h_in = send.cpu()
+            h_out = torch.empty(out.shape, dtype=out.dtype)
+            if mode["now"] == "root":
+                parts = list(h_out.view((world,) + tuple(h_in.shape)).unbind(0)) if rank == 0 else None
+                dist.gather(h_in, parts, dst=0)
+            else:
+                dist.all_gather_into_tensor(h_out, h_in)
+            out.copy_(h_out)
 
     def step(i):
         b = i & 1
-        if gather:
-            if comm_done[b] is not None:
-                stream.wait_event(comm_done[b])            # tile buffer b is free again
-            st.run_resident(iq, ro.RO_IQ_F32, samples, 0, R, rows, d_tile=tiles[b], d_records=recs[b],
-                            stream=sptr)
-            if gather_used["mode"] == "none":
-                return
-            ready = torch.cuda.Event()
-            ready.record(stream)
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(ready)
-                all_gather(g_tiles[b], tiles[b])
-                all_gather(g_recs[b], recs[b])
-                ev = torch.cuda.Event()
-                ev.record(comm_stream)
-                comm_done[b] = ev
-        else:
-            st.run_resident(iq, ro.RO_IQ_F32, samples, 0, R, rows, d_records=recs[b], stream=sptr)
+        if comm_done[b] is not None:
+            stream.wait_event(comm_done[b])                 # tile buffer b is free again
+        st.run_resident(iq, ro.RO_IQ_F32, samples, 0, R, rows, d_tile=tiles[b] if tile else None, d_records=recs[b],
+                        stream=sptr)
+        if not exchanging or mode["now"] == "none":
+            return
+        ready = torch.cuda.Event()
+        ready.record(stream)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(ready)
+            exchange(g_tiles[b], tiles[b], tcols, b, 0)
+            exchange(g_recs[b], recs[b], 3, b, 1)
+            ev = torch.cuda.Event()
+            ev.record(comm_stream)
+            comm_done[b] = ev
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -323,6 +426,37 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev if a.comm == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def min_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev if a.comm == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t.item())
+
+    def usable(m):
+        """probe one way of ending a step OUTSIDE any timed region; every rank learns the same answer"""
+        keep = mode["now"]
+        mode["now"] = m
+        ok = 1.0
+        try:
+            step(0)
+            step(1)
+            torch.cuda.synchronize(dev)
+        except Exception as e:                                  # e.g. a backend without gather
+            ok = 0.0
+            mode["note"] = "%s refused by the backend (%s)" % (m, str(e)[:120])
+        if world > 1:
+            ok = min_over_ranks(ok)
+        mode["now"] = keep
+        return ok > 0.5
+
+    # the way a step ends is chosen ONCE, before anything is timed, and by all ranks together
+    if exchanging and mode["now"] == "root" and not usable("root"):
+        mode["now"] = "all"
+        mode["note"] = (mode["note"] or "") + ": all-gather instead"
     for i in range(a.prewarm + a.warmup):
         step(i)
     fence()
@@ -334,38 +468,50 @@ def main():
     ev_b.record(stream)
     fence()
     dt = time.perf_counter() - t0
-    gpu_ms_per_step = ev_a.elapsed_time(ev_b) / a.steps
-    def max_over_ranks(x):
-        t = torch.tensor([x], dtype=torch.float64, device=dev if a.comm == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
+    gpu_ms_per_step = ev_a.elapsed_time(ev_b) / a.steps       # HIP events on the launch stream, over the timed region
     if world > 1:
         dt = max_over_ranks(dt)
+
+    # ---- c5: what the job produced, stitched in row order on rank 0, hashed (N ranks == 1 rank, bit for bit)
+    c5_hash = None
+    if c5:
+        import hashlib
+        last = (a.steps - 1) & 1
+        if exchanging and mode["now"] != "none":
+            if a.exchange == "capi" and mode["now"] == "root":
+                t_all, r_all = g_tiles[last][:R_total], g_recs[last][:R_total]
+            else:
+                t_all, r_all = sh.stitch(g_tiles[last], R_total, world), sh.stitch(g_recs[last], R_total, world)
+        else:
+            t_all, r_all = tiles[last], recs[last]
+        if rank == 0 and (world == 1 or mode["now"] != "none"):
+            hh = hashlib.sha256()
+            hh.update(t_all.cpu().numpy().tobytes())
+            hh.update(r_all.cpu().numpy().tobytes())
+            c5_hash = hh.hexdigest()[:32]
 
     # ---- N > 1, OUTSIDE the timed region of `value`: the same K steps with the other ways of ending a step, so that
     # one run separates compute from exchange (all-gather as north_star words it, gather to rank 0, compute only)
     legs = None
     if world > 1 and a.gather != "none" and not a.no_legs:
-        main_mode = gather_used["mode"]
-        legs = {main_mode: R * world * a.steps / dt}
-        for mode in ("all", "root", "none"):
-            if mode in legs:
+        main_mode = mode["now"]
+        legs = {main_mode: R_total * a.steps / dt}
+        for m in ("all", "root", "none"):
+            if m in legs:
                 continue
-            gather_used["mode"] = mode
-            try:
-                for i in range(max(a.warmup, 2)):
-                    step(i)
-                fence()
-                t1 = time.perf_counter()
-                for i in range(a.steps):
-                    step(i)
-                fence()
-                if gather_used["mode"] == mode:                 # (a refused gather has fallen back: not a leg of its own)
-                    legs[mode] = R * world * a.steps / max_over_ranks(time.perf_counter() - t1)
-            except Exception as e:                              # never lose the main line to a side measurement
-                legs[mode] = "failed: %s" % str(e)[:100]
-        gather_used["mode"] = main_mode
+            if m != "none" and not usable(m):
+                legs[m] = "unavailable: %s" % mode["note"]
+                continue
+            mode["now"] = m
+            for i in range(max(a.warmup, 2)):
+                step(i)
+            fence()
+            t1 = time.perf_counter()
+            for i in range(a.steps):
+                step(i)
+            fence()
+            legs[m] = R_total * a.steps / max_over_ranks(time.perf_counter() - t1)
+        mode["now"] = main_mode
 
     # ---- kernel durations with HIP events on the launch stream (same launches as the timed loop)
     ms_all, k_stft, k_scan = st.time_resident(iq, ro.RO_IQ_F32, samples, 0, R, rows, max(a.steps, 5),
@@ -374,35 +520,58 @@ def main():
 
     out = None
     if rank == 0:
-        total_rows = R * world * a.steps
+        total_rows = R_total * a.steps
         value = total_rows / dt
-        achieved = ALG_BYTES_PER_ROW * R / (k_stft * 1e-3) / 1e9
+        fused = BINS == 32768 and world == 1                # one step = one kernel: scan and tile are its epilogue
+        # The dominant kernel's average launch duration: HIP events on the launch stream around the K launches of the
+        # TIMED region when a step is exactly that one kernel (bins = 32768: scan and tile are its epilogue); for the
+        # plans with a separate scan kernel the transform's own share comes from the event pairs of
+        # ro_stft_time_resident, taken right behind the timed region.
+        kernel_ms = gpu_ms_per_step if fused else k_stft
+        achieved = ALG_BYTES_PER_ROW * R / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "FFT rows/sec (spectra/sec), N=32768 75% overlap, incl. per-row bolid scan",
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "prewarm": a.prewarm,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if c5 else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: synthetic IQ 48 kHz, FFT bins=%d, overlap=%d (%d%%), "
+            "config": {"workload": ("C5: one synthetic IQ stream of %.0f s at 48 kHz (%d rows), FFT bins=%d, overlap=%d, "
+                                    "noise + a chirp every 30 s, split over the ranks by time chunk" %
+                                    (a.c5_seconds, R_total, BINS, OVERLAP)) if c5 else
+                                   "%s: synthetic IQ 48 kHz, FFT bins=%d, overlap=%d (%d%%), "
                                    "%s window, waterfall magnitude rows + BolidRecorder scan"
                                    % ("C3/C4" if (BINS, OVERLAP) == (32768, 24576) else
                                       "C2" if (BINS, OVERLAP) == (4096, 2048) else "custom", BINS, OVERLAP,
                                       round(100.0 * OVERLAP / BINS), a.window.capitalize()),
                        "rows_per_step_per_gpu": R, "samples_per_step_per_gpu": samples,
+                       "untimed_launches_before_the_timed_region": a.prewarm + a.warmup,
                        "input": "float32 I/Q resident in HBM", "output": "float32 rows in HBM",
-                       "parallelism": "time-chunk per GPU" + (("; %s of band tile [%d,+%d) + scan records per step, "
+                       "parallelism": "time-chunk per GPU" + (("; %s of band tile [%d,+%d) + scan records per step (%s), "
                                                                "overlapped with the next step"
-                                                               % (({"all": "all-gather", "root": "gather to rank 0"}[gather_used["mode"]],)
-                                                                  + tile)) if tile and gather_used["mode"] != "none" else
-                                                              ("; compute only (--gather none)" if tile else "")),
-                       **({"gather_note": gather_used["note"]} if gather_used["note"] else {}),
+                                                               % (({"all": "all-gather", "root": "gather to rank 0"}[mode["now"]],)
+                                                                  + tile + ("C ABI: ro_allgather_rows / ro_gather_rows"
+                                                                            if a.exchange == "capi" else
+                                                                            "torch.distributed",)))
+                                                              if exchanging and mode["now"] != "none" else
+                                                              ("; compute only (--gather none)" if exchanging else "")),
+                       **({"gather_note": mode["note"]} if mode["note"] else {}),
+                       **({"c5_hash_of_stitched_band_and_records": c5_hash} if c5_hash else {}),
                        **({"exchange_legs_rows_per_s": legs} if legs else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
+                         # the same bytes over the wall-clock step of the timed region (host gaps and exchange included)
+                         "frac_step": ALG_BYTES_PER_ROW * R / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
+                         # ... and over the event pairs of a separate loop of launches behind the timed region
+                         "frac_posthoc": ALG_BYTES_PER_ROW * R / (k_stft * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": a.pmc_traffic if a.pmc_traffic is not None else pmc_traffic(R),
                          "traffic_source": "--pmc-traffic" if a.pmc_traffic is not None else
                                            "newest profiles/r*_traffic.json (rocprofv3 --pmc passes of this command; "
                                            "counters cannot be read from inside the run)",
-                         "kernel": "stft_kernel<%d>" % BINS, "kernel_ms": k_stft,
+                         "kernel": ("stft32k_kernel" if BINS == 32768 else "stft_kernel<%d>" % BINS),
+                         "kernel_ms": kernel_ms,
+                         "kernel_ms_source": "HIP events on the launch stream around the %d launches of the timed region"
+                                             % a.steps if fused else "ro_stft_time_resident event pairs behind the timed region",
+                         "kernel_ms_posthoc": k_stft,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ROW * R,
                          "scan_kernel_ms": k_scan},
             "device": st.device_name,
@@ -453,10 +622,23 @@ def main():
                 ms64, k64, s64 = st64.time_resident(iq, ro.RO_IQ_F32, samples, 0, r64, rows, 5, d_records=recs[1],
                                                     stream=sptr)
                 torch.cuda.synchronize(dev)
+                ms_strict = float(np.mean(ms64[1:]))
+                # traffic model of the two-trip form at bins = 32768: trip 1 reads the row's samples
+                # (8 B per point, overlap re-reads from L2) and writes complex doubles (16 B); trip 2 reads them
+                # (16 B) and writes the float row (4 B): 44 B per point against 6 B algorithmic
+                model = 44.0 * BINS
                 entry = {"mode": "RO_PRECISION_F64 (double window multiply, double transform in two trips through HBM "
                                  "scratch, double sqrt, one narrowing: the reference's arithmetic type)",
-                         "value": r64 / (float(np.mean(ms64[1:])) * 1e-3), "unit": "rows/s", "rows_per_step": r64,
-                         "ms_per_step": float(np.mean(ms64[1:])), "dtype": "f64"}
+                         "value": r64 / (ms_strict * 1e-3), "unit": "rows/s", "rows_per_step": r64,
+                         "ms_per_step": ms_strict, "dtype": "f64",
+                         "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                      "achieved": ALG_BYTES_PER_ROW * r64 / (ms_strict * 1e-3) / 1e9,
+                                      "frac": ALG_BYTES_PER_ROW * r64 / (ms_strict * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "kernel": "f64_pair_kernel (two launches per step) + scan_kernel",
+                                      "traffic_model_bytes_per_row": model,
+                                      "traffic_model_GBs": model * r64 / (ms_strict * 1e-3) / 1e9,
+                                      "traffic_model_frac_of_peak": model * r64 / (ms_strict * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "traffic": None}}
                 if not a.no_parity:
                     sys.path.insert(0, os.path.join(ROOT, "oracle"))
                     import ro_oracle as O
@@ -469,6 +651,15 @@ def main():
                     entry["parity"] = {"rows_checked": [0, r64 - 1], "max_err_per_bin_relative": worst,
                                        "tolerance_per_bin": 1e-5}
             out["strict_precision"] = entry
+
+        # ---- the drop-in path at full speed (never the headline): Frontend::process -> HipWaterfallBackend::process
+        # with 4096-sample vector<Complex> calls (src/RawStream.cpp:44-66) -> kernels -> full rows back to the host row
+        # ring -> BolidRecorder::update per row; PCIe both ways included, handle creation and warm-up calls excluded
+        if world == 1 and not a.no_streaming and not c5:
+            out["streaming"] = streaming_leg(a.stream_seconds, 0)
+            # (the Backend's own default bounds a batch by latency -- one second of rows = 6; the same path with 256 rows
+            # per launch, what a file replay would ask for through WaterfallConfig::max_batch_rows)
+            out["streaming_batch256"] = streaming_leg(a.stream_seconds, 256)
 
         # ---- CPU baseline (rank 0, N=1 only): the oracle port on the host cores of this box.  Its FP64 transform runs
         # on libfftw3 itself (fftw_plan_dft_1d(..., FFTW_FORWARD, FFTW_ESTIMATE) + fftw_execute, the reference's call
@@ -509,9 +700,9 @@ def main():
             O.use_fftw(False)
             # the reference is built -O0 (Makefile:26-28): the same port compiled that way, radix-2 transform
             try:
-                subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libro_oracle_O0.so"],
-                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-                O0 = oracle_module(os.path.join(ROOT, "oracle", "libro_oracle_O0.so"))
+                if not os.path.exists(o0_lib):                   # (built before the first HIP call, or by build())
+                    raise RuntimeError(o0_err or "oracle/libro_oracle_O0.so is missing")
+                O0 = oracle_module(o0_lib)
                 done0, cdt0 = cpu_baseline(host, st.window, bands, min(4.0, a.cpu_seconds / 3), O0)
                 out["cpu_baseline_O0"] = {"value": done0 / cdt0, "unit": "rows/s", "cores": 1, "kind": "port",
                                           "fft_engine": "port",

@@ -194,7 +194,10 @@ int ro_stft_set_bands(ro_stft_t *h, const ro_bands_t *bands);
  *               [tile_first_col, +tile_cols) of d_rows), or NULL
  *   d_records   device, rows records, or NULL (needs enable_scan)
  *   stream      hipStream_t as void* (NULL = the default stream, with its usual ordering rules)
- * The call is asynchronous on `stream`. */
+ * The call is asynchronous on `stream`.  One handle = one stream: the handle owns scratch that some paths use
+ * (bins > 131072, chirp-z lengths, RO_PRECISION_F64, tile_ln), so two launches of ONE handle may only be in flight
+ * together when they are ordered on one stream -- like FFTBackend::process, which one thread calls at a time
+ * (src/JackFrontend.cpp:19-22 only logs a re-entry).  Use one handle per concurrent stream. */
 int ro_stft_run_resident(ro_stft_t *h, const void *d_iq, int format, int64_t samples,
                          int64_t first_row, int64_t rows,
                          float *d_rows, int64_t row_stride,

@@ -18,6 +18,7 @@
 #include <ctime>
 #include <deque>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/ro_stft.h"
@@ -373,9 +374,12 @@ int launch_tile_and_scan(ro_stft *h, const float *d_rows, int64_t row_stride, in
 int ensure_ln_part(ro_stft *h, int64_t rows)
 {
     if (rows <= h->ln_part_rows) return RO_OK;
+    // sized generously the first time (16 bytes per row) and doubled after that, so that the device-wide wait a
+    // regrow needs -- an earlier launch may still be writing the old block -- happens at most a few times per handle
+    int64_t want = std::max<int64_t>(rows, std::max<int64_t>(65536, 2 * h->ln_part_rows));
     if (h->d_ln_part) { (void)hipDeviceSynchronize(); (void)hipFree(h->d_ln_part); h->d_ln_part = nullptr; h->ln_part_rows = 0; }
-    HIP_TRY(hipMalloc(&h->d_ln_part, (size_t)rows * 4 * sizeof(float)));
-    h->ln_part_rows = rows;
+    HIP_TRY(hipMalloc(&h->d_ln_part, (size_t)want * 4 * sizeof(float)));
+    h->ln_part_rows = want;
     return RO_OK;
 }
 
@@ -703,6 +707,24 @@ int ensure_stream_slots(ro_stft *h)
 
 size_t stage_sample_bytes(const ro_stft *h) { return h->stage_fmt == RO_IQ_I16 ? 4 : 8; }
 
+// The one place the host waits for the GPU on the streaming path: a batch's download has finished.  Its kernel time
+// (GPU events around its kernels) goes into the counters of ro_stft_timing / ro_stft_stats the first time round.
+int await_batch(ro_stft *h, Batch *b)
+{
+    if (!b->pending) return RO_OK;
+    HIP_TRY(hipEventSynchronize(b->done));
+    b->pending = false;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, b->k0, b->k1) == hipSuccess) {
+        h->stat_kernel_ms += ms;
+        h->timing.batches += 1;
+        h->timing.batch_rows += b->rows;
+        h->batch_ms_sum += ms;
+        h->timing.batch_gpu_ms_max = std::max(h->timing.batch_gpu_ms_max, (double)ms);
+    }
+    return RO_OK;
+}
+
 // run one batch of the streaming path: rows [rows_emitted, +rows) from the staged samples.  Upload, kernels and
 // download are queued on three streams chained by events and the call returns; the host only waits when it is about
 // to overwrite a pinned staging buffer whose upload has not finished.
@@ -715,6 +737,14 @@ int run_stream_batch(ro_stft *h, int64_t rows)
     ro_stft::Slot &sl = h->slot[h->batch_seq & 1];
     HIP_TRY(hipEventSynchronize(sl.uploaded));                          // the upload two batches ago is done
     std::memcpy(sl.h_in, h->staged.data() + h->staged_begin * sb, (size_t)need * sb);
+    // Back-pressure: one large ro_stft_push must not queue a pinned batch per launch without bound (64 MiB each with
+    // full rows).  Batches older than the newest MAX_IN_FLIGHT are waited for here -- they stay in `ready` for the
+    // next fetch, their buffers are simply known to be complete.
+    constexpr size_t MAX_IN_FLIGHT = 4;
+    if (h->ready.size() >= MAX_IN_FLIGHT) {
+        const int wrc = await_batch(h, h->ready[h->ready.size() - MAX_IN_FLIGHT]);
+        if (wrc != RO_OK) return wrc;
+    }
     Batch *b = acquire_batch(h);
     if (!b) return fail(RO_ERR_NOMEM, "out of pinned host memory for a row batch");
     int rc = RO_OK;
@@ -914,7 +944,36 @@ extern "C" int ro_stitch_rows(const void *gathered, int64_t total_rows, int worl
     return RO_OK;
 }
 
-// the all-gather itself: RCCL, resolved at run time so that the library has no link-time dependency on it
+// RCCL, resolved at run time so that the library has no link-time dependency on it: one dlopen / dlsym per process,
+// under std::call_once (several host threads may drive their own handles and communicators)
+namespace {
+struct Rccl {
+    int (*all_gather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*group_start)(void) = nullptr;
+    int (*group_end)(void) = nullptr;
+    int (*send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+};
+const Rccl &rccl_api()
+{
+    static Rccl api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return;
+        api.all_gather = reinterpret_cast<decltype(api.all_gather)>(dlsym(lib, "ncclAllGather"));
+        api.group_start = reinterpret_cast<decltype(api.group_start)>(dlsym(lib, "ncclGroupStart"));
+        api.group_end = reinterpret_cast<decltype(api.group_end)>(dlsym(lib, "ncclGroupEnd"));
+        api.send = reinterpret_cast<decltype(api.send)>(dlsym(lib, "ncclSend"));
+        api.recv = reinterpret_cast<decltype(api.recv)>(dlsym(lib, "ncclRecv"));
+    });
+    return api;
+}
+}  // namespace
+
+// the all-gather itself
 extern "C" int ro_allgather_rows(void *nccl_comm, const void *d_local, int64_t local_rows, int64_t total_rows, int world,
                                  int rank, size_t row_bytes, void *d_staging, void *d_gathered, void *stream)
 {
@@ -926,22 +985,15 @@ extern "C" int ro_allgather_rows(void *nccl_comm, const void *d_local, int64_t l
     if (local_rows != mine)
         return fail(RO_ERR_INVALID, "ro_allgather_rows: rank %d of %d owns %lld of %lld rows, not %lld", rank, world,
                     (long long)mine, (long long)total_rows, (long long)local_rows);
-    typedef int (*allgather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
-    static allgather_fn all_gather = nullptr;
-    if (!all_gather) {
-        void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        all_gather = lib ? (allgather_fn)dlsym(lib, "ncclAllGather") : nullptr;
-        if (!all_gather) return fail(RO_ERR_UNSUPPORTED, "librccl (ncclAllGather) not found on this host");
-    }
+    const Rccl &rccl = rccl_api();
+    if (!rccl.all_gather) return fail(RO_ERR_UNSUPPORTED, "librccl (ncclAllGather) not found on this host");
     hipStream_t s = (hipStream_t)stream;
     const int64_t block = ro_shard_max_rows(total_rows, world);
     if (block == 0) return RO_OK;
     const size_t used = (size_t)local_rows * row_bytes, whole = (size_t)block * row_bytes;
     if (used) HIP_TRY(hipMemcpyAsync(d_staging, d_local, used, hipMemcpyDeviceToDevice, s));
     if (whole > used) HIP_TRY(hipMemsetAsync(static_cast<char *>(d_staging) + used, 0, whole - used, s));
-    const int rc = all_gather(d_staging, d_gathered, whole, /*ncclInt8*/ 0, nccl_comm, s);
+    const int rc = rccl.all_gather(d_staging, d_gathered, whole, /*ncclInt8*/ 0, nccl_comm, s);
     if (rc != 0) return fail(RO_ERR_HIP, "ncclAllGather failed with code %d", rc);
     return RO_OK;
 }
@@ -958,27 +1010,12 @@ extern "C" int ro_gather_rows(void *nccl_comm, const void *d_local, int64_t loca
     if (local_rows != mine)
         return fail(RO_ERR_INVALID, "ro_gather_rows: rank %d of %d owns %lld of %lld rows, not %lld", rank, world,
                     (long long)mine, (long long)total_rows, (long long)local_rows);
-    typedef int (*group_fn)(void);
-    typedef int (*send_fn)(const void *, size_t, int, int, void *, hipStream_t);
-    typedef int (*recv_fn)(void *, size_t, int, int, void *, hipStream_t);
-    static group_fn group_start = nullptr, group_end = nullptr;
-    static send_fn send = nullptr;
-    static recv_fn recv = nullptr;
-    if (!recv) {
-        void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (lib) {
-            group_start = (group_fn)dlsym(lib, "ncclGroupStart");
-            group_end = (group_fn)dlsym(lib, "ncclGroupEnd");
-            send = (send_fn)dlsym(lib, "ncclSend");
-            recv = (recv_fn)dlsym(lib, "ncclRecv");
-        }
-        if (!group_start || !group_end || !send || !recv) {
-            recv = nullptr;
-            return fail(RO_ERR_UNSUPPORTED, "librccl (ncclSend / ncclRecv) not found on this host");
-        }
-    }
+    const Rccl &rccl = rccl_api();
+    if (!rccl.group_start || !rccl.group_end || !rccl.send || !rccl.recv)
+        return fail(RO_ERR_UNSUPPORTED, "librccl (ncclSend / ncclRecv) not found on this host");
+    const auto group_start = rccl.group_start, group_end = rccl.group_end;
+    const auto send = rccl.send;
+    const auto recv = rccl.recv;
     hipStream_t s = (hipStream_t)stream;
     if (rank == root && mine > 0)           // the root's own rows: a copy
         HIP_TRY(hipMemcpyAsync(static_cast<char *>(d_out) + (size_t)first * row_bytes, d_local, (size_t)mine * row_bytes,
@@ -1624,18 +1661,7 @@ extern "C" int ro_stft_fetch(ro_stft_t *h, int64_t max_rows, int first_col, int 
         *first_row_index = h->ready.front()->first_row + h->ready.front()->consumed;
     while (got < max_rows && !h->ready.empty()) {
         Batch *b = h->ready.front();
-        if (b->pending) {                                   // the only place the host waits for the GPU
-            HIP_TRY(hipEventSynchronize(b->done));
-            b->pending = false;
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, b->k0, b->k1) == hipSuccess) {
-                h->stat_kernel_ms += ms;
-                h->timing.batches += 1;
-                h->timing.batch_rows += b->rows;
-                h->batch_ms_sum += ms;
-                h->timing.batch_gpu_ms_max = std::max(h->timing.batch_gpu_ms_max, (double)ms);
-            }
-        }
+        { const int rc = await_batch(h, b); if (rc != RO_OK) return rc; }
         const int64_t take = std::min(max_rows - got, b->rows - b->consumed);
         for (int64_t r = 0; r < take; ++r) {
             const float *src = b->data + (size_t)(b->consumed + r) * h->out_cols + (first_col - h->out_first);
@@ -1665,6 +1691,7 @@ extern "C" int ro_stft_fetch_ln(ro_stft_t *h, int64_t max_rows, float *tile_out,
     if (!h->cfg.tile_ln) return fail(RO_ERR_STATE, "this handle was not created with tile_ln");
     if (max_rows < 0) return fail(RO_ERR_INVALID, "negative max_rows");
     if (records_out && !h->cfg.enable_scan) return fail(RO_ERR_STATE, "scan records requested but scan is off");
+    const double t0 = now_ms();
     int64_t got = 0;
     if (first_row_index) *first_row_index = h->rows_emitted;
     if (first_row_index && !h->ready.empty())
@@ -1672,10 +1699,7 @@ extern "C" int ro_stft_fetch_ln(ro_stft_t *h, int64_t max_rows, float *tile_out,
     const size_t w = (size_t)h->out_cols;
     while (got < max_rows && !h->ready.empty()) {
         Batch *b = h->ready.front();
-        if (b->pending) {
-            HIP_TRY(hipEventSynchronize(b->done));
-            b->pending = false;
-        }
+        { const int rc = await_batch(h, b); if (rc != RO_OK) return rc; }
         const int64_t take = std::min(max_rows - got, b->rows - b->consumed);
         const size_t at = (size_t)b->consumed;
         if (tile_out) std::memcpy(tile_out + (size_t)got * w, b->data + at * w, sizeof(float) * w * (size_t)take);
@@ -1691,6 +1715,10 @@ extern "C" int ro_stft_fetch_ln(ro_stft_t *h, int64_t max_rows, float *tile_out,
     }
     h->rows_ready -= got;
     *rows_got = got;
+    const double dt = now_ms() - t0;
+    h->timing.fetch_calls += 1;
+    h->fetch_ms_sum += dt;
+    h->timing.fetch_ms_max = std::max(h->timing.fetch_ms_max, dt);
     return RO_OK;
 }
 

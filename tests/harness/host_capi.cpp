@@ -1,7 +1,10 @@
 // host_capi.cpp -- plain-C harness over the product's host-side C++ objects (radio-observer_amd/host/, linked as
 // libro_host.so), for the ctypes tests (tests/test_ring.py, tests/test_host_cpu.py, tests/test_gpu_host_pipeline.py)
 // and bench.py's streaming leg.  Test infrastructure: not part of the product, not in its libraries.
+#include <cmath>
+#include <cstdint>
 #include <cstring>
+#include <ctime>
 #include <vector>
 
 #include <sstream>
@@ -438,6 +441,75 @@ int64_t ro_host_bolid_replay(int bins, int overlap, int sample_rate, float lo_de
     const int64_t m = std::min<int64_t>((int64_t)ev.size(), max);
     for (int64_t i = 0; i < m; ++i) out[i] = ev[(size_t)i];
     return (int64_t)ev.size();
+}
+
+// ---- bench.py's streaming leg: the drop-in path at full speed.  Frontend::process -> HipWaterfallBackend::process
+// (ro_stft_push of RO_IQ_F64 into pinned staging, kernels, ro_stft_fetch of full rows) -> Recorder::update per row,
+// driven exactly as src/RawStream.cpp:44-66 drives the reference: `block` samples of vector<Complex> per call.
+// Handle creation (startStream) and the first `warm_calls` calls are outside the timed region; the region ends
+// behind endStream, when every row has been through BolidRecorder::update.
+// stats: [0] seconds  [1] samples  [2] rows delivered  [3] process() calls  [4] rows per kernel launch
+//        [5] mean ms per process() call  [6] max ms per process() call  [7] events fired
+int ro_host_stream_bench(int bins, int overlap, int sample_rate, int block, double seconds, int max_batch_rows,
+                         int warm_calls, double *stats)
+{
+    if (bins <= 0 || block <= 0 || seconds <= 0 || !stats) return -1;
+    WaterfallConfig w;
+    w.bins = bins;
+    w.overlap = overlap;
+    w.max_batch_rows = max_batch_rows;
+    w.metadata_path = "";
+    BolidConfig b;                                   // radio-observer.json:62-87
+    b.snapshot_length = 60;
+    b.low_detect_freq = 10300; b.hi_detect_freq = 10900; b.low_noise_freq = 9000; b.hi_noise_freq = 9600;
+    b.advance_time = 2; b.jitter_time = 5; b.avg_freq_range = 40;
+    b.write_files = false;
+    HipWaterfallBackend backend(w);
+    BolidRecorder bolid(&backend, b);
+    backend.addRecorder(&bolid);
+    FrontendDriver frontend(&backend);
+    // a few different blocks of sigma = 1 noise (the content does not change the work)
+    const int NBLK = 16;
+    std::vector<std::vector<Complex>> blocks((size_t)NBLK, std::vector<Complex>((size_t)block));
+    uint64_t lcg = 0x9E3779B97F4A7C15ull;
+    auto uni = [&]() { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return (double)(lcg >> 11) * (1.0 / 9007199254740992.0); };
+    for (auto &blk : blocks)
+        for (auto &c : blk) {
+            const double u1 = uni() + 1e-300, u2 = uni();
+            const double r = std::sqrt(-2.0 * std::log(u1));
+            c.real = (float)(r * std::cos(6.283185307179586 * u2));
+            c.imag = (float)(r * std::sin(6.283185307179586 * u2));
+        }
+    StreamInfo si;
+    si.sampleRate = sample_rate;
+    frontend.startStream(si);
+    if (!backend.lastError().empty()) return -2;
+    int64_t calls = 0;
+    for (int i = 0; i < warm_calls; ++i) frontend.process(blocks[(size_t)(calls++ % NBLK)]);
+    const int64_t rows0 = backend.rowsDelivered();
+    auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
+    const double t0 = now();
+    double worst = 0.0;
+    int64_t timed = 0;
+    for (;;) {
+        const double a = now();
+        frontend.process(blocks[(size_t)(calls++ % NBLK)]);
+        const double d = now() - a;
+        worst = d > worst ? d : worst;
+        ++timed;
+        if (a + d - t0 >= seconds) break;
+    }
+    frontend.endStream();
+    const double dt = now() - t0;
+    stats[0] = dt;
+    stats[1] = (double)timed * (double)block;
+    stats[2] = (double)(backend.rowsDelivered() - rows0);
+    stats[3] = (double)timed;
+    stats[4] = (double)backend.batchRows();
+    stats[5] = 1e3 * dt / (double)timed;
+    stats[6] = 1e3 * worst;
+    stats[7] = (double)bolid.events().size();
+    return backend.lastError().empty() ? 0 : -3;
 }
 
 }  // extern "C"

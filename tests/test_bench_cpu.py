@@ -11,8 +11,25 @@ def test_bench_flags():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True,
                        timeout=120)
     assert r.returncode == 0
-    for flag in ("--gpus", "--steps", "--warmup", "--gather", "--rows", "--bins", "--overlap"):
+    for flag in ("--gpus", "--steps", "--warmup", "--prewarm", "--gather", "--exchange", "--workload", "--c5-seconds",
+                 "--rows", "--bins", "--overlap", "--no-streaming", "--stream-seconds"):
         assert flag in r.stdout, flag
+    # the all-gather north_star names is what ends a step inside the timed region unless asked otherwise
+    assert "all (default)" in " ".join(r.stdout.split())
+
+
+def test_bench_capi_exchange_needs_one_gpu_per_rank():
+    """--exchange capi with the two-ranks-on-one-GPU rehearsal transport is refused before anything is measured"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "--exchange capi needs one GPU per rank" in src
+
+
+def test_bench_builds_nothing_after_the_first_hip_call():
+    """the -O0 oracle twin is made before `import torch` (a fork + exec from a process that holds the GPU is a hazard)"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    assert main.index("libro_oracle_O0.so") < main.index("import torch")
+    assert main.count("subprocess.check_call") == 1
 
 
 def test_bench_refuses_to_run_without_a_device():
