@@ -24,7 +24,7 @@ for f in glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")):
 # idle to reach its steady clocks, so the --stats average over ALL launches sits above the steady-state figure
 for f in glob.glob(os.path.join(d, "trace", "*", "*_kernel_trace.csv")):
     dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(f))
-           if "stft_kernel" in r["Kernel_Name"]]
+           if "stft_kernel" in r["Kernel_Name"] or "stft32k_kernel" in r["Kernel_Name"]]
     if dur:
         n = len(dur)
         k = (n - 55) // 2 if n > 70 else n // 2
@@ -44,7 +44,7 @@ cal = {}
 for c, known in (("FETCH_SIZE", 32768 * 8192 * 8), ("WRITE_SIZE", 32768 * 8192 * 4)):
     acc = counters("calib_" + c)
     for k, v in acc.items():
-        if "stft_kernel" in k and c in v:
+        if ("stft_kernel" in k or "stft32k_kernel" in k) and c in v:
             rep = sum(v[c]) / len(v[c]) * 1024.0
             cal[c] = known / rep
             print("  %s: reported %.4g B per launch, known %.4g B  -> multiply the counter by %.3f" % (c, rep, known, cal[c]))
@@ -63,7 +63,7 @@ for k in sorted(acc):
     for c in sorted(acc[k]):
         v = acc[k][c]
         print("     %-26s n=%3d mean=%.6g" % (c, len(v), sum(v) / len(v)))
-    if "stft_kernel" in k and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
+    if ("stft_kernel" in k or "stft32k_kernel" in k) and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
         f = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"]) * 1024.0
         w = sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"]) * 1024.0
         fc, wc = f * cal.get("FETCH_SIZE", 1.0), w * cal.get("WRITE_SIZE", 1.0)

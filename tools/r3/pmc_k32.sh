@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_${1:-k32}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-SHORT="python3 $ROOT/bench.py --steps 3 --warmup 1 --prewarm 2 --no-cpu-baseline --no-parity --no-strict"
+SHORT="python3 $ROOT/bench.py --steps 3 --warmup 1 --prewarm 2 --no-cpu-baseline --no-parity --no-strict --no-streaming"
 i=0
 for C in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQC_ICACHE_BUSY_CYCLES SQ_IFETCH SQ_IFETCH_LEVEL SQ_BUSY_CYCLES" \
          "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" \
