@@ -1,10 +1,10 @@
 #!/bin/bash
 # GPU box: package power, clocks and temperature sampled once a second while bench.py runs back-to-back launches of
-# the headline kernel for ~12 s (and idle before / after).  usage: tools/r3/power_run.sh > out.txt
+# the headline kernel for ~12 s (and idle before / after).  usage: [POWER_ARGS="--bins 4096 --overlap 2048 --rows 65536" POWER_STEPS=24000] tools/r3/power_run.sh > out.txt
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 smi() { rocm-smi --showpower --showclocks --showtemp 2>/dev/null | grep -E "Power|sclk|mclk|fclk|junction" | tr -s ' ' | tr '\n' ';'; echo; }
 echo "idle before: $(smi)"
-python3 $ROOT/bench.py --steps 12000 --warmup 5 --prewarm 5 --no-cpu-baseline --no-strict --no-streaming --no-parity > /tmp/power_bench.json 2>/dev/null &
+python3 $ROOT/bench.py $POWER_ARGS --steps ${POWER_STEPS:-12000} --warmup 5 --prewarm 5 --no-cpu-baseline --no-strict --no-streaming --no-parity > /tmp/power_bench.json 2>/dev/null &
 BP=$!
 sleep 4
 for i in 1 2 3 4 5 6; do echo "under load $i: $(smi)"; sleep 1; done
