@@ -162,6 +162,8 @@ bool       stft_window_layout(int bins, const float *w, float *out);   // host: 
 hipError_t launch_stft(int bins, int fmt, const StftArgs &a, hipStream_t s);
 // the N = 32768 magnitude-row kernel with the fused scan / tile epilogue (ro_stft32k.hip); launch_stft routes to it
 hipError_t launch_stft32k(int fmt, const StftArgs &a, hipStream_t s);
+// (diagnostic builds only: tools/r3/ro_stft_wl.hip, the same structure at N = 16384 / 8192)
+hipError_t launch_stft_wl(int bins, int fmt, const StftArgs &a, hipStream_t s);
 hipError_t launch_scan(const ScanArgs &a, hipStream_t s);
 hipError_t launch_tile(const TileArgs &a, hipStream_t s);
 hipError_t launch_ln_tile(const LnArgs &a, hipStream_t s);

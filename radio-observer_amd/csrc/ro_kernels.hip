@@ -31,8 +31,22 @@
 #define RO_STAMPS 0
 #endif
 #define RO_DIAG_KNOBS 1
+// the round-3 experiment tools/r3/ro_stft_wl.hip (stft32k_kernel's structure at N = 16384 / 8192; tools/r3/ab_wl_build.sh
+// adds it to the build): correct, and no faster than this file's generic loop (profiles/r03_ab_wl.txt)
+#ifndef RO_USE_WL
+#define RO_USE_WL 0
+#endif
+#ifndef RO_WL_FUSE16
+#define RO_WL_FUSE16 1
+#endif
+#ifndef RO_WL_FUSE8
+#define RO_WL_FUSE8 0
+#endif
 #else
 #define RO_STAMPS 0
+#define RO_USE_WL 0
+#define RO_WL_FUSE16 0
+#define RO_WL_FUSE8 0
 #endif
 
 namespace ro {
@@ -117,125 +131,6 @@ template <class PL> __host__ __device__ constexpr int plan_pair_off(int tid)
 // ---------------------------------------------------------------------------
 // stage helpers (all indices compile-time after unrolling -> v[] stays in VGPRs)
 // ---------------------------------------------------------------------------
-template <int P, int R> __device__ __forceinline__ void butterflies(v2f (&v)[P])
-{
-#pragma unroll
-    for (int b = 0; b < P / R; ++b) {
-        dit<R>(&v[b * R]);
-    }
-}
-
-__device__ __forceinline__ v2f tw_load(__amdgpu_buffer_rsrc_t tw, int koff, int entry)
-{
-    return buf_load_f2(tw, koff, entry * 8);
-}
-
-// Stage twiddles.  A radix-R stage needs w^r, r = 1..R-1, per butterfly, w = exp(-2 pi i k / (NS R)) depending on
-// the thread.  Radix <= 8 loads them all (8-byte loads from the generic table).  Radix 16 / 32 load a few powers
-// from the packed table (three 16-byte loads) and get the rest by multiplication -- radix 32 needs only
-// w, w^2, w^4, w^8, w^16 (fdit32), radix 16 holds w, w^2, w^3, w^4, w^8, w^12 and composes w^(4m+c).  At most two
-// extra roundings (~1e-7) on top of the table's correctly rounded entries.  The loads are split from their use so
-// that they are issued BEFORE the LDS exchange of the stage and land while the workgroup sits in its barriers.
-constexpr int TW_SET = 7;     // twiddles held per butterfly: R=32: 5, R=16: 6, R<=8: R-1
-
-// C8 (radix 8 only): load w, w^2, w^4 and let tw_apply make the other four by multiplication -- 6 registers held per
-// butterfly across the exchange instead of 14 (the N = 8192 add-TID plan has four radix-8 butterflies per thread)
-template <int P, int T, int R, int NS, int OFF, int PK, bool C8 = false>
-__device__ __forceinline__ void tw_prefetch(v2f (&t)[P / R][TW_SET], __amdgpu_buffer_rsrc_t tw,
-                                            __amdgpu_buffer_rsrc_t twk, int tid)
-{
-    static_assert(R == 32 || R == 16 || R <= 8, "unsupported radix");
-#pragma unroll
-    for (int b = 0; b < P / R; ++b) {
-        const int koff = ((tid + T * b) & (NS - 1)) * 8;
-        if constexpr (R >= 16) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(twk, koff * 2, (PK + q * NS) * 16, 0);
-                const v2f lo = (v2f){__uint_as_float(u.x), __uint_as_float(u.y)};
-                const v2f hi = (v2f){__uint_as_float(u.z), __uint_as_float(u.w)};
-                // radix 32: t = {w, w^2, w^4, w^8, w^16}; radix 16: t = {w, w^2, w^3, w^4, w^8, w^12}
-                if (q == 0) { t[b][0] = lo; t[b][1] = hi; }
-                else if (q == 1) { t[b][2] = lo; t[b][3] = hi; }
-                else { t[b][4] = lo; if constexpr (R == 16) t[b][5] = hi; }
-            }
-        } else if constexpr (C8 && R == 8) {
-            t[b][0] = tw_load(tw, koff, OFF);
-            t[b][1] = tw_load(tw, koff, OFF + NS);
-            t[b][3] = tw_load(tw, koff, OFF + 3 * NS);
-        } else {
-#pragma unroll
-            for (int r = 1; r < R; ++r) t[b][r - 1] = tw_load(tw, koff, OFF + (r - 1) * NS);
-        }
-    }
-}
-
-// stage twiddles applied up front: x[r] *= w^r, all R-1 powers held (radix <= 8; larger radices go through
-// tw_butterflies' fused forms)
-template <int P, int R, bool C8 = false>
-__device__ __forceinline__ void tw_apply(v2f (&v)[P], const v2f (&t)[P / R][TW_SET])
-{
-#pragma unroll
-    for (int b = 0; b < P / R; ++b) {
-        v2f *x = &v[b * R];
-        if constexpr (C8 && R == 8) {
-            const v2f w1 = t[b][0], w2 = t[b][1], w4 = t[b][3], w3 = cmul(w1, w2);
-            x[1] = cmul(x[1], w1);
-            x[2] = cmul(x[2], w2);
-            x[3] = cmul(x[3], w3);
-            x[4] = cmul(x[4], w4);
-            x[5] = cmul(x[5], cmul(w4, w1));
-            x[6] = cmul(x[6], cmul(w4, w2));
-            x[7] = cmul(x[7], cmul(w4, w3));
-            continue;
-        }
-#pragma unroll
-        for (int r = 1; r < R; ++r) x[r] = cmul(x[r], t[b][R <= 8 ? r - 1 : r % 5]);
-    }
-}
-
-// Twiddles and butterflies of one stage.  Radix 32: the twiddles are factored through the levels (fdit32 in
-// ro_fft_device.h).  Radix 16 fuses them into the first level:
-//   A = x[r] w^r (two ops),  a' = A + x[r+R/2] w^(r+R/2) (two FMAs),  b' = 2A - a' (one)
-// five issue slots per pair where twiddling both and then adding / subtracting takes six.
-template <int P, int R, bool C8 = false>
-__device__ __forceinline__ void tw_butterflies(v2f (&v)[P], const v2f (&t)[P / R][TW_SET])
-{
-    if constexpr (R >= 16) {
-#pragma unroll
-        for (int b = 0; b < P / R; ++b) {
-            v2f *x = &v[b * R];
-            constexpr int H = R / 2;
-            // radix 16: w^r for r = 4m + c (c, m in 0..3) from the held set t = {w, w^2, w^3, w^4, w^8, w^12}
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int r = 4 * m + c;
-                    if constexpr (R == 32) {
-                        continue;                                   // handled below (fdit32)
-                    } else {
-                        // R == 16: pairs (r, 8 + r) for r < 8; r >= 8 is the partner's twiddle w^(8+r')
-                        if (r >= H) continue;
-                        const v2f wlo = (r == 0) ? (v2f){1.0f, 0.0f}
-                                        : (m == 0) ? t[b][c - 1] : (c == 0) ? t[b][2 + m] : cmul(t[b][2 + m], t[b][c - 1]);
-                        const int rh = r + H, mh = rh / 4, ch = rh % 4;
-                        const v2f whi = (ch == 0) ? t[b][2 + mh] : cmul(t[b][2 + mh], t[b][ch - 1]);
-                        const v2f A = (r == 0) ? x[0] : cmul(x[r], wlo);
-                        const v2f s = cmadd(x[rh], whi, A);
-                        x[rh] = __builtin_elementwise_fma(A, (v2f){2.0f, 2.0f}, -s);
-                        x[r] = s;
-                    }
-                }
-            }
-            if constexpr (R == 32) fdit32(x, t[b][4], t[b][3], t[b][2], t[b][1], t[b][0]);
-            else dit_after_first_level<R>(x);
-        }
-    } else {
-        tw_apply<P, R, C8>(v, t);
-        butterflies<P, R>(v);
-    }
-}
 
 // autosort scatter of a finished stage (R, NS) into LDS (element index, padded).
 // The padded index i + (i>>5) is affine in r when r*NS never carries into bit 5 on
@@ -1442,6 +1337,11 @@ template <class PL> static hipError_t launch_fmt(const StftArgs &a, int fmt, hip
         if (fmt == RO_FMT_F32) return launch_plan<PL, RO_FMT_F32, 1>(a, s);
         if (fmt == RO_FMT_I16) return launch_plan<PL, RO_FMT_I16, 1>(a, s);
     } else {
+#if RO_USE_WL
+        if constexpr (PL::N == 16384 || PL::N == 8192) {
+            if (!spec) return launch_stft_wl(PL::N, fmt, a, s);    // magnitude rows: ro_stft_wl.hip
+        }
+#endif
         if (fmt == RO_FMT_F32) return spec ? launch_plan<PL, RO_FMT_F32, 1>(a, s) : launch_plan<PL, RO_FMT_F32, 0>(a, s);
         if (fmt == RO_FMT_I16) return spec ? launch_plan<PL, RO_FMT_I16, 1>(a, s) : launch_plan<PL, RO_FMT_I16, 0>(a, s);
     }
@@ -1450,7 +1350,11 @@ template <class PL> static hipError_t launch_fmt(const StftArgs &a, int fmt, hip
 
 bool stft_fuses_scan(int bins)
 {
-    return bins == 32768;               // stft32k_kernel (ro_stft32k.hip)
+    // ro_stft32k.hip, ro_stft_wl.hip.  (The scan costs the same few thousand cycles of ONE wave whatever the row length:
+    // a sixteenth of the workgroup for a twelfth of the row at 32768 and it hides in the oldest waves' slack; at 8192 it
+    // is a quarter of the workgroup for half of the row -- there the separate scan_kernel, one wave per row over all
+    // rows at once, is the cheaper form.)
+    return bins == 32768 || (RO_USE_WL && ((bins == 16384 && RO_WL_FUSE16) || (bins == 8192 && RO_WL_FUSE8)));
 }
 
 bool stft_supported(int bins)
