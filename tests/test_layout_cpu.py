@@ -1,0 +1,33 @@
+"""The index algebra of stft32k_kernel's one LDS layout, replayed on the CPU: tools/r3/emu32k.py walks
+the kernel's three passes with the kernel's own lane / slot / cell maps on a random row and compares with numpy's fft;
+on the way it asserts that every gather is bank-conflict-free and that every add-TID write splits into a 16-bit M0
+and a 16-bit immediate.  The kernel itself is checked on the GPU (tests/test_gpu_*.py); this keeps the derivation it
+was written from under test, so a change of the layout is made there first."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(script, *args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "r3", script), *args], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+def test_stft32k_layout_reproduces_the_fft_without_bank_conflicts():
+    out = run("emu32k.py")
+    assert "exchange 1 gathers conflict-free: True" in out
+    assert "exchange 2 gathers conflict-free: True" in out
+    assert "bins match numpy fft" in out
+    assert "read-back = fft-shifted row; conflict-free: True" in out
+    assert "LDS bytes: 131200" in out
+
+
+def test_the_general_form_agrees_at_32_points_per_wave_column():
+    """tools/r3/emu_wl.py is the same derivation for 32.32.S; at S = 32 it has to give stft32k_kernel's layout"""
+    out = run("emu_wl.py", "32")
+    assert "S=32 read-back = fft-shifted row; conflict-free: True" in out
+    assert "S=32 closed-form image address: True; LDS bytes 131200" in out
