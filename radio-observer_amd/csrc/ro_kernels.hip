@@ -31,6 +31,9 @@
 #define RO_STAMPS 0
 #endif
 #define RO_DIAG_KNOBS 1
+#ifndef RO_ROW_PRIO
+#define RO_ROW_PRIO 1                 // -DRO_ROW_PRIO=0: the A/B baseline of profiles/r03_row_priority.txt
+#endif
 // the round-3 experiment tools/r3/ro_stft_wl.hip (stft32k_kernel's structure at N = 16384 / 8192; tools/r3/ab_wl_build.sh
 // adds it to the build): correct, and no faster than this file's generic loop (profiles/r03_ab_wl.txt)
 #ifndef RO_USE_WL
@@ -44,6 +47,7 @@
 #endif
 #else
 #define RO_STAMPS 0
+#define RO_ROW_PRIO 1
 #define RO_USE_WL 0
 #define RO_WL_FUSE16 0
 #define RO_WL_FUSE8 0
@@ -430,6 +434,7 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
         }
     };
     stamp(-1);
+    if constexpr (RO_STAMPS == 1) st_acc[13] = st_prev;             // when this workgroup started
     // window coefficients of the row about to be transformed (fetched in the previous
     // epilogue / the prologue, all at once: P floats)
     constexpr bool WPERM = PAIRED && RO_WIN_PERM;
@@ -496,7 +501,24 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
     }
 
     unsigned touch = 0;                    // destination of the next-row prefetch touches (touch_next)
+    [[maybe_unused]] unsigned rows_done = 0;
     for (;;) {
+        if constexpr (RO_ROW_PRIO && N >= 1024) {       // one-wave workgroups of N = 512: 5 % slower with it, 256: even
+            // The workgroups sharing a CU do equal work, but the arbiter serves the oldest wave first: left alone the
+            // workgroup dispatched first runs at nearly its solo speed, the others on what it leaves, and once it is
+            // done the CU runs under-filled to the end of the launch (lifetimes 0.63 ... 1.0 of the launch at N =
+            // 16384, 0.51 ... 1.0 at 8192: profiles/r03_workgroup_lifetimes.txt).  Priority by rows done, modulo 4:
+            // whoever has fallen behind (by up to three rows) outranks its neighbours until it has caught up, and all
+            // workgroups of a CU end within a row of each other: 9 % less time at 16384, 7 % at 4096, 4 % at 8192
+            // (profiles/r03_row_priority.txt).
+            switch (rows_done & 3) {
+            case 0: __builtin_amdgcn_s_setprio(3); break;
+            case 1: __builtin_amdgcn_s_setprio(2); break;
+            case 2: __builtin_amdgcn_s_setprio(1); break;
+            default: __builtin_amdgcn_s_setprio(0); break;
+            }
+            ++rows_done;
+        }
         // ---- stage 0: window.  Coefficients arrive in chunks of WIN_CHUNK, two chunks in
         // flight, so the stage peaks at 2P + 2*WIN_CHUNK VGPRs (+P while a row waits to be stored).
         // ---- stage 0: window (coefficients and samples were requested a whole epilogue ago)
@@ -802,6 +824,12 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
         row = next;
     }
     if constexpr (RO_STAMPS) {
+        if constexpr (RO_STAMPS == 1) {                            // ... when it ended, and where it ran
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+            st_acc[14] = st_prev;
+            st_acc[15] = ((unsigned long long)xcc << 32) | hw;
+        }
         if (a.stamps && tid == 0)
             for (int k = 0; k < 16; ++k) a.stamps[blockIdx.x * 16 + k] = st_acc[k];
     }

@@ -43,6 +43,10 @@ per = a[:, :, :12].sum(0) / a[:, :, 15].sum(0)[:, None]          # [wave][stamp]
 tot = per.sum(1)
 print("scan fused: %s; workgroups 256, rows/wg/launch %.1f, ticks/row %.0f; launch %.1f us -> %.2f us/row, clock ~ %.2f GHz" % (
     scan, rows_wg, tot.mean(), kernel_us, kernel_us / rows_wg, tot.mean() * rows_wg / kernel_us / 1000.0))
+wg_tot = a[:, 0, :12].sum(1)                                  # wave 0 of each workgroup: its ticks from first row to last
+print("workgroup lifetime (wave 0, ticks): mean %.0f min %.0f max %.0f -> mean / max = %.3f of the CU time is used; by XCD (workgroup %% 8): %s"
+      % (wg_tot.mean(), wg_tot.min(), wg_tot.max(), wg_tot.mean() / wg_tot.max(),
+         " ".join("%.0f" % wg_tot[x::8].mean() for x in range(8))))
 print("per wave, ticks per row: e->a work = scan/late loads + window + pass 0 head; a wait; a->d; d->e work; e wait")
 for w in range(16):
     ea = per[w, 11] + per[w, 0] + per[w, 1]

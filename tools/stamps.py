@@ -18,8 +18,17 @@ for _ in range(2):
     st.run_resident(iq, ro.RO_IQ_F32, samples, 0, R, rows, stream=torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
 lib.ro_stft_debug_stamps(st._h, None, 0)          # allocate; from now on the kernel records
-st.run_resident(iq, ro.RO_IQ_F32, samples, 0, R, rows, stream=torch.cuda.current_stream().cuda_stream)
+# the launch that is read back comes last of a run long enough for the power governor to settle (the stamps of a launch
+# overwrite those of the one before); its duration from events, so ticks / duration = the clock it ran at
+K = int(os.environ.get("STAMP_LAUNCHES", "400"))
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+for i in range(K):
+    if i == K - 1:
+        ev[0].record()
+    st.run_resident(iq, ro.RO_IQ_F32, samples, 0, R, rows, stream=torch.cuda.current_stream().cuda_stream)
+ev[1].record()
 torch.cuda.synchronize()
+launch_us = ev[0].elapsed_time(ev[1]) * 1e3
 buf = np.zeros(4096 * 16, dtype=np.uint64)
 lib.ro_stft_debug_stamps(st._h, buf.ctypes.data_as(C.c_void_p), buf.size)
 a = buf.reshape(-1, 16)
@@ -30,6 +39,7 @@ names = ["window mult (+sample wait)", "-", "butterflies0 + tw prefetch", "excha
          "LDS read-back + stores issue", "barrier 2"]
 per_row = a[:, idx].sum(0) / a[:, 9].sum()
 tot = per_row.sum()
-print("workgroups %d, rows/wg %.1f, ticks/row %.0f (s_memtime = shader cycles; at 2.1 GHz => %.2f us)" % (len(a), a[:, 9].mean(), tot, tot / 2100.0))
+print("workgroups %d, rows/wg %.1f, ticks/row %.0f; the launch took %.1f us = %.0f ticks/us per workgroup (s_memtime against the launch's duration)"
+      % (len(a), a[:, 9].mean(), tot, launch_us, tot * a[:, 9].mean() / launch_us))
 for n, t in zip(names, per_row):
     print("  %-30s %8.0f ticks  %5.1f %%" % (n, t, 100 * t / tot))
