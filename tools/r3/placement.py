@@ -56,8 +56,8 @@ for i in order[1:]:
 clusters.append(cur)
 print("workgroup lifetime: mean %.0f ticks, min %.0f, max %.0f (%.0f ticks/us if the slowest spans the launch)"
       % (life.mean(), life.min(), life.max(), life.max() / us))
-print("%d clock domains" % len(clusters))
-for c in clusters:
+print("%d clock domains%s" % (len(clusters), "" if "--clusters" in sys.argv else " (--clusters lists them)"))
+for c in (clusters if "--clusters" in sys.argv else []):
     c = np.array(c)
     t0, t1 = start[c].min(), end[c].max()
     span = t1 - t0
