@@ -510,7 +510,8 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
             // 16384, 0.51 ... 1.0 at 8192: profiles/r03_workgroup_lifetimes.txt).  Priority by rows done, modulo 4:
             // whoever has fallen behind (by up to three rows) outranks its neighbours until it has caught up, and all
             // workgroups of a CU end within a row of each other: 9 % less time at 16384, 7 % at 4096, 4 % at 8192
-            // (profiles/r03_row_priority.txt).
+            // (profiles/r03_row_priority.txt; a step per HALF row, priority 3 - half-rows done mod 4, was 3-6 % slower at
+            // 4096 and 2048 and even at 16384 and 8192).
             switch (rows_done & 3) {
             case 0: __builtin_amdgcn_s_setprio(3); break;
             case 1: __builtin_amdgcn_s_setprio(2); break;
