@@ -231,6 +231,7 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
         }
     };
     stamp(-1);
+    if constexpr (RO_STAMPS32K) st_acc[13] = __builtin_amdgcn_s_memrealtime();   // start, on the chip-wide 100 MHz counter
 
     // the image of the row before this one and where it goes; 0 bytes = nothing to store
     const float *prev_out = a.rows_out;
@@ -560,6 +561,7 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
         }
     }
     if constexpr (RO_STAMPS32K) {
+        st_acc[14] = __builtin_amdgcn_s_memrealtime();             // ... and end (tools/r3/stamps32k.py)
         if (a.stamps && (tid & 63) == 0)
             for (int k = 0; k < 16; ++k) a.stamps[(blockIdx.x * 16 + wave) * 16 + k] = st_acc[k];
     }

@@ -47,6 +47,15 @@ wg_tot = a[:, 0, :12].sum(1)                                  # wave 0 of each w
 print("workgroup lifetime (wave 0, ticks): mean %.0f min %.0f max %.0f -> mean / max = %.3f of the CU time is used; by XCD (workgroup %% 8): %s"
       % (wg_tot.mean(), wg_tot.min(), wg_tot.max(), wg_tot.mean() / wg_tot.max(),
          " ".join("%.0f" % wg_tot[x::8].mean() for x in range(8))))
+u = buf.reshape(256, 16, 16)
+start, end = u[:, 0, 13].astype(np.float64), u[:, 0, 14].astype(np.float64)
+t0 = start.min()
+print("on the chip-wide 100 MHz counter: workgroups START over %.1f us, END over %.1f us, first start to last end %.1f us (the launch by events: %.1f us);"
+      " mean lifetime %.1f us" % ((start.max() - t0) / 100, (end.max() - end.min()) / 100, (end.max() - t0) / 100, kernel_us, (end - start).mean() / 100))
+print("by XCD (workgroup %% 8): end after the first start, us: %s;  lifetime us: %s;  ticks/us: %s" % (
+    " ".join("%.0f" % ((end[x::8].max() - t0) / 100) for x in range(8)),
+    " ".join("%.0f" % ((end[x::8] - start[x::8]).mean() / 100) for x in range(8)),
+    " ".join("%.0f" % (wg_tot[x::8] / ((end[x::8] - start[x::8]) / 100)).mean() for x in range(8))))
 print("per wave, ticks per row: e->a work = scan/late loads + window + pass 0 head; a wait; a->d; d->e work; e wait")
 for w in range(16):
     ea = per[w, 11] + per[w, 0] + per[w, 1]
