@@ -32,7 +32,7 @@ struct StftArgs {
     int           spare_cus;   // CUs per XCD the persistent grid leaves to other kernels (ro_stft_config_t)
     int           dec, dec_log2; // MODE 3 (large transform, bins = dec x N): the factor, its log2; else 1, 0
     const float2 *dif_tw;        // MODE 3: exp(-2 pi i j / dec), j < dec
-    const float2 *dif_rot;       // MODE 3: [dec][N] exp(-2 pi i q m / (dec N))
+    const float2 *dif_shift;     // MODE 3: [dec][16]: exp(-2 pi i (q / dec) 2^i / M), i < 5, M = 32, 1024, 32768 at 0, 5, 10
     int           big_form;      // 1 selects MODE 3 (a large transform in one kernel), else 0
     // fused per-row band scan (BolidRecorder::noise/peak/average on the row while it is still in LDS): plans that
     // support it (stft_fuses_scan) fill records[row] themselves, the others leave it to launch_scan

@@ -533,8 +533,8 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
                 const bool odd = tid & 1;
                 if constexpr (DIF) {
                     // v[] holds block 0 of the row; add the other dec-1 blocks, each times its window block and
-                    // W_dec^(r q), then rotate by W_bins^(m q).  Everything here is per element, so it happens
-                    // before the lane swap below, with the loads' own (lane, slot) -> m map.
+                    // W_dec^(r q).  Everything here is per element, so it happens before the lane swap below, with
+                    // the loads' own (lane, slot) -> m map.
                     static_assert(WPERM && NB == 1, "MODE 3 runs on the plans with one paired butterfly per thread");
                     load_window(win_rsrc(row, true), c0{}, cN{});
                     const int q = (int)(row & (a.dec - 1));
@@ -597,22 +597,8 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
                         unit_load(ua, blk_rsrc(r + 1), wblk_rsrc(r + 1), 0, v[H + 2 * KC].x);     // (zero-sized past the last block)
                         unit_add(ub, 3 * KC, cxx, cyn);
                     }
-                    // (residue 0 needs no rotation: W^0)
-                    const __amdgpu_buffer_rsrc_t rs_rot = make_rsrc(a.dif_rot + (int64_t)q * N, N * 8);
-                    if (q != 0)
-#pragma unroll
-                    for (int k0 = 0; k0 < H; k0 += KC) {
-                        v2f tl[KC], th[KC];
-                        const int pod = k0 >= 2 * KC ? after(po, v[H + k0 - 2 * KC].x) : po;
-#pragma unroll
-                        for (int j = 0; j < KC; ++j)
-                            Sample<RO_FMT_F32>::load_pair(rs_rot, pod * 8, (k0 + j) * (N / R0) * 8, tl[j], th[j]);
-#pragma unroll
-                        for (int j = 0; j < KC; ++j) {
-                            v[k0 + j] = cmul(v[k0 + j], tl[j]);
-                            v[H + k0 + j] = cmul(v[H + k0 + j], th[j]);
-                        }
-                    }
+                    // (no rotation here: W_bins^(m q) is a shift of the bin index by q / dec, and the three stages take it
+                    // in their twiddles -- shift_stage below)
                 }
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
@@ -678,7 +664,31 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
         if constexpr (RO_PREFETCH_NEXT == 1) touch_next();
         stamp(0);                                   // window multiply (+ wait for samples)
 
-        butterflies<P, R0>(v);
+        // MODE 3, residue q != 0: the braces carry the factor W_bins^(m q) = W_N^(m q / dec) -- the transform evaluated
+        // at the bins k' + q / dec.  In the autosort recurrence that is every stage's twiddle exponent (j mod Ns) moved
+        // by q / dec (stage 0, Ns = 1: w^r with w = exp(-2 pi i (q / dec) / R0), the same for every thread), so the
+        // rotation costs no table and no loads: 15 uniform constants per residue (StftArgs::dif_shift: {w, w^2, w^4,
+        // w^8, w^16} of the shift at each of the three radix-32 stages) -- stage 0 runs its twiddled form, stages 1 and
+        // 2 multiply their five held powers by the shift's.  (Until round 3 the rotation was a [dec][N] table read in the
+        // window stage, 256 KiB from L2 per row with q != 0: 65536 1.3 % and 131072 3.5 % faster without it,
+        // profiles/r03_dif_shift.txt.  Residue 0 runs the twiddled stage 0 as well, with w = 1: the two forms side by
+        // side behind a branch on q cost 68 spilled registers.)
+        [[maybe_unused]] const int dif_q = DIF ? (int)(row & (a.dec - 1)) : 0;
+        [[maybe_unused]] auto shift_stage = [&](v2f (&t)[TW_SET], int stage) {
+            const float2 *sh = a.dif_shift + dif_q * 16 + stage * 5;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) t[i] = cmul(t[i], (v2f){sh[i].x, sh[i].y});
+        };
+        if constexpr (DIF) {
+            static_assert(R0 == 32 && PL::R1 == 32 && PL::R2 == 32 && P == 32, "the shifted stages are written for 32.32.32");
+            {
+                const float2 *sh = a.dif_shift + dif_q * 16;
+                fdit32(v, (v2f){sh[4].x, sh[4].y}, (v2f){sh[3].x, sh[3].y}, (v2f){sh[2].x, sh[2].y},
+                       (v2f){sh[1].x, sh[1].y}, (v2f){sh[0].x, sh[0].y});
+            }
+        } else {
+            butterflies<P, R0>(v);
+        }
         if constexpr (PL::R1 > 1 && !RES) tw_prefetch<P, T, PL::R1, PL::NS1, PL::TW1, PL::PK1>(tw1, rs_tw, rs_twk, fresh_tid());
         stamp(2);                                   // butterflies 0
 
@@ -687,6 +697,7 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
             if constexpr (ADDTID) exchange_addtid<1, SWAP32, P / 32, T>(smem, v, tid, [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             else exchange<PL, PL::R0, 1, PL::R1>(smem, v, fresh_tid(), [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             stamp(3);                               // exchange 1
+            if constexpr (DIF) { if (dif_q != 0) shift_stage(tw1[0], 1); }
             tw_butterflies<P, PL::R1>(v, tw1);
             // behind the butterflies: in front of them hipcc's wait for this pass's twiddles (which it believes to be
             // the youngest loads in flight) would sit through the touches' HBM misses as well
@@ -700,6 +711,7 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
             else exchange<PL, PL::R1, PL::NS1, PL::R2>(smem, v, fresh_tid(), [&](int k) { if constexpr (RO_STAMPS == 3) stamp(12 + k); });
             stamp(5);                               // exchange 2
             if constexpr (RO_PREFETCH_NEXT == 3) touch_next();
+            if constexpr (DIF) { if (dif_q != 0) shift_stage(tw2[0], 2); }
             tw_butterflies<P, PL::R2, TW8C>(v, tw2);
             stamp(6);                               // twiddles + butterflies 2
 

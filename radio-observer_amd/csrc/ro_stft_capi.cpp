@@ -214,6 +214,7 @@ struct ro_stft {
     bool    dif = false;               // dec <= RO_DIF_MAX_DEC: one kernel sums the row's blocks itself (MODE 3)
     float  *d_window_dif = nullptr;    // ... [dec][sub_bins]: window block r in the sub-plan's kernel order
     float2 *d_dif_tw = nullptr;        // ... exp(-2 pi i j / dec)
+    float2 *d_dif_shift = nullptr;     // ... [dec][16]: the bin shift q / dec as the stages' twiddles (StftArgs::dif_shift)
     bool    fold = false;              // else fold_kernel to scratch, the N = 32768 kernel on its rows, interleave_kernel
     float2 *d_spec = nullptr;          // ... the folded sub-rows, [spec_rows][dec][sub_bins] float2
     float  *d_mag = nullptr;           // ... their magnitudes, [spec_rows][dec][sub_bins]
@@ -591,7 +592,7 @@ int launch_transform(ro_stft *h, const void *d_iq, int format, int64_t first_row
         a.dec = h->dec;
         a.dec_log2 = log2;
         a.dif_tw = h->d_dif_tw;
-        a.dif_rot = h->d_tw_combine;
+        a.dif_shift = h->d_dif_shift;
         a.big_form = 1;
         HIP_TRY(ro::launch_stft(h->sub_bins, format, a, s));
         return RO_OK;
@@ -1249,6 +1250,18 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
         }
         CREATE_TRY(hipMalloc(&h->d_dif_tw, sizeof(float2) * td.size()));
         CREATE_TRY(hipMemcpy(h->d_dif_tw, td.data(), sizeof(float2) * td.size(), hipMemcpyHostToDevice));
+        // residue q's rotation W_bins^(m q) as a shift of the bin index by q / dec: per stage (32, 32 x 32, 32^3 points
+        // behind it) the powers 1, 2, 4, 8, 16 of exp(-2 pi i (q / dec) / M), each rounded once from long double
+        std::vector<float2> ts((size_t)h->dec * 16, make_float2(1.0f, 0.0f));
+        const long double span[3] = {32.0L, 1024.0L, 32768.0L};
+        for (int q = 0; q < h->dec; ++q)
+            for (int st = 0; st < 3; ++st)
+                for (int i = 0; i < 5; ++i) {
+                    const long double ang = -two_pi * ((long double)q / (long double)h->dec) * (long double)(1 << i) / span[st];
+                    ts[(size_t)q * 16 + st * 5 + i] = make_float2((float)cosl(ang), (float)sinl(ang));
+                }
+        CREATE_TRY(hipMalloc(&h->d_dif_shift, sizeof(float2) * ts.size()));
+        CREATE_TRY(hipMemcpy(h->d_dif_shift, ts.data(), sizeof(float2) * ts.size(), hipMemcpyHostToDevice));
     }
     if (h->czt) {
         const int N = h->bins, M = h->czt_m;
@@ -1337,6 +1350,7 @@ extern "C" int ro_stft_destroy(ro_stft_t *h)
     if (h->d_mag) (void)hipFree(h->d_mag);
     if (h->d_ones) (void)hipFree(h->d_ones);
     if (h->d_dif_tw) (void)hipFree(h->d_dif_tw);
+    if (h->d_dif_shift) (void)hipFree(h->d_dif_shift);
     if (h->d_tw_f64) (void)hipFree(h->d_tw_f64);
     if (h->d_ln_part) (void)hipFree(h->d_ln_part);
     for (int i = 0; i < 2; ++i)
