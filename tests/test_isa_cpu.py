@@ -196,3 +196,26 @@ def test_square_roots_are_not_stored_to_lds_straight_away(isa):
                 for r in _regs(ops[0]):
                     last_sqrt[r] = 0
     assert checked >= 64
+
+
+def test_row_priority_is_set_where_workgroups_share_a_cu(isa):
+    """stft_kernel raises and lowers its priority by rows done in the plans of N >= 1024; the one-wave
+    plans below and the one-workgroup-per-CU kernel of N = 32768 do not touch it."""
+    with_prio, without = 0, 0
+    for name, body in kernels(isa).items():
+        if "stft_kernel" not in name:
+            continue
+        m = re.search(r"PlanILi(\d+)E", name)
+        assert m, name
+        n = int(m.group(1))
+        levels = {l.split()[-1] for l in body if re.match(r"\s+s_setprio\b", l)}
+        if n >= 1024:
+            assert levels == {"0", "1", "2", "3"}, (name, levels)
+            with_prio += 1
+        else:
+            assert not levels, (name, levels)
+            without += 1
+    assert with_prio >= 20 and without == 8
+    for name, body in kernels(isa).items():
+        if "stft32k_kernel" in name:
+            assert not any(re.match(r"\s+s_setprio\b", l) for l in body), name
