@@ -4,7 +4,9 @@
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
   N > 1 is launched by the driver as
       python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-  one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the env), RCCL = backend "nccl".
+  one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the env), RCCL = backend "nccl".  Started from a plain
+  shell (`python3 bench.py --gpus N`, no WORLD_SIZE in the env) it starts that very job as a child process before
+  it has imported torch or made any HIP call, and exits with the child's code (launch_ranks).
 
 Workload (BASELINE.json configs[2..3], "C3/C4"): synthetic IQ resident in HBM, 48 kHz,
 FFT bins = 32768, overlap = 24576 (75 %), Nuttall window, R = 16384 rows per step per GPU
@@ -274,8 +276,27 @@ class RcclComm:
         self.rccl.ncclCommDestroy(self.comm)
 
 
+def launch_ranks(n):
+    """`python3 bench.py --gpus N` from a plain shell: start the N ranks as a CHILD job
+    (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <the same arguments>) and exit with
+    its code.  This process has not imported torch and has made no HIP call -- it never touches a GPU, it only waits;
+    rank 0 of the child prints the JSON line on the stdout it inherits."""
+    import socket
+    with socket.socket() as s:                                # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus))
     global BINS, OVERLAP, HOP, ALG_BYTES_PER_ROW
     if a.bins != BINS or a.overlap is not None:             # non-headline shapes (e.g. C2: --bins 4096 --overlap 2048)
         BINS = a.bins
@@ -300,9 +321,7 @@ def main():
     import torch.distributed as dist
 
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus %d must be started by torch.distributed.run with %d ranks"
-                     % (a.gpus, a.gpus))
+        sys.exit("bench.py --gpus %d was started with WORLD_SIZE=%d: the two must agree" % (a.gpus, world))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
     if a.comm == "gloo-host":
@@ -522,7 +541,9 @@ def main():
     if rank == 0:
         total_rows = R_total * a.steps
         value = total_rows / dt
-        fused = BINS == 32768 and world == 1                # one step = one kernel: scan and tile are its epilogue
+        # one step = one kernel (scan and tile are its epilogue) and nothing else on the launch stream: with an exchange
+        # every step begins with a wait for the side stream, which would be counted as kernel time
+        fused = BINS == 32768 and world == 1 and not exchanging
         # The dominant kernel's average launch duration: HIP events on the launch stream around the K launches of the
         # TIMED region when a step is exactly that one kernel (bins = 32768: scan and tile are its epilogue); for the
         # plans with a separate scan kernel the transform's own share comes from the event pairs of

@@ -41,3 +41,29 @@ def test_bench_refuses_to_run_without_a_device():
     assert r.returncode != 0
     assert "no CPU fallback" in (r.stderr + r.stdout)
     assert not r.stdout.strip().startswith("{")     # and no JSON line that could be mistaken for a measurement
+
+
+def test_bench_gpus_n_from_a_plain_shell_starts_n_ranks():
+    """`python3 bench.py --gpus 2` with no WORLD_SIZE in the env starts the two ranks itself (as a child
+    torch.distributed.run job, before this process has imported torch) and exits with the child's code.  Without a
+    device every rank refuses to run, so what can be checked here is the launcher: two ranks came up with
+    WORLD_SIZE = 2, both said why they stop, and the launcher handed the failure on."""
+    import torch
+    if torch.cuda.is_available():
+        return                                     # (tests/test_gpu_bench.py runs the 2-rank rehearsal for real)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", "gloo-host",
+                        "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode != 0
+    assert (r.stderr + r.stdout).count("no CPU fallback") >= 2, r.stderr[-2000:]
+    assert "must be started by" not in r.stderr
+    assert not r.stdout.strip().startswith("{")
+
+
+def test_bench_launcher_runs_before_torch_is_imported():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    assert main.index("launch_ranks(a.gpus)") < main.index("import torch")
+    launcher = src[src.index("def launch_ranks("):src.index("def main():")]
+    assert "import torch" not in launcher and "torch.distributed.run" in launcher
