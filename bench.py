@@ -249,6 +249,73 @@ def streaming_leg(seconds, max_batch_rows):
                     "startStream (handle creation) and the warm-up calls are outside the timed region, endStream inside"}
 
 
+class ClockPowerSampler:
+    """shader clock and package power of THIS GPU during the run, from the amdgpu hwmon files in sysfs (plain file reads
+    from a thread of this process: no child process, no rocm-smi).  The card is the one whose PCI address is the
+    device's (torch: pci_domain_id / pci_bus_id / pci_device_id); without a match nothing is reported."""
+
+    def __init__(self, torch, dev_index):
+        import glob
+        import threading
+        self.files = None
+        self.samples = []                      # (perf_counter, sclk MHz, watts)
+        self.card = None
+        try:
+            p = torch.cuda.get_device_properties(dev_index)
+            want = "%04x:%02x:%02x." % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+            for d in sorted(glob.glob("/sys/class/drm/card*/device")):
+                if os.path.basename(os.path.realpath(d)).startswith(want):
+                    hw = sorted(glob.glob(os.path.join(d, "hwmon", "hwmon*")))
+                    if hw and os.path.exists(os.path.join(hw[0], "freq1_input")):
+                        pw = [f for f in ("power1_input", "power1_average") if os.path.exists(os.path.join(hw[0], f))]
+                        self.files = (os.path.join(hw[0], "freq1_input"), os.path.join(hw[0], pw[0]) if pw else None)
+                        self.card = os.path.basename(os.path.dirname(d)) + " " + os.path.basename(os.path.realpath(d))
+                    break
+        except Exception:
+            self.files = None
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True) if self.files else None
+
+    def _read(self, f):
+        try:
+            with open(f) as fh:
+                return float(fh.read().strip())
+        except Exception:
+            return float("nan")
+
+    def _run(self):
+        while not self._stop.is_set():
+            t = time.perf_counter()
+            mhz = self._read(self.files[0]) / 1e6
+            w = self._read(self.files[1]) / 1e6 if self.files[1] else float("nan")
+            self.samples.append((t, mhz, w))
+            time.sleep(0.002)
+
+    def start(self):
+        if self._thread:
+            self._thread.start()
+
+    def stop(self):
+        if self._thread:
+            self._stop.set()
+            self._thread.join()
+
+    def summary(self, t0, t1):
+        """mean / min / max inside [t0, t1] (the timed region) and, for context, over the warm-up before it"""
+        if not self.files:
+            return {"available": False, "note": "no amdgpu hwmon files for this device's PCI address in sysfs"}
+
+        def stats(rows, col):
+            x = np.array([r[col] for r in rows], dtype=np.float64)
+            x = x[np.isfinite(x)]
+            return None if x.size == 0 else {"mean": float(x.mean()), "min": float(x.min()), "max": float(x.max())}
+        inside = [r for r in self.samples if t0 <= r[0] <= t1]
+        before = [r for r in self.samples if r[0] < t0]
+        return {"available": True, "card": self.card, "source": "hwmon freq1_input / power1_input, one read per ~2 ms",
+                "timed_region": {"samples": len(inside), "sclk_mhz": stats(inside, 1), "package_watts": stats(inside, 2)},
+                "warmup": {"samples": len(before), "sclk_mhz": stats(before, 1), "package_watts": stats(before, 2)}}
+
+
 class RcclComm:
     """an ncclComm_t of this job's ranks for the product's own exchange (--exchange capi): created through ctypes on
     librccl, the unique id travelling over the torch.distributed group that already exists"""
@@ -476,6 +543,9 @@ def main():
     if exchanging and mode["now"] == "root" and not usable("root"):
         mode["now"] = "all"
         mode["note"] = (mode["note"] or "") + ": all-gather instead"
+    sampler = ClockPowerSampler(torch, local_rank) if rank == 0 else None
+    if sampler:
+        sampler.start()
     for i in range(a.prewarm + a.warmup):
         step(i)
     fence()
@@ -487,6 +557,10 @@ def main():
     ev_b.record(stream)
     fence()
     dt = time.perf_counter() - t0
+    clock_power = None
+    if sampler:
+        sampler.stop()
+        clock_power = sampler.summary(t0, t0 + dt)
     gpu_ms_per_step = ev_a.elapsed_time(ev_b) / a.steps       # HIP events on the launch stream, over the timed region
     if world > 1:
         dt = max_over_ranks(dt)
@@ -596,6 +670,9 @@ def main():
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ROW * R,
                          "scan_kernel_ms": k_scan},
             "device": st.device_name,
+            # what the device ran at while it was timed ("make the line self-qualifying"): at the package's
+            # 1400 W cap the shader clock, not the kernel, differs between boxes
+            "clock_power": clock_power,
             "gpu_ms_per_step_events": gpu_ms_per_step, "step_ms_back_to_back": float(np.mean(ms_all)),
             "step_ms_median": float(np.median(ms_all)), "step_ms_min": float(np.min(ms_all)),
         }

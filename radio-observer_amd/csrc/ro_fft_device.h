@@ -15,7 +15,20 @@
 #include <hip/hip_runtime.h>
 #include <utility>
 
+// The butterflies' scheduling leash (tie(), below) comes in two forms, chosen per translation unit BEFORE this header
+// is included: RO_TIE_SCHED = 0 an empty asm statement (ro_kernels.hip), 1 a scheduling barrier (ro_stft32k.hip).
+// Everything in this header that depends on the choice lives in an inline namespace named after it, so the two
+// translation units of the library define differently NAMED functions, not one inline function with two bodies.
+#ifndef RO_TIE_SCHED
+#define RO_TIE_SCHED 0
+#endif
+
 namespace ro {
+#if RO_TIE_SCHED
+inline namespace tie_sched {
+#else
+inline namespace tie_asm {
+#endif
 
 // cos(k*pi/16), k = 0..8
 #define RO_C1 0.98078528040323044913f
@@ -90,9 +103,6 @@ constexpr int SEQ_G = RO_SEQ_G;
 // cross it) instead of an empty asm statement.  hipcc (ROCm 7.2) assumes that ANY inline asm result may be a
 // "dst_sel-forwarded" value on gfx950 and puts an s_nop 0 in front of the next VALU instruction that reads it -- and
 // another one in front of the asm when its input comes from a packed op: ~300 s_nop per row and wave in the butterflies.
-#ifndef RO_TIE_SCHED
-#define RO_TIE_SCHED 0
-#endif
 __device__ __forceinline__ void tie(v2f &x, const v2f &dep)
 {
 #if RO_TIE_SCHED
@@ -167,15 +177,9 @@ __device__ __forceinline__ v2f cmadd_mi(v2f x, v2f w, v2f acc)
 }
 
 // (a, b) <- (a + W32^E b, a - W32^E b)
-// diagnostic builds only: -DRO_FFT_NO_BFLY=1 removes the butterflies' arithmetic (dependence chains stay) to price it
-#ifndef RO_FFT_NO_BFLY
-#define RO_FFT_NO_BFLY 0
-#endif
 template <int E> __device__ __forceinline__ void dit_pair(v2f &a, v2f &b)
 {
-    if constexpr (RO_FFT_NO_BFLY) {
-        return;
-    } else if constexpr (E == 0) {
+    if constexpr (E == 0) {
         const v2f s = a + b;
         b = a - b;
         a = s;
@@ -250,11 +254,9 @@ template <int L, int U, int I> __device__ __forceinline__ void fdit_bfly(v2f *x,
     constexpr int S = 32 >> L, E = bitrev_bits<L>(U) * (16 >> L), base = U * S;
     v2f &a = x[base + I], &b = x[base + I + S / 2];
     if constexpr (I % SEQ_G == 0) tie(a, *tok);
-    if constexpr (!RO_FFT_NO_BFLY) {
-        const v2f s = (E >= 8) ? cmadd_mi(b, tw[E & 7], a) : cmadd(b, tw[E & 7], a);
-        b = __builtin_elementwise_fma(a, (v2f){2.0f, 2.0f}, -s);
-        a = s;
-    }
+    const v2f s = (E >= 8) ? cmadd_mi(b, tw[E & 7], a) : cmadd(b, tw[E & 7], a);
+    b = __builtin_elementwise_fma(a, (v2f){2.0f, 2.0f}, -s);
+    a = s;
     tok = &b;
 }
 
@@ -308,7 +310,6 @@ __device__ __forceinline__ void tie(v2f &x, float dep)
 // one last-level butterfly (a, b) <- (a + W32^E g1 b, a - W32^E g1 b), the product w = W32^(E & 7) g1 given
 template <int E> __device__ __forceinline__ void fdit_last_bfly(v2f &a, v2f &b, v2f w)
 {
-    if constexpr (RO_FFT_NO_BFLY) return;
     const v2f s = (E >= 8) ? cmadd_mi(b, w, a) : cmadd(b, w, a);
     b = __builtin_elementwise_fma(a, (v2f){2.0f, 2.0f}, -s);
     a = s;
@@ -421,4 +422,5 @@ template <int R> __host__ __device__ constexpr int bitrev(int k)
 
 __device__ __forceinline__ constexpr int lds_pad(int i) { return i + (i >> 5); }
 
+}  // inline namespace tie_sched / tie_asm
 }  // namespace ro

@@ -16,6 +16,7 @@ struct StftArgs {
     const void   *iq;          // sample 0 of the stream (device)
     const float  *window;      // bins floats (device), natural order
     const float  *window_k;    // the same coefficients in kernel order (stft_window_layout)
+    const float  *window_k32;  // ... in the order of the N = 32768 magnitude-row kernel (stft32k_window_layout)
     const float2 *twiddles;    // per-stage tables (device), see build_twiddles
     const float4 *twiddles_k;  // radix-16/32 stages repacked for 16-byte loads (stft_pack_twiddles)
     float        *rows_out;    // rows x row_stride (magnitude mode)
@@ -162,6 +163,7 @@ bool       stft_window_layout(int bins, const float *w, float *out);   // host: 
 hipError_t launch_stft(int bins, int fmt, const StftArgs &a, hipStream_t s);
 // the N = 32768 magnitude-row kernel with the fused scan / tile epilogue (ro_stft32k.hip); launch_stft routes to it
 hipError_t launch_stft32k(int fmt, const StftArgs &a, hipStream_t s);
+void       stft32k_window_layout(const float *w, float *out);         // host: 32768 floats -> StftArgs::window_k32
 // (diagnostic builds only: tools/r3/ro_stft_wl.hip, the same structure at N = 16384 / 8192)
 hipError_t launch_stft_wl(int bins, int fmt, const StftArgs &a, hipStream_t s);
 hipError_t launch_scan(const ScanArgs &a, hipStream_t s);

@@ -11,104 +11,90 @@
 //   pass 2 over a  -> k2   (thread = (k0, k1))
 // The exchange between pass 0 and pass 1 is a transposition over the whole workgroup (every wave needs data of
 // every other wave).  From there on a wave owns two values of k0 and ALL of their a, so the exchange between pass
-// 1 and pass 2 is a 32 x 32 transposition inside each half of the wave: no workgroup barrier between the last read
-// of exchange 1 and the completed magnitude image -- two thirds of the row's butterflies -- and the waves of a SIMD
-// drift apart, one wave's LDS traffic running under another's butterflies.  (The stft_kernel<Plan32768> this replaces
-// made both exchanges over the whole workgroup: ten barriers per row held all sixteen waves in the same phase, so
-// VALU, LDS and the memory pipe took turns: 0.42 of the HBM roofline.)  Five barriers per row are left.
+// 1 and pass 2 is a 32 x 32 transposition inside the wave: no workgroup barrier between the last read of exchange 1
+// and the completed magnitude image -- two thirds of the row's butterflies.  Five barriers per row.
 //
 // ONE LDS layout serves the three uses (floats; real and imaginary plane one after the other, a complex row does
 // not fit 160 KiB):
-//   cell(q, w, l) = 1025 q + 64 w + l        q < 32 a row, w < 16 the wave whose territory it is, l < 64
+//   cell(q, w, l) = 1026 q + 64 w + l        q < 32 a row, w < 16 the wave whose territory it is, l < 64
 // * every write is ds_write_addtid_b32 (address = M0 + offset + 4 lane: lane-linear, no address VGPR, twice the
 //   rate of ds_write_b32); M0 and the offset field hold 16 bits each and every cell is within their reach;
-// * 1025 is odd: a column read (32 rows, one cell each) walks 32 different banks;
+// * every read is ds_read_b64 -- two neighbouring cells of one row, i.e. the same component of two points (256 B/clk
+//   where ds_read_b32 gives 128): that is why passes 1 and 2 keep their points on a PLANAR register layout
+//   (ro_fft_planar.h) -- R[i] = (re p, re p'), I[i] = (im p, im p') -- and why the lane maps below put the two points a
+//   thread wants together into neighbouring lanes of the writing wave;
+// * 1026 = 2 mod 64: a column read (32 rows, two cells each) walks all 64 banks, and 16 rows are 32 banks;
 // * a wave only ever READS its own territory until the image is complete, and nobody writes into a territory
 //   between the barrier in front of exchange 1's reads and the next row: that is what removes the barriers.
-//   exchange 1:  slot k0 of pass-0 wave w', lane l  ->  cell(w' + 16 (k0 & 1), k0 >> 1, l)
-//                pass-1 lane (a >> 1) + 16 kb + 32 (a & 1) of wave w is thread (k0 = 2 w + kb, a) and reads slot b
-//                from cell((b >> 1) + 16 kb, w, (a >> 1) + 16 (b & 1) + 32 (a & 1))
+//   pass 0:      lane l of wave w' is column n1 = a + 32 b with a = 2 ((l & 31) >> 1) + (l >> 5), b = 2 w' + (l & 1):
+//                lanes l, l + 1 (l even) hold the same a and b, b + 1
+//   exchange 1:  slot k0 of that thread  ->  cell(w' + 16 (k0 & 1), k0 >> 1, l)
+//                pass-1 lane (a >> 1) + 16 (a & 1) + 32 kb of wave w is thread (k0 = 2 w + kb, a) and reads slots
+//                b = 2 w', 2 w' + 1 from cell(w' + 16 kb, w, 2 (a >> 1) + 32 (a & 1)), + 1       (mates b, b + 1)
 //   exchange 2:  slot k1 of that thread -> cell(k1, w, lane)
-//                pass-2 lane l' of wave w is thread (k0 = 2 w + (l' >> 5), k1 = (l' + 4 (w >> 1)) & 31) and reads
-//                slot a from cell(k1, w, (a >> 1) + 16 kb + 32 (a & 1))
-//   image:       slot k2 of that thread = bin k0 + 32 k1 + 1024 k2 -> cell(k2, w, l')
-//                (the rotation by 4 (w >> 1) makes the 16-byte-per-lane read-back of the row conflict-free)
-// tools/r3/emu32k.py restates these maps with numpy and checks them against numpy's FFT and for bank conflicts.
-#ifndef RO_K32_ABLATE
-#define RO_K32_ABLATE 0
-#endif
-#if RO_K32_ABLATE & 8
-#define RO_FFT_NO_BFLY 1
-#endif
+//                pass-2 lane l' of wave w is thread (k0 = 2 w + (l' & 1), k1 = ((l' >> 1) + 4 (w >> 1)) & 31) and reads
+//                slots a = 4 u + p, 4 u + p + 2 from cell(k1, w, 2 u + 16 p + 32 kb), + 1       (mates a, a + 2)
+//   image:       slot k2 of that thread = bin k0 + 32 k1 + 1024 k2 -> cell(k2, w, l'): bins k0 = 2 w, 2 w + 1 of one
+//                (k1, k2) are neighbours, and the rotation by 4 (w >> 1) makes the 16-byte-per-lane read-back of the
+//                row (two ds_read_b64: territories w, w + 1) conflict-free
+// tools/r4/emu32k.py restates these maps and the planar butterflies (with the VOP3P modifiers of ro_fft_planar.h) in
+// numpy and checks them against numpy's FFT and for bank conflicts.
 // the butterflies' scheduling leash as a scheduling barrier, not an empty asm statement (see tie() in ro_fft_device.h):
-// 240 fewer s_nop per row and wave, 7 VGPRs fewer, the same bits
-#ifndef RO_TIE_SCHED
+// hipcc pads an s_nop around every inline-asm result on gfx950; 240 fewer s_nop per row and wave, 7 VGPRs fewer
 #define RO_TIE_SCHED 1
-#endif
 #include "ro_kernels.h"
 #include "ro_fft_device.h"
+#include "ro_fft_planar.h"
 #include "ro_device_util.h"
 
 #include <mutex>
 
-// Diagnostic only: -DRO_STAMPS32K=1 accumulates s_memtime deltas per phase of the row loop (every wave of every
-// workgroup) into StftArgs::stamps.  Never timed, never shipped.
-#ifndef RO_STAMPS32K
+// The ONE diagnostic switch of this file.  A -DRO_DIAG=1 build (tools/ab_build.sh) may set RO_STAMPS32K=1: s_memtime
+// deltas per phase of the row loop (every wave of every workgroup) accumulated into StftArgs::stamps
+// (tools/r3/stamps32k.py).  Never timed, never shipped.
+#if !defined(RO_DIAG) || !defined(RO_STAMPS32K)
+#undef RO_STAMPS32K
 #define RO_STAMPS32K 0
-#endif
-// butterfly pairs of pass 2's last level that request next-row samples (of 8); the rest is requested behind the scan
-#ifndef RO_K32_PIPE_J
-#define RO_K32_PIPE_J 6
-#endif
-// share (percent) of the next row's window coefficients requested right behind the window stage
-#ifndef RO_K32_WIN_EARLY_PCT
-#define RO_K32_WIN_EARLY_PCT 25
-#endif
-
-// Diagnostic builds only (tools/ab_build.sh): RO_K32_ABLATE bits remove one kind of memory traffic to price it (1: no
-// twiddle loads, 2: no window loads, 4: no LDS exchanges, 8: no butterflies (-DRO_FFT_NO_BFLY), 16: no row stores;
-// results are wrong by design); RO_K32_PRIO tries wave priorities
-// between exchange 1 and the image (1: by progress -- 3, 2, 1, 0 through the four butterfly phases; 2: static, youngest
-// wave of a SIMD highest).
-#ifndef RO_K32_ABLATE
-#define RO_K32_ABLATE 0
-#endif
-#ifndef RO_K32_PRIO
-#define RO_K32_PRIO 0
-#endif
-// the next row's last sample legs and window coefficients are requested in front of the image-complete barrier by
-// every wave that does not scan (1), or behind the scan by all (0)
-#ifndef RO_K32_EARLY_LOADS
-#define RO_K32_EARLY_LOADS 1
-#endif
-#ifndef RO_K32_TW1_SCALAR
-#define RO_K32_TW1_SCALAR 1
 #endif
 
 namespace ro {
 namespace k32 {
 
 constexpr int N = 32768, T = 1024, H = 16;
-constexpr int RQ = 1025;                              // floats per row of the LDS layout
-constexpr int IMAGE_BYTES = 32 * RQ * 4;              // 131200
+constexpr int RQ = 1026;                              // floats per row of the LDS layout
+constexpr int IMAGE_BYTES = 32 * RQ * 4;              // 131328
 constexpr int LDS_BYTES = IMAGE_BYTES + 1024;         // + the fused scan's radix-select histogram
-constexpr int HB = 61568;                             // added to M0 where offset + base would not fit 16 bits
-static_assert(15 * 256 + HB <= 65535 && 31 * 4 * RQ - HB <= 65535 && 16 * 4 * RQ - HB >= 0, "rows 16..31: M0 / offset split");
-static_assert(15 * 4 * RQ + 4032 <= 65535 && 4 * 16 * RQ + 15 * 256 - 4032 <= 65535, "exchange 1, odd slots: M0 / offset split");
+constexpr int HB = 61692;                             // own territory, rows >= 16: added to M0 so that the offset fits 16 bits
+constexpr int XB = 3972;                              // exchange 1, odd slots: likewise
+static_assert(HB % 4 == 0 && 15 * 256 + HB <= 65535 && 31 * 4 * RQ - HB <= 65535 && 16 * 4 * RQ - HB >= 0,
+              "rows 16..31: M0 / offset split");
+static_assert(XB % 4 == 0 && 15 * 4 * RQ + XB <= 65535 && 4 * 16 * RQ + 15 * 256 - XB <= 65535 && 4 * 16 * RQ - XB >= 0,
+              "exchange 1, odd slots: M0 / offset split");
+// legs of the next row requested from inside pass 2's last level, two per unit (of 16); the rest behind the scan
+constexpr int PIPE_UNITS = 6;
+// share of the next row's window coefficients requested right behind the window stage (quads of 8)
+constexpr int WIN_EARLY = 2;
 
-// exchange 1, the four slots q, q+1, q+16, q+17 (q even) a last-level pair finishes: even slots from M0 = ma = 4100 w,
-// odd slots from mb = ma + 4032
+// column of thread position t in pass 0 (see the header); the window table is laid out with it (stft32k_window_layout)
+__host__ __device__ constexpr int column(int t)
+{
+    const int l = t & 63, j = l & 31;
+    return (t & ~63) + 2 * ((j >> 1) + 16 * (j & 1)) + (l >> 5);
+}
+
+// exchange 1, the four slots q, q+1, q+16, q+17 (q even) a last-level pair finishes: even slots from M0 = ma = 4104 w,
+// odd slots from mb = ma + XB
 template <int Q>
 __device__ __forceinline__ void x1_write_pair(unsigned ma, unsigned mb, float s_q, float s_q1, float s_q16, float s_q17)
 {
     static_assert(Q % 2 == 0 && Q < 16, "slot algebra");
-    constexpr int E = 256 * (Q >> 1), O = 4 * 16 * RQ - 4032 + 256 * (Q >> 1);
+    constexpr int E = 256 * (Q >> 1), O = 4 * 16 * RQ - XB + 256 * (Q >> 1);
     addtid_write4<E, E + 2048, O, O + 2048>(ma, mb, s_q, s_q16, s_q1, s_q17);
 }
 // a whole plane of exchange 1: f(k0) for the 32 slots
 template <typename F> __device__ __forceinline__ void x1_write_plane(unsigned ma, unsigned mb, F f)
 {
-    constexpr int O = 4 * 16 * RQ - 4032;
+    constexpr int O = 4 * 16 * RQ - XB;
     addtid_write8<0, 256, 512, 768, 1024, 1280, 1536, 1792>(ma, f(0), f(2), f(4), f(6), f(8), f(10), f(12), f(14));
     addtid_write8<2048, 2304, 2560, 2816, 3072, 3328, 3584, 3840>(ma, f(16), f(18), f(20), f(22), f(24), f(26), f(28), f(30));
     addtid_write8<O, O + 256, O + 512, O + 768, O + 1024, O + 1280, O + 1536, O + 1792>(mb, f(1), f(3), f(5), f(7), f(9), f(11),
@@ -116,14 +102,14 @@ template <typename F> __device__ __forceinline__ void x1_write_plane(unsigned ma
     addtid_write8<O + 2048, O + 2304, O + 2560, O + 2816, O + 3072, O + 3328, O + 3584, O + 3840>(
         mb, f(17), f(19), f(21), f(23), f(25), f(27), f(29), f(31));
 }
-// rows q, q+1, q+16, q+17 of the wave's own territory (exchange 2 and the image): rows < 16 from M0 = mc = 256 w,
-// rows >= 16 from md = mc + HB
-template <int Q>
-__device__ __forceinline__ void own_write_pair(unsigned mc, unsigned md, float s_q, float s_q1, float s_q16, float s_q17)
+// rows QA, QB (< 16) and QC, QD (>= 16) of the wave's own territory (exchange 2 and the image): rows < 16 from
+// M0 = mc = 256 w, rows >= 16 from md = mc + HB
+template <int QA, int QB, int QC, int QD>
+__device__ __forceinline__ void own_write4(unsigned mc, unsigned md, float sa, float sb, float sc, float sd)
 {
-    static_assert(Q % 2 == 0 && Q < 16, "slot algebra");
+    static_assert(QA < 16 && QB < 16 && QC >= 16 && QD >= 16 && QC < 32 && QD < 32, "row algebra");
     constexpr int R = 4 * RQ;
-    addtid_write4<R * Q, R * (Q + 1), R * (Q + 16) - HB, R * (Q + 17) - HB>(mc, md, s_q, s_q1, s_q16, s_q17);
+    addtid_write4<R * QA, R * QB, R * QC - HB, R * QD - HB>(mc, md, sa, sb, sc, sd);
 }
 template <typename F> __device__ __forceinline__ void own_write_plane(unsigned mc, unsigned md, F f)
 {
@@ -144,16 +130,29 @@ struct ImageRow {
     {
         const int k = (c + N / 2) & (N - 1), r = k >> 10, beta = k & 1023;
         const int w = (beta & 31) >> 1, kb = beta & 1, k1 = beta >> 5;
-        return img[RQ * r + 64 * w + ((k1 - 4 * (w >> 1)) & 31) + 32 * kb];
+        return img[RQ * r + 64 * w + 2 * ((k1 - 4 * (w >> 1)) & 31) + kb];
     }
 };
 
-typedef const volatile __attribute__((address_space(3))) float lds_vfloat;
+typedef const volatile __attribute__((address_space(3))) v2f lds_vpair;
+
+// levels 1..3 of dit<32> in level order behind a level 0 the caller has done itself, with the hook of dit32_head
+template <typename F> __device__ __forceinline__ void dit32_levels123(v2f *v, F hook)
+{
+    const v2f *tok = &v[31];
+    dit_level_order<1>(v, tok, std::make_integer_sequence<int, 2>{});
+    hook(std::integral_constant<int, 1>{});
+    dit_level_order<2>(v, tok, std::make_integer_sequence<int, 4>{});
+    hook(std::integral_constant<int, 2>{});
+    dit_level_order<3>(v, tok, std::make_integer_sequence<int, 8>{});
+    hook(std::integral_constant<int, 3>{});
+}
 
 template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using S = Sample<FMT>;
+    using namespace planar;
 
     // XCD-aware placement: workgroups b and b+8 share an XCD (round-robin dispatch), so each XCD gets one contiguous
     // run of rows and its workgroups take consecutive rows of it at the same time -- consecutive rows share
@@ -175,9 +174,8 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
 
     // ---- sample loads.  Lanes l and l + 32 of a wave share two neighbouring columns: lane l < 32 fetches both for
     // legs 0..15, lane l + 32 for legs 16..31, 16 bytes per load (v[k] / v[16 + k] = even / odd column of the leg);
-    // the window stage multiplies them in place and v_permlane32_swap gives every lane one whole column:
-    // position t of the workgroup ends up with column (t & ~63) + 2 (t & 31) + ((t >> 5) & 1).
-    const int po = (((tid & ~63) + 2 * (tid & 31)) + ((tid >> 5) & 1) * H * (N / 32)) * S::BYTES;
+    // v_permlane32_swap gives every lane one whole column, column(t).
+    const int po = (column(tid & ~32) + ((tid >> 5) & 1) * H * (N / 32)) * S::BYTES;
     auto row_rsrc = [&](int64_t k, bool valid) {
         return make_rsrc(iq + (a.first_row + k) * (int64_t)a.hop * S::BYTES, valid ? (unsigned)N * S::BYTES : 0u);
     };
@@ -186,40 +184,38 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
 #pragma unroll
         for (int k = 0; k < H; ++k) S::load_pair(rs, po, k * (N / 32) * S::BYTES, v[k], v[H + k]);
     }
-    // window coefficients in the kernel's own order (StftArgs::window_k, stft_window_layout): 16 bytes per lane =
-    // {even, odd column of leg k, even, odd column of leg k + 1}
+    // window coefficients in the kernel's own order (StftArgs::window_k32, stft32k_window_layout): quad q of a thread =
+    // the coefficients of legs {2q, 2q + 16, 2q + 1, 2q + 17} of its column -- the two butterflies (2q, 2q + 16) and
+    // (2q + 1, 2q + 17) of pass 0's first level, which takes the window multiply in
     v4f w4[H / 2];
     auto load_window = [&](const __amdgpu_buffer_rsrc_t &rs_win, auto first_c, auto last_c) {
         constexpr int first = decltype(first_c)::value, last = decltype(last_c)::value;
 #pragma unroll
-        for (int k = first; k < last; k += 2) {
-            if constexpr (RO_K32_ABLATE & 2) { w4[k / 2] = (v4f){0.5f, 0.25f, 0.5f, 0.25f}; continue; }
-            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_win, tid * 16, (k / 2) * T * 16, 0);
-            w4[k / 2] = (v4f){__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
+        for (int q = first; q < last; ++q) {
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_win, tid * 16, q * T * 16, 0);
+            w4[q] = (v4f){__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
         }
     };
-    constexpr int NW_EARLY = ((H * RO_K32_WIN_EARLY_PCT) / 100) & ~1;
     using c0 = std::integral_constant<int, 0>;
-    using cE = std::integral_constant<int, NW_EARLY>;
-    using cN = std::integral_constant<int, H>;
-    auto win_rsrc = [&](bool valid) { return make_rsrc(a.window_k, valid ? N * 4 : 0); };
+    using cE = std::integral_constant<int, WIN_EARLY>;
+    using cN = std::integral_constant<int, H / 2>;
+    auto win_rsrc = [&](bool valid) { return make_rsrc(a.window_k32, valid ? N * 4 : 0); };
     load_window(win_rsrc(true), c0{}, cN{});
 
     // stage twiddles: {w, w^2} {w^4, w^8} {w^16, -} of butterfly k from the packed table (three 16-byte loads);
-    // fdit32 makes the other powers.  Pass 1: k = k0 (32 entries at unit 0), pass 2: k = k0 + 32 k1 (1024 at unit 96).
+    // the levels make the other powers.  Pass 1: k = k0 (32 entries at unit 0), pass 2: k = k0 + 32 k1 (1024 at unit 96).
     v2f tw1[5], tw2[5];
     auto tw_load = [&](v2f (&t)[5], int k, auto pk_c, auto ns_c) {
         constexpr int PK = decltype(pk_c)::value, NS = decltype(ns_c)::value;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            if constexpr (RO_K32_ABLATE & 1) { t[2 * q] = (v2f){0.6f, 0.8f}; if (q < 2) t[2 * q + 1] = (v2f){0.8f, 0.6f}; continue; }
             const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_twk, k * 16, (PK + q * NS) * 16, 0);
             t[2 * q] = (v2f){__uint_as_float(u.x), __uint_as_float(u.y)};
             if (q < 2) t[2 * q + 1] = (v2f){__uint_as_float(u.z), __uint_as_float(u.w)};
         }
     };
 
-    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
+    [[maybe_unused]] unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
     auto stamp = [&](int k) {
         if constexpr (RO_STAMPS32K) {
             unsigned long long t;
@@ -238,45 +234,25 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
     unsigned prev_bytes = 0;
     unsigned touch = 0;
     // chunk q of the image: bins 4 m .. 4 m + 3 of segment r = 4 q + (tid >> 8), m = tid & 255, sit in the territories of
-    // waves 2 (m & 7) and 2 (m & 7) + 1 (two lanes each); out as 1 KiB per wave-instruction; bin k leaves for column
-    // (k + N/2) mod N (src/WaterfallBackend.cpp:492-505)
+    // waves 2 (m & 7) (bins 4 m, 4 m + 1: neighbouring cells) and 2 (m & 7) + 1; out as 1 KiB per wave-instruction; bin k
+    // leaves for column (k + N/2) mod N (src/WaterfallBackend.cpp:492-505)
     // (ONE register holds the thread's chunk-0 address for the whole kernel; laundered per chunk, else hipcc keeps all
-    // eight chunk addresses alive through the row -- and recomputed from tid per chunk it cost ~100 VALU ops per row)
-    int rb_base = RQ * (tid >> 8) + 128 * (tid & 7) + ((((tid & 255) >> 3) - 4 * (tid & 7)) & 31);
+    // eight chunk addresses alive through the row)
+    int rb_base = RQ * (tid >> 8) + 128 * (tid & 7) + 2 * ((((tid & 255) >> 3) - 4 * (tid & 7)) & 31);
     auto store_chunk = [&](int q, const __amdgpu_buffer_rsrc_t &rs) {
         int rb = rb_base;
         asm volatile("" : "+v"(rb));
-        const float *p = lds + rb + 4 * RQ * q;
-        const float x0 = p[0], x1 = p[32], x2 = p[64], x3 = p[96];
-        if constexpr (RO_K32_ABLATE & 16) asm volatile("" ::"v"(x0), "v"(x1), "v"(x2), "v"(x3));
-        else buf_store_f4(x0, x1, x2, x3, rs, tid * 16, ((q * T * 4 + N / 2) & (N - 1)) * 4);
+        lds_vpair *p = (lds_vpair *)(lds + rb + 4 * RQ * q);
+        const v2f x01 = p[0], x23 = p[32];
+        buf_store_f4(x01.x, x01.y, x23.x, x23.y, rs, tid * 16, ((q * T * 4 + N / 2) & (N - 1)) * 4);
     };
-    auto prio = [&](auto pc) {
-        constexpr int P = decltype(pc)::value;
-        if constexpr (RO_K32_PRIO == 1) __builtin_amdgcn_s_setprio(P);
-    };
-    // RO_K32_PRIO 3 / 4: one step per butterfly LEVEL (3: passes 1 and 2, 4: pass 0 as well): level n of the row runs at
-    // priority 3 - (n mod 4), so a wave that is a level behind outranks the waves ahead of it
-    auto lprio = [&](auto nc) {
-        constexpr int n = decltype(nc)::value;
-        if constexpr (RO_K32_PRIO == 4 || (RO_K32_PRIO == 3 && n >= 5)) __builtin_amdgcn_s_setprio(3 - (n & 3));
-    };
-    if constexpr (RO_K32_PRIO == 2) {
-        if (wave >= 12) __builtin_amdgcn_s_setprio(3);
-        else if (wave >= 8) __builtin_amdgcn_s_setprio(2);
-        else if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-    }
-    using p0 = std::integral_constant<int, 0>;
-    using p1 = std::integral_constant<int, 1>;
-    using p2 = std::integral_constant<int, 2>;
-    using p3 = std::integral_constant<int, 3>;
 
-    const unsigned ma = (unsigned)wave * (4u * RQ), mb = ma + 4032u;      // exchange 1: M0 of the even / odd slots
-    const unsigned mc = (unsigned)wave * 256u, md = mc + (unsigned)HB;    // own territory: M0 of rows < 16 / >= 16
+    const unsigned ma = (unsigned)wave * (4u * RQ), mb = ma + (unsigned)XB;   // exchange 1: M0 of the even / odd slots
+    const unsigned mc = (unsigned)wave * 256u, md = mc + (unsigned)HB;        // own territory: M0 of rows < 16 / >= 16
 
     for (;;) {
         const __amdgpu_buffer_rsrc_t rs_prev = make_rsrc(prev_out, prev_bytes);
-        // ---- window (coefficients and samples were requested a whole epilogue ago)
+        // ---- every lane gets its column (the samples were requested a whole epilogue ago)
         {
             const v2f gain2 = (v2f){0.0f, a.gain};          // src/FFTBackend.cpp:78-79: Q += gain
             if (a.gain != 0.0f) {                           // every shipped config has iq_gain = 0: skip the adds
@@ -286,18 +262,28 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
 #pragma unroll
             for (int k = 0; k < H; ++k) {
                 v2f &lo = v[k], &hi = v[H + k];
-                const v4f c4 = w4[k / 2];
-                const v2f e = lo * ((k & 1) ? c4.zz : c4.xx);          // even column, leg k (16 + k on lanes >= 32)
-                const v2f o = hi * ((k & 1) ? c4.ww : c4.yy);          // odd column
                 // lanes 0..31 hold legs k, lanes 32..63 legs 16 + k of both columns: the upper half of slot k trades
                 // places with the lower half of slot 16 + k
-                const auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(e.x), __float_as_uint(o.x), false, false);
-                const auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(e.y), __float_as_uint(o.y), false, false);
+                const auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo.x), __float_as_uint(hi.x), false, false);
+                const auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo.y), __float_as_uint(hi.y), false, false);
                 lo = (v2f){__uint_as_float(rx[0]), __uint_as_float(ry[0])};
                 hi = (v2f){__uint_as_float(rx[1]), __uint_as_float(ry[1])};
             }
         }
         asm volatile("" ::"v"(touch));                       // see touch_next
+        // ---- pass 0, level 0 with the window multiply in it (src/FFTBackend.cpp:229-232):
+        //   (x_i w_i + x_{i+16} w_{i+16},  x_i w_i - x_{i+16} w_{i+16})  =  t = x_i w_i;  fma(x_{i+16}, +-w_{i+16}, t)
+        // three packed operations where multiply, multiply, add, subtract are four
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            const v4f c4 = w4[i / 2];
+            const v2f wi = (i & 1) ? c4.zz : c4.xx, wj = (i & 1) ? c4.ww : c4.yy;
+            const v2f t = v[i] * wi;
+            const v2f s = __builtin_elementwise_fma(v[H + i], wj, t);
+            v[H + i] = __builtin_elementwise_fma(v[H + i], -wj, t);
+            v[i] = s;
+            if (i & 1) planar::leash();
+        }
         const int64_t next = row + stride;
         const bool has_next = next < xcd_end;
         // the first coefficients of the NEXT row right away: their registers are free for the whole transform
@@ -313,20 +299,25 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
         };
         stamp(0);
 
-        // ---- pass 0, levels 0..3; the previous row's image goes out between them (LDS read-back + 16-byte stores)
-        lprio(std::integral_constant<int, 0>{});
-        dit32_head(v, [&](auto hc) {
+        // ---- pass 0, levels 1..3; the previous row's image goes out between them (LDS read-back + 16-byte stores)
+        store_chunk(0, rs_prev);
+        store_chunk(1, rs_prev);
+        dit32_levels123(v, [&](auto hc) {
             constexpr int h = decltype(hc)::value;
             store_chunk(2 * h, rs_prev);
             store_chunk(2 * h + 1, rs_prev);
-            lprio(std::integral_constant<int, h + 1>{});
         });
-        if constexpr (RO_K32_TW1_SCALAR) {
-            // pass-1 twiddles depend on k0 only -- two values per wave: scalar loads (the scalar cache, not the vector
-            // memory pipe, which at this point is busy with the row's samples) and one select per register
+        int lane;
+        {
             int lt = tid;
             asm volatile("" : "+v"(lt));
-            const bool odd = (lt >> 4) & 1;
+            lane = lt & 63;
+        }
+        {
+            // pass-1 twiddles depend on k0 only -- two values per wave (lanes < 32: k0 = 2 w, the others 2 w + 1): scalar
+            // loads (the scalar cache, not the vector memory pipe, which at this point is busy with the row's samples)
+            // and one select per register
+            const bool odd = lane >= 32;
             const float4 *tk = a.twiddles_k + 2 * wave;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
@@ -340,10 +331,6 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
                 tw1[2 * q] = (v2f){odd ? o.x : e.x, odd ? o.y : e.y};
                 if (q < 2) tw1[2 * q + 1] = (v2f){odd ? o.z : e.z, odd ? o.w : e.w};
             }
-        } else {
-            int lt = tid;
-            asm volatile("" : "+v"(lt));
-            tw_load(tw1, 2 * wave + ((lt >> 4) & 1), std::integral_constant<int, 0>{}, std::integral_constant<int, 32>{});
         }
         stamp(1);
         wg_sync();                              // (a) every wave has read its part of the old image: LDS is free
@@ -351,117 +338,114 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
         // ---- pass 0, last level: the x plane of exchange 1 leaves as the pairs finish
         dit32_last(v, [&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            if constexpr (!(RO_K32_ABLATE & 4)) x1_write_pair<bitrev<32>(2 * j)>(ma, mb, v[2 * j].x, v[16 + 2 * j].x, v[2 * j + 1].x, v[17 + 2 * j].x);
+            x1_write_pair<bitrev<32>(2 * j)>(ma, mb, v[2 * j].x, v[16 + 2 * j].x, v[2 * j + 1].x, v[17 + 2 * j].x);
             return v[17 + 2 * j].y;
         });
         stamp(3);
-        // ---- exchange 1, the rest: thread (k0, a) of pass 1 reads slot b from its own territory
+        // ---- exchange 1, the rest: thread (k0, a) of pass 1 reads slots b = 2 w', 2 w' + 1 (one ds_read_b64) from its own
+        // territory, for the sixteen writer waves w'
+        v2f R[16], I[16];
         {
-            int lt = tid;
-            asm volatile("" : "+v"(lt));
-            const int l = lt & 63;
-            lds_vfloat *g1 = (lds_vfloat *)(lds + RQ * 16 * ((l >> 4) & 1) + 64 * wave + (l & 15) + 32 * (l >> 5));
-            auto off = [](int b) constexpr { return RQ * (b >> 1) + 16 * (b & 1); };
+            lds_vpair *g1 = (lds_vpair *)(lds + RQ * 16 * (lane >> 5) + 64 * wave + 2 * (lane & 15) + 32 * ((lane >> 4) & 1));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the x-plane writes (hipcc does not count them)
             __builtin_amdgcn_s_barrier();                                // (b)
             asm volatile("" ::: "memory");
 #pragma unroll
-            for (int b = 0; b < 32; ++b) if constexpr (!(RO_K32_ABLATE & 4)) v[b].x = g1[off(b)];
+            for (int i = 0; i < 16; ++i) R[i] = g1[(RQ / 2) * i];
             wg_sync();                                                   // (c) everyone has its x: the plane may go
-            if constexpr (!(RO_K32_ABLATE & 4)) x1_write_plane(ma, mb, [&](int k0) { return v[bitrev<32>(k0)].y; });
+            x1_write_plane(ma, mb, [&](int k0) { return v[bitrev<32>(k0)].y; });
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                // (d)
             asm volatile("" ::: "memory");
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {                               // in the order level 0 of pass 1 pairs them
-                if constexpr (RO_K32_ABLATE & 4) continue;
-                v[i].y = g1[off(i)];
-                v[i + 16].y = g1[off(i + 16)];
+            for (int i = 0; i < 8; ++i) {                                // in the order level 0 of pass 1 pairs them
+                I[i] = g1[(RQ / 2) * i];
+                I[i + 8] = g1[(RQ / 2) * (i + 8)];
             }
         }
         stamp(4);
-        // ---- pass 1.  From here to the completed image the wave is on its own.
-        prio(p3{});
-        lprio(std::integral_constant<int, 5>{});
-        fdit32_head(v, tw1[4], tw1[3], tw1[2], tw1[1], [&](auto hc) { lprio(std::integral_constant<int, 6 + decltype(hc)::value>{}); });
+        // ---- pass 1 (mates b, b + 1: planar<0>).  From here to the completed image the wave is on its own.
+        planar::head<0>(R, I, tw1[4], tw1[3], tw1[2], tw1[1]);
         touch_next();
         int k1p, kbp;                                                    // this thread in pass 2: (k0 = 2 wave + kbp, k1 = k1p)
         {
-            int lt = tid;
-            asm volatile("" : "+v"(lt));
-            k1p = ((lt & 31) + 4 * (wave >> 1)) & 31;
-            kbp = (lt >> 5) & 1;
+            k1p = ((lane >> 1) + 4 * (wave >> 1)) & 31;
+            kbp = lane & 1;
             tw_load(tw2, 2 * wave + kbp + 32 * k1p, std::integral_constant<int, 96>{}, std::integral_constant<int, 1024>{});
         }
         stamp(5);
-        prio(p2{});
-        fdit32_last(v, tw1[0], [&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            if constexpr (!(RO_K32_ABLATE & 4)) own_write_pair<bitrev<32>(2 * j)>(mc, md, v[2 * j].x, v[16 + 2 * j].x, v[2 * j + 1].x, v[17 + 2 * j].x);
-            return v[17 + 2 * j].y;
+        planar::last0(R, I, tw1[0], [&](auto jc) {
+            // positions 2j, 2j + 1 (pair j) and 16 + 2j, 17 + 2j (pair 8 + j) are final: results k1 = q, q + 16, q + 1,
+            // q + 17 with q = bitrev32(2j); their real parts leave for exchange 2
+            constexpr int j = decltype(jc)::value, q = bitrev<32>(2 * j);
+            own_write4<q, q + 1, q + 16, q + 17>(mc, md, R[j].x, R[8 + j].x, R[j].y, R[8 + j].y);
         });
         stamp(6);
         // ---- exchange 2: a 32 x 32 transposition inside each half of the wave, through the wave's own rows.  One
         // wave's LDS instructions execute in order: no wait between its writes and its reads of the same cells.
+        v2f R2[16], I2[16];
         {
-            lds_vfloat *g2 = (lds_vfloat *)(lds + RQ * k1p + 64 * wave + 16 * kbp);
-            auto off = [](int s) constexpr { return (s >> 1) + 32 * (s & 1); };
+            lds_vpair *g2 = (lds_vpair *)(lds + RQ * k1p + 64 * wave + 32 * kbp);
             asm volatile("" ::: "memory");
 #pragma unroll
-            for (int s = 0; s < 32; ++s) if constexpr (!(RO_K32_ABLATE & 4)) v[s].x = g2[off(s)];
+            for (int i = 0; i < 16; ++i) R2[i] = g2[(i >> 1) + 8 * (i & 1)];          // pair 2u + p: cells 2u + 16p, + 1
             asm volatile("" ::: "memory");
-            if constexpr (!(RO_K32_ABLATE & 4)) own_write_plane(mc, md, [&](int k1) { return v[bitrev<32>(k1)].y; });
+            own_write_plane(mc, md, [&](int k1) {
+                constexpr int MB = 0;
+                const int p = bitrev<32>(k1);
+                return hf<MB>(p) ? I[pr<MB>(p)].y : I[pr<MB>(p)].x;
+            });
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if constexpr (RO_K32_ABLATE & 4) continue;
-                v[i].y = g2[off(i)];
-                v[i + 16].y = g2[off(i + 16)];
-            }
+            for (int i = 0; i < 16; ++i) I2[i] = g2[(i >> 1) + 8 * (i & 1)];
         }
         stamp(7);
-        // ---- pass 2
-        prio(p1{});
-        lprio(std::integral_constant<int, 10>{});
-        fdit32_head(v, tw2[4], tw2[3], tw2[2], tw2[1], [&](auto hc) { lprio(std::integral_constant<int, 11 + decltype(hc)::value>{}); });
-        prio(p0{});
+        // ---- pass 2 (mates a, a + 2: planar<1>)
+        planar::head<1>(R2, I2, tw2[4], tw2[3], tw2[2], tw2[1]);
         stamp(8);
         {
-            // Last level with the epilogue folded in.  After butterflies (j, 8 + j) x[2j], x[2j+1], x[16+2j], x[17+2j]
-            // are final = bins k0 + 32 k1 + 1024 q for q = qj, qj+16, qj+1, qj+17 (qj = bitrev32(2j)): their magnitudes
-            // go to rows q of the wave's territory, and the four freed registers receive legs 2j, 2j+1 of the NEXT
-            // row's samples -- for j < PIPE_J; the last legs are requested behind the scan.
+            // Last level with the epilogue folded in.  After unit u positions 4u .. 4u + 3 are final = bins
+            // k0 + 32 k1 + 1024 k2 for k2 = r, r + 8 (pair 2u) and r + 16, r + 24 (pair 2u + 1), r = bitrev8(u): their
+            // magnitudes go to those rows of the wave's territory, and the eight freed registers receive legs 2u, 2u + 1
+            // of the NEXT row's samples -- for u < PIPE_UNITS; the last legs are requested behind the scan.
             const __amdgpu_buffer_rsrc_t rs_next = row_rsrc(has_next ? next : row, has_next);   // zero-sized after the last row
-            // The image writes of pair j are issued one pair late (from done(j + 1), the last ones behind the level):
+            // The image writes of unit u are issued one unit late (from done(u + 1), the last ones behind the level):
             // v_sqrt_f32 runs in the transcendental pipe and hipcc pads no hazards in front of inline asm.
-            float pm0 = 0.f, pm1 = 0.f, pm16 = 0.f, pm17 = 0.f;
-            fdit32_last(v, tw2[0], [&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                auto mag = [](v2f x) { const v2f sq = x * x; return __builtin_amdgcn_sqrtf(sq.x + sq.y); };
-                const float m0 = mag(v[2 * j]), m16 = mag(v[2 * j + 1]);
-                const float m1 = mag(v[16 + 2 * j]), m17 = mag(v[17 + 2 * j]);
-                if constexpr (j > 0) own_write_pair<bitrev<32>(2 * (j > 0 ? j - 1 : 0))>(mc, md, pm0, pm1, pm16, pm17);
-                pm0 = m0; pm1 = m1; pm16 = m16; pm17 = m17;
-                if constexpr (j < RO_K32_PIPE_J) {
-                    const int pj = after(po, m17);      // the loads may not start before these magnitudes exist
-                    S::load_pair(rs_next, pj, (2 * j) * (N / 32) * S::BYTES, v[2 * j], v[H + 2 * j]);
-                    S::load_pair(rs_next, pj, (2 * j + 1) * (N / 32) * S::BYTES, v[2 * j + 1], v[H + 2 * j + 1]);
+            v2f pma = {0.f, 0.f}, pmb = {0.f, 0.f};
+            planar::last1(R2, I2, tw2[0], [&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                // |X| = sqrt(re^2 + im^2) (src/WaterfallBackend.cpp:497-503), two bins per packed operation
+                auto mag = [](v2f re, v2f im) {
+                    const v2f s = __builtin_elementwise_fma(im, im, re * re);
+                    return (v2f){__builtin_amdgcn_sqrtf(s.x), __builtin_amdgcn_sqrtf(s.y)};
+                };
+                const v2f m_a = mag(R2[2 * u], I2[2 * u]), m_b = mag(R2[2 * u + 1], I2[2 * u + 1]);
+                if constexpr (u > 0) {
+                    constexpr int r = bitrev<8>(u > 0 ? u - 1 : 0);
+                    own_write4<r, r + 8, r + 16, r + 24>(mc, md, pma.x, pma.y, pmb.x, pmb.y);
                 }
-                return m17;
+                pma = m_a;
+                pmb = m_b;
+                if constexpr (u < PIPE_UNITS) {
+                    const int pj = after(po, m_b.y);    // the loads may not start before these magnitudes exist
+                    S::load_pair(rs_next, pj, (2 * u) * (N / 32) * S::BYTES, v[2 * u], v[H + 2 * u]);
+                    S::load_pair(rs_next, pj, (2 * u + 1) * (N / 32) * S::BYTES, v[2 * u + 1], v[H + 2 * u + 1]);
+                }
             });
             asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // the last square roots: see above
-            own_write_pair<bitrev<32>(14)>(mc, md, pm0, pm1, pm16, pm17);
+            {
+                constexpr int r = bitrev<8>(7);
+                own_write4<r, r + 8, r + 16, r + 24>(mc, md, pma.x, pma.y, pmb.x, pmb.y);
+            }
             // The legs the last level did not request and the rest of the window coefficients.  The waves reach this
             // point up to ~6k cycles apart (the oldest wave of a SIMD first) and then wait for the barrier: whoever is
             // not about to scan asks NOW, so the memory pipe works through most of the next row's 384 KiB while the
             // younger waves are still in their butterflies, instead of starting behind the barrier with all 16 waves
             // in its queue.  (The two scanning waves need these registers for their band.)
             // who has work on the image behind the barrier: waves 0, 1 scan, waves 2, 3 cut the band tile
-            const bool image_work = RO_K32_EARLY_LOADS ? ((a.records != nullptr && wave < 2) ||
-                                                          (a.tile_out != nullptr && (wave == 2 || wave == 3)))
-                                                       : true;
+            const bool image_work = (a.records != nullptr && wave < 2) || (a.tile_out != nullptr && (wave == 2 || wave == 3));
             auto late_loads = [&]() {
 #pragma unroll
-                for (int k = 2 * RO_K32_PIPE_J; k < H; ++k)
+                for (int k = 2 * PIPE_UNITS; k < H; ++k)
                     S::load_pair(rs_next, po, k * (N / 32) * S::BYTES, v[k], v[H + k]);
                 load_window(win_rsrc(has_next), cE{}, cN{});
             };
@@ -484,8 +468,8 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
                 // limits is laundered through empty asm: otherwise hipcc hoists those loop invariants in front of the row
                 // loop, where they sit in VGPRs of all 16 waves for the whole row.
                 {
-                    int lane = tid & 63;
-                    asm volatile("" : "+v"(lane));
+                    int sl = tid & 63;
+                    asm volatile("" : "+v"(sl));
                     const ImageRow img{lds};
                     if (a.records != nullptr && wave < 2) {
                         int low_noise = a.low_noise, noise_width = a.noise_width, low_detect = a.low_detect;
@@ -494,13 +478,13 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
                         if (wave == 0) {
                             unsigned *hist = reinterpret_cast<unsigned *>(smem + IMAGE_BYTES);
                             // bands up to 512 columns (the shipped configs: 409 / 410) keep their keys in registers
-                            const float nz = noise_width <= 512 ? scan_noise<8>(img, low_noise, noise_width, hist, lane)
-                                                                : scan_noise<0>(img, low_noise, noise_width, hist, lane);
-                            if (lane == 0) a.records[row].noise = nz;
+                            const float nz = noise_width <= 512 ? scan_noise<8>(img, low_noise, noise_width, hist, sl)
+                                                                : scan_noise<0>(img, low_noise, noise_width, hist, sl);
+                            if (sl == 0) a.records[row].noise = nz;
                         } else {
-                            const int pk = scan_peak<8>(img, low_detect, detect_width, lane);
-                            const float av = scan_average(img, low_detect + pk - avg_bins / 2, avg_bins, N, lane);
-                            if (lane == 0) {
+                            const int pk = scan_peak<8>(img, low_detect, detect_width, sl);
+                            const float av = scan_average(img, low_detect + pk - avg_bins / 2, avg_bins, N, sl);
+                            if (sl == 0) {
                                 a.records[row].peak = pk;
                                 a.records[row].average = av;
                             }
@@ -514,13 +498,13 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
                         const int c1 = wave == 2 ? (half < tile_cols ? half : tile_cols) : tile_cols;
                         float *dst = a.tile_out + row * (int64_t)tile_cols;
                         if (a.ln_out == nullptr) {
-                            for (int c = c0 + lane; c < c1; c += 64) dst[c] = img(tile_first + c);
+                            for (int c = c0 + sl; c < c1; c += 64) dst[c] = img(tile_first + c);
                         } else {
                             // the viewer's log image of the tile (fits2png:46) and this wave's share of the row's min /
                             // max over the non-zero pixels (:476-477), while the magnitudes are still in LDS
                             float *ldst = a.ln_out + row * (int64_t)tile_cols;
                             unsigned kmin = 0xffffffffu, kmax = 0u;
-                            for (int c = c0 + lane; c < c1; c += 64) {
+                            for (int c = c0 + sl; c < c1; c += 64) {
                                 const float x = img(tile_first + c);
                                 const float l = logf(x);
                                 dst[c] = x;
@@ -533,7 +517,7 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
                             }
                             kmin = wave_min_u32(kmin);
                             kmax = wave_max_u32(kmax);
-                            if (lane == 0) {
+                            if (sl == 0) {
                                 float *part = a.ln_part + row * 4 + (wave == 2 ? 0 : 2);
                                 part[0] = kmin == 0xffffffffu ? __builtin_inff() : key_to_float(kmin);
                                 part[1] = kmax == 0u ? -__builtin_inff() : key_to_float(kmax);
@@ -547,7 +531,7 @@ template <int FMT> __global__ __launch_bounds__(T, 1) void stft32k_kernel(StftAr
         stamp(11);
         prev_out = a.rows_out + row * a.row_stride;
         prev_bytes = N * 4;
-        st_acc[15] += 1;
+        if constexpr (RO_STAMPS32K) st_acc[15] += 1;
         if (!has_next) break;
         row = next;
     }
@@ -611,10 +595,27 @@ template <int FMT> static hipError_t launch_fmt(const StftArgs &a, hipStream_t s
 
 }  // namespace k32
 
+// StftArgs::window_k32 from the natural table: thread t of the kernel reads 16 bytes at (q T + t) 16, q < 8 =
+// {w[c + 1024 (2q)], w[c + 1024 (2q + 16)], w[c + 1024 (2q + 1)], w[c + 1024 (2q + 17)]}, c = its column
+void stft32k_window_layout(const float *w, float *out)
+{
+    using namespace k32;
+    for (int t = 0; t < T; ++t) {
+        const int c = column(t);
+        for (int q = 0; q < H / 2; ++q) {
+            float *o = out + ((size_t)q * T + t) * 4;
+            o[0] = w[c + 1024 * (2 * q)];
+            o[1] = w[c + 1024 * (2 * q + 16)];
+            o[2] = w[c + 1024 * (2 * q + 1)];
+            o[3] = w[c + 1024 * (2 * q + 17)];
+        }
+    }
+}
+
 hipError_t launch_stft32k(int fmt, const StftArgs &a, hipStream_t s)
 {
     if (a.rows <= 0) return hipSuccess;
-    if (a.spec_out != nullptr || a.big_form) return hipErrorInvalidValue;
+    if (a.spec_out != nullptr || a.big_form || a.window_k32 == nullptr) return hipErrorInvalidValue;
     if (fmt == RO_FMT_F32) return k32::launch_fmt<RO_FMT_F32>(a, s);
     if (fmt == RO_FMT_I16) return k32::launch_fmt<RO_FMT_I16>(a, s);
     return hipErrorInvalidValue;

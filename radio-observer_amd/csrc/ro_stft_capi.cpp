@@ -33,6 +33,13 @@
 #ifndef RO_SPEC_SCRATCH_MB
 #define RO_SPEC_SCRATCH_MB 2048
 #endif
+// RO_PRECISION_F64: MiB per complex-double scratch block (two blocks); the passes of one chunk run back to back, and a
+// chunk that stays inside the 256 MiB Infinity Cache keeps most of the trip between them off HBM: 2.75-2.80 x 10^6
+// rows/s at the C3 shape with 128 against 2.46 with 512, 2.36 with 256, 2.50 with 64, 1.96 with 32 (too few workgroups
+// per launch); the same bits whatever the chunk (profiles/r04_strict_chunk.txt, tools/r4/strict_sweep.py)
+#ifndef RO_F64_SCRATCH_MB
+#define RO_F64_SCRATCH_MB 128
+#endif
 
 namespace {
 
@@ -165,6 +172,7 @@ struct ro_stft {
     std::vector<float> window;
     float *d_window = nullptr;
     float *d_window_k = nullptr;       // kernel-order copy (single-pass plans)
+    float *d_window_k32 = nullptr;     // ... in the order of the N = 32768 magnitude-row kernel (bins = 32768)
     float2 *d_twiddles = nullptr;
     float4 *d_twiddles_k = nullptr;    // packed copy for the radix-16/32 stages
     hipStream_t stream = nullptr;
@@ -291,6 +299,7 @@ ro::StftArgs make_stft_args(const ro_stft *h, const void *d_iq, int64_t first_ro
     a.iq = d_iq;
     a.window = h->d_window;
     a.window_k = h->d_window_k;
+    a.window_k32 = h->d_window_k32;
     a.twiddles = h->d_twiddles;
     a.twiddles_k = h->d_twiddles_k;
     a.rows_out = d_rows;
@@ -421,6 +430,7 @@ int launch_spectra_big(ro_stft *h, const void *d_iq, int format, int64_t first_r
         ro::StftArgs a = make_stft_args(h, h->d_spec, 0, n * h->dec, nullptr, 0);
         a.window = h->d_ones;
         a.window_k = h->d_ones;
+        a.window_k32 = h->d_ones;
         a.hop = h->sub_bins;
         a.gain = 0.0f;
         a.spec_out = h->d_spec2;
@@ -491,7 +501,11 @@ int launch_transform_f64(ro_stft *h, const void *d_iq, int format, int64_t first
                          int64_t row_stride, hipStream_t s)
 {
     if (!h->d_scratch_d[0]) {
-        h->scratch_rows_d = std::max<int64_t>(1, ((int64_t)512 << 20) / ((int64_t)h->bins * 16));
+        int64_t mib = RO_F64_SCRATCH_MB;
+#ifdef RO_DIAG
+        if (const char *e = getenv("RO_F64_SCRATCH_MB")) mib = std::max(1, atoi(e));     // tools/r4/strict_sweep.sh
+#endif
+        h->scratch_rows_d = std::max<int64_t>(1, (mib << 20) / ((int64_t)h->bins * 16));
         for (int i = 0; i < 2; ++i)
             HIP_TRY(hipMalloc(&h->d_scratch_d[i], (size_t)h->scratch_rows_d * h->bins * sizeof(double2)));
     }
@@ -568,6 +582,7 @@ int launch_transform(ro_stft *h, const void *d_iq, int format, int64_t first_row
             ro::StftArgs a = make_stft_args(h, h->d_spec, 0, n * h->dec, h->d_mag, h->sub_bins);
             a.window = h->d_ones;
             a.window_k = h->d_ones;
+            a.window_k32 = h->d_ones;
             a.hop = h->sub_bins;
             a.gain = 0.0f;
             HIP_TRY(ro::launch_stft(h->sub_bins, RO_FMT_F32, a, s));
@@ -1197,6 +1212,11 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
         }
         CREATE_TRY(hipMalloc(&h->d_window_k, sizeof(float) * h->bins));
         CREATE_TRY(hipMemcpy(h->d_window_k, wk.data(), sizeof(float) * h->bins, hipMemcpyHostToDevice));
+        if (h->bins == 32768) {
+            ro::stft32k_window_layout(h->window.data(), wk.data());
+            CREATE_TRY(hipMalloc(&h->d_window_k32, sizeof(float) * h->bins));
+            CREATE_TRY(hipMemcpy(h->d_window_k32, wk.data(), sizeof(float) * h->bins, hipMemcpyHostToDevice));
+        }
     }
     if (!tw.empty())
         CREATE_TRY(hipMemcpy(h->d_twiddles, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice));
@@ -1328,6 +1348,7 @@ extern "C" int ro_stft_destroy(ro_stft_t *h)
     free_stream_slots(h);
     if (h->d_window) (void)hipFree(h->d_window);
     if (h->d_window_k) (void)hipFree(h->d_window_k);
+    if (h->d_window_k32) (void)hipFree(h->d_window_k32);
     if (h->d_ln_keys) (void)hipFree(h->d_ln_keys);
     if (h->d_twiddles) (void)hipFree(h->d_twiddles);
     if (h->d_twiddles_k) (void)hipFree(h->d_twiddles_k);

@@ -1,7 +1,8 @@
-"""The index algebra of stft32k_kernel's one LDS layout, replayed on the CPU: tools/r3/emu32k.py walks
-the kernel's three passes with the kernel's own lane / slot / cell maps on a random row and compares with numpy's fft;
-on the way it asserts that every gather is bank-conflict-free and that every add-TID write splits into a 16-bit M0
-and a 16-bit immediate.  The kernel itself is checked on the GPU (tests/test_gpu_*.py); this keeps the derivation it
+"""The index algebra of stft32k_kernel's one LDS layout, replayed on the CPU: tools/r4/emu32k.py walks
+the kernel's three passes with the kernel's own lane / slot / cell maps (and its window-table order) on a random row
+and compares with numpy's fft; on the way it asserts that every ds_read_b64 is aligned and bank-conflict-free and that
+every add-TID write splits into a 16-bit M0 and a 16-bit immediate.  It also runs the planar butterflies of
+csrc/ro_fft_planar.h -- with the VOP3P modifier strings parsed out of that header -- against the 32-point DFT.  The kernel itself is checked on the GPU (tests/test_gpu_*.py); this keeps the derivation it
 was written from under test, so a change of the layout is made there first."""
 import os
 import subprocess
@@ -10,24 +11,27 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(script, *args):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "r3", script), *args], capture_output=True, text=True,
+def run(script, *args, where="r3"):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", where, script), *args], capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     return r.stdout
 
 
 def test_stft32k_layout_reproduces_the_fft_without_bank_conflicts():
-    out = run("emu32k.py")
-    assert "exchange 1 gathers conflict-free: True" in out
-    assert "exchange 2 gathers conflict-free: True" in out
+    out = run("emu32k.py", where="r4")
+    assert "planar radix-32 stage (modifier strings from ro_fft_planar.h) == DFT32" in out
+    assert "exchange 1 reads (ds_read_b64) conflict-free: True" in out
+    assert "exchange 2 reads (ds_read_b64) conflict-free: True" in out
     assert "bins match numpy fft" in out
-    assert "read-back = fft-shifted row; conflict-free: True" in out
-    assert "LDS bytes: 131200" in out
+    assert "= fft-shifted row; conflict-free: True" in out
+    assert "ImageRow(c) = column c" in out
+    assert "LDS bytes: 131328" in out
 
 
 def test_the_general_form_agrees_at_32_points_per_wave_column():
-    """tools/r3/emu_wl.py is the same derivation for 32.32.S; at S = 32 it has to give stft32k_kernel's layout"""
+    """tools/r3/emu_wl.py is the derivation of round 3's layout (ds_read_b32 gathers, rows of 1025 floats) for 32.32.S;
+    it stays as the record of the experiment in tools/r3/ro_stft_wl.hip"""
     out = run("emu_wl.py", "32")
     assert "S=32 read-back = fft-shifted row; conflict-free: True" in out
     assert "S=32 closed-form image address: True; LDS bytes 131200" in out
