@@ -32,7 +32,7 @@ extern "C" {
 #define RO_ERR_NOMEM       (-4)
 #define RO_ERR_STATE       (-5)   /* call not valid in the handle's current state */
 
-#define RO_ABI_VERSION 2
+#define RO_ABI_VERSION 3
 
 /* window function; the reference hard-codes the 4-term Nuttall
  * (src/FFTBackend.cpp:165-184) and keeps Hann as dead code (:157-163). */
@@ -280,6 +280,21 @@ int ro_stft_flush(ro_stft_t *h, int64_t *rows_ready);
 int ro_stft_fetch(ro_stft_t *h, int64_t max_rows, int first_col, int cols,
                   float *rows_out, ro_scan_record_t *records_out,
                   int64_t *first_row_index, int64_t *rows_got);
+/* Row sink: the streaming path's rows go STRAIGHT into the caller's row ring instead of the handle's pinned batches --
+ * WaterfallBackend::processFFT writes each finished row into buffer_->push() (src/WaterfallBackend.cpp:488-505); with a
+ * sink the device-to-host copy of a batch is that write, and the ring's only copy.  Row r of the stream (counted from
+ * ro_stft_create / ro_stft_reset) lands at  base + ((first_slot + r) mod capacity_rows) * row_stride  floats: the
+ * handle's full rows, or its tile's columns when one is configured.  The ring has to be page-locked memory from
+ * ro_pinned_alloc (the copies are asynchronous) and has to stay allocated until the sink is removed (base = NULL) or
+ * the handle destroyed.  A row is in place once ro_stft_fetch has reported it
+ * (rows_out = NULL from then on: RO_ERR_STATE otherwise; the scan records still come through records_out), and the
+ * handle writes up to a batch of slots AHEAD of what has been fetched: capacity_rows >= 2 x max_batch_rows, and
+ * whoever reads old rows of the ring (snapshot writers) has to stay that far behind the head, as it has to for push().
+ * Only on an idle stream (RO_ERR_STATE otherwise); not for tile_ln handles (RO_ERR_UNSUPPORTED). */
+int ro_stft_set_row_sink(ro_stft_t *h, float *base, int64_t row_stride, int64_t capacity_rows, int64_t first_slot);
+/* page-locked host memory for such a ring (hipHostMalloc on `device`'s context); NULL when there is none to be had */
+void *ro_pinned_alloc(int device, size_t bytes);
+void  ro_pinned_free(void *p);
 /* ro_stft_fetch for a handle with tile_ln = 1: the whole tile of each row, its log, the row's min / max of the log
  * (2 floats) and the scan record -- any of the four may be NULL. */
 int ro_stft_fetch_ln(ro_stft_t *h, int64_t max_rows, float *tile_out, float *ln_out, float *minmax_out,

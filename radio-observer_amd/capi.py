@@ -110,6 +110,9 @@ _EXPORTS = {
     "ro_stft_fetch": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_float),
                                 C.POINTER(ScanRecord), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ro_stft_reset": (C.c_int, [C.c_void_p]),
+    "ro_stft_set_row_sink": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]),
+    "ro_pinned_alloc": (C.c_void_p, [C.c_int, C.c_size_t]),
+    "ro_pinned_free": (None, [C.c_void_p]),
     "ro_stft_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "ro_stft_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                 C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
@@ -143,6 +146,29 @@ def library():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+class PinnedArray:
+    """a float32 numpy view [rows, cols] of page-locked host memory from ro_pinned_alloc (freed with the object)"""
+
+    def __init__(self, rows, cols, device=0):
+        n = rows * cols * 4
+        self._p = library().ro_pinned_alloc(device, n)
+        if not self._p:
+            raise MemoryError("ro_pinned_alloc(%d bytes) failed" % n)
+        self.array = np.ctypeslib.as_array((C.c_float * (rows * cols)).from_address(self._p)).reshape(rows, cols)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            library().ro_pinned_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _check(rc):
@@ -407,6 +433,26 @@ class Stft:
 
     def reset(self):
         _check(library().ro_stft_reset(self._h))
+
+    def set_row_sink(self, ring, first_slot=0):
+        """ring: a C-contiguous float32 numpy array [capacity_rows, row_stride] that stays alive (and unmoved) while it
+        is the sink (pinned_array gives page-locked ones); None removes the sink"""
+        if ring is None:
+            _check(library().ro_stft_set_row_sink(self._h, None, 0, 0, 0))
+            self._sink = None
+            return
+        assert ring.dtype == np.float32 and ring.ndim == 2 and ring.flags["C_CONTIGUOUS"]
+        _check(library().ro_stft_set_row_sink(self._h, C.c_void_p(ring.ctypes.data), ring.shape[1], ring.shape[0], first_slot))
+        self._sink = ring
+
+    def fetch_records(self, max_rows):
+        """ro_stft_fetch with rows_out = NULL (the rows are in the sink): (first row index, rows got, records or None)"""
+        recs = np.empty(max_rows, dtype=SCAN_DTYPE) if self.scan_enabled else None
+        first, got = C.c_int64(), C.c_int64()
+        _check(library().ro_stft_fetch(self._h, max_rows, 0, 0, None,
+                                       recs.ctypes.data_as(C.POINTER(ScanRecord)) if recs is not None else None,
+                                       C.byref(first), C.byref(got)))
+        return first.value, got.value, (recs[:got.value] if recs is not None else None)
 
     def timing(self, reset=False):
         t = Timing()

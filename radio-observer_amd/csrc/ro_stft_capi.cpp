@@ -24,6 +24,11 @@
 #include "../../include/ro_stft.h"
 #include "ro_kernels.h"
 
+// a -DRO_DIAG=1 build (tools/ab_build.sh) reads its run-time knobs (RO_BIG_FORM, RO_F64_SCRATCH_MB) from the environment
+#if defined(RO_DIAG) && !defined(RO_DIAG_KNOBS)
+#define RO_DIAG_KNOBS 1
+#endif
+
 // scratch of the large transforms' scratch form (the folded sub-rows between the kernels), MiB per block
 // largest bins / 16384 the one-kernel form of the large transforms is used for (see ro_stft_create)
 #ifndef RO_DIF_MAX_DEC
@@ -180,11 +185,16 @@ struct ro_stft {
     // streaming state.  Three HIP streams and two slots of device buffers: while the kernels of batch n run on
     // `stream`, batch n+1 is uploaded on `s_in` and batch n-1 goes home on `s_out`.
     int batch_rows = 0;
-    int stage_fmt = RO_IQ_F32;                 // what `staged` holds: RO_IQ_F32 (8 B per sample) or RO_IQ_I16 (4 B)
+    // Samples are staged where the upload reads them: in the pinned buffer (h_in) of the slot the next batch will use
+    // (slot = batch_seq & 1), from its first byte.  A batch uploads the front of it and the samples later rows still
+    // need -- the overlap and whatever came in behind the batch's last row -- are carried over to the other slot.
+    int stage_fmt = RO_IQ_F32;                 // what is staged: RO_IQ_F32 (8 B per sample) or RO_IQ_I16 (4 B)
     bool stage_fmt_set = false;
-    std::vector<char> staged;                  // interleaved I,Q in stage_fmt; samples before staged_begin are spent
-    size_t  staged_begin = 0;                  // first live sample in `staged`
-    int64_t stream_sample0 = 0;                // stream index of the sample at staged_begin
+    size_t  staged_have = 0;                   // live samples at the front of slot[batch_seq & 1].h_in
+    int64_t stream_sample0 = 0;                // stream index of the first of them
+    // row sink (ro_stft_set_row_sink): finished rows go straight into the caller's ring (ro_pinned_alloc memory)
+    float  *sink = nullptr;
+    int64_t sink_stride = 0, sink_cap = 0, sink_first = 0;
     struct Slot {
         void  *d_iq = nullptr;                 // batch input  ((batch_rows-1)*hop + bins samples, 8 B each at most)
         float *d_rows = nullptr;               // batch output (batch_rows x bins)
@@ -625,8 +635,9 @@ Batch *acquire_batch(ro_stft *h)
     Batch *b = new (std::nothrow) Batch();
     if (!b) return nullptr;
     b->capacity_rows = h->batch_rows;
-    if (hipHostMalloc(reinterpret_cast<void **>(&b->data), (size_t)b->capacity_rows * h->out_cols * sizeof(float),
-                      hipHostMallocDefault) != hipSuccess ||
+    if ((!h->sink &&
+         hipHostMalloc(reinterpret_cast<void **>(&b->data), (size_t)b->capacity_rows * h->out_cols * sizeof(float),
+                       hipHostMallocDefault) != hipSuccess) ||
         hipHostMalloc(reinterpret_cast<void **>(&b->records), (size_t)b->capacity_rows * sizeof(ro_scan_record_t),
                       hipHostMallocDefault) != hipSuccess ||
         (h->cfg.tile_ln &&
@@ -750,9 +761,9 @@ int run_stream_batch(ro_stft *h, int64_t rows)
     HIP_TRY(hipSetDevice(h->device));
     const size_t sb = stage_sample_bytes(h);
     const int64_t need = (rows - 1) * (int64_t)h->hop + h->bins;       // samples
-    ro_stft::Slot &sl = h->slot[h->batch_seq & 1];
-    HIP_TRY(hipEventSynchronize(sl.uploaded));                          // the upload two batches ago is done
-    std::memcpy(sl.h_in, h->staged.data() + h->staged_begin * sb, (size_t)need * sb);
+    if ((int64_t)h->staged_have < need) return fail(RO_ERR_STATE, "internal: %lld samples staged, %lld needed",
+                                                    (long long)h->staged_have, (long long)need);
+    ro_stft::Slot &sl = h->slot[h->batch_seq & 1];                      // (its samples are already in sl.h_in)
     // Back-pressure: one large ro_stft_push must not queue a pinned batch per launch without bound (64 MiB each with
     // full rows).  Batches older than the newest MAX_IN_FLIGHT are waited for here -- they stay in `ready` for the
     // next fetch, their buffers are simply known to be complete.
@@ -787,8 +798,21 @@ int run_stream_batch(ro_stft *h, int64_t rows)
     step(hipStreamWaitEvent(h->s_out, sl.computed, 0), "hipStreamWaitEvent");
     if (rc == RO_OK) {
         const float *src = h->cfg.tile_cols > 0 ? sl.d_tile : sl.d_rows;
-        step(hipMemcpyAsync(b->data, src, (size_t)rows * h->out_cols * sizeof(float), hipMemcpyDeviceToHost, h->s_out),
-             "download");
+        if (h->sink) {
+            // straight into the caller's ring: row r of the stream at slot (sink_first + r) mod sink_cap, in at most
+            // two runs of consecutive slots
+            const size_t w = (size_t)h->out_cols * sizeof(float);
+            const int64_t s0 = (h->sink_first + h->rows_emitted) % h->sink_cap;
+            const int64_t n0 = std::min<int64_t>(rows, h->sink_cap - s0);
+            step(hipMemcpy2DAsync(h->sink + s0 * h->sink_stride, (size_t)h->sink_stride * sizeof(float), src, w, w, (size_t)n0,
+                                  hipMemcpyDeviceToHost, h->s_out), "download");
+            if (n0 < rows)
+                step(hipMemcpy2DAsync(h->sink, (size_t)h->sink_stride * sizeof(float), src + (size_t)n0 * h->out_cols, w, w,
+                                      (size_t)(rows - n0), hipMemcpyDeviceToHost, h->s_out), "download");
+        } else {
+            step(hipMemcpyAsync(b->data, src, (size_t)rows * h->out_cols * sizeof(float), hipMemcpyDeviceToHost, h->s_out),
+                 "download");
+        }
         if (h->cfg.enable_scan)
             step(hipMemcpyAsync(b->records, sl.d_records, (size_t)rows * sizeof(ro_scan_record_t), hipMemcpyDeviceToHost,
                                 h->s_out), "download");
@@ -815,23 +839,26 @@ int run_stream_batch(ro_stft *h, int64_t rows)
     h->stat_launches += 1;
     h->stat_rows += rows;
 
-    // the samples no later row needs are spent: the next row starts rows*hop further on
+    // the samples no later row needs are spent: the next row starts rows*hop further on.  What is left -- the overlap
+    // and anything behind the batch's last row -- moves to the front of the other slot's staging buffer, whose own
+    // upload (the batch before this one) has to be over first; the upload just queued only READS this slot.
     const int64_t consumed = rows * (int64_t)h->hop;
-    h->staged_begin += (size_t)consumed;
-    if (h->staged_begin * sb > h->staged.size() / 2 && h->staged_begin > (size_t)h->bins) {   // compact now and then
-        h->staged.erase(h->staged.begin(), h->staged.begin() + h->staged_begin * sb);
-        h->staged_begin = 0;
-    }
     h->stream_sample0 += consumed;
     h->rows_emitted += rows;
     h->rows_ready += rows;
     h->ready.push_back(b);
+    ro_stft::Slot &nx = h->slot[h->batch_seq & 1];                      // (batch_seq has moved on)
+    const hipError_t we = hipEventSynchronize(nx.uploaded);
+    const size_t left = h->staged_have - (size_t)consumed;
+    std::memcpy(nx.h_in, static_cast<const char *>(sl.h_in) + (size_t)consumed * sb, left * sb);
+    h->staged_have = left;
+    if (we != hipSuccess) return fail(RO_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(we));
     return RO_OK;
 }
 
 int64_t staged_complete_rows(const ro_stft *h)
 {
-    const int64_t have = (int64_t)(h->staged.size() / stage_sample_bytes(h)) - (int64_t)h->staged_begin;
+    const int64_t have = (int64_t)h->staged_have;
     if (have < h->bins) return 0;
     return (have - h->bins) / h->hop + 1;
 }
@@ -1622,41 +1649,47 @@ extern "C" int ro_stft_push(ro_stft_t *h, const void *iq, int format, int64_t sa
     // over un-normalised, the kernel widens them); float32 and the double Complex are staged as float32 (lossless for
     // every frontend of the reference).  A stream that changes format mid-way is widened to float32 once.
     const bool in_i16 = format == RO_IQ_I16;
+    const size_t cap = (size_t)(h->batch_rows - 1) * h->hop + h->bins;        // samples one slot's staging buffer holds
     if (!h->stage_fmt_set) {
         h->stage_fmt = in_i16 ? RO_IQ_I16 : RO_IQ_F32;
         h->stage_fmt_set = true;
     } else if (h->stage_fmt == RO_IQ_I16 && !in_i16) {
-        const size_t live = h->staged.size() / 4 - h->staged_begin;           // samples still needed, as int16 pairs
-        std::vector<char> wide(live * 8);
-        const int16_t *src = reinterpret_cast<const int16_t *>(h->staged.data()) + h->staged_begin * 2;
-        float *dst = reinterpret_cast<float *>(wide.data());
-        for (size_t i = 0; i < live * 2; ++i) dst[i] = (float)src[i];
-        h->staged.swap(wide);
-        h->staged_begin = 0;
+        // widen what is staged, in place and from the back (the buffer is sized for 8 bytes per sample)
+        char *base = static_cast<char *>(h->slot[h->batch_seq & 1].h_in);
+        const int16_t *src = reinterpret_cast<const int16_t *>(base);
+        float *dst = reinterpret_cast<float *>(base);
+        for (size_t i = h->staged_have * 2; i-- > 0;) dst[i] = (float)src[i];
         h->stage_fmt = RO_IQ_F32;
     }
     const size_t sb = stage_sample_bytes(h);
-    const size_t old = h->staged.size();
-    h->staged.resize(old + (size_t)samples * sb);
-    if (h->stage_fmt == RO_IQ_I16) {
-        std::memcpy(h->staged.data() + old, iq, (size_t)samples * 4);
-    } else {
-        float *dst = reinterpret_cast<float *>(h->staged.data() + old);
-        if (format == RO_IQ_F32) {
-            std::memcpy(dst, iq, (size_t)samples * 2 * sizeof(float));
-        } else if (in_i16) {
-            const int16_t *src = static_cast<const int16_t *>(iq);
-            for (int64_t i = 0; i < samples * 2; ++i) dst[i] = (float)src[i];
-        } else {
-            const double *src = static_cast<const double *>(iq);               // struct Complex
-            for (int64_t i = 0; i < samples * 2; ++i) dst[i] = (float)src[i];
-        }
-    }
+    const size_t isb = format == RO_IQ_F64 ? 16 : format == RO_IQ_F32 ? 8 : 4;       // bytes per sample as delivered
+    const char *in = static_cast<const char *>(iq);
     h->stat_samples += samples;
-
-    while (staged_complete_rows(h) >= h->batch_rows) {
-        rc = run_stream_batch(h, h->batch_rows);
-        if (rc != RO_OK) return rc;
+    for (int64_t left = samples; left > 0;) {
+        // into the pinned buffer the next upload reads, converting on the way (no second copy)
+        char *dstb = static_cast<char *>(h->slot[h->batch_seq & 1].h_in) + h->staged_have * sb;
+        const int64_t take = std::min<int64_t>(left, (int64_t)(cap - h->staged_have));
+        if (h->stage_fmt == RO_IQ_I16) {
+            std::memcpy(dstb, in, (size_t)take * 4);
+        } else {
+            float *dst = reinterpret_cast<float *>(dstb);
+            if (format == RO_IQ_F32) {
+                std::memcpy(dst, in, (size_t)take * 2 * sizeof(float));
+            } else if (in_i16) {
+                const int16_t *src = reinterpret_cast<const int16_t *>(in);
+                for (int64_t i = 0; i < take * 2; ++i) dst[i] = (float)src[i];
+            } else {
+                const double *src = reinterpret_cast<const double *>(in);         // struct Complex
+                for (int64_t i = 0; i < take * 2; ++i) dst[i] = (float)src[i];
+            }
+        }
+        h->staged_have += (size_t)take;
+        in += (size_t)take * isb;
+        left -= take;
+        if (h->staged_have == cap) {                                      // = batch_rows complete rows
+            rc = run_stream_batch(h, h->batch_rows);
+            if (rc != RO_OK) return rc;
+        }
     }
     if (rows_ready) *rows_ready = h->rows_ready;
     const double dt = now_ms() - t0;
@@ -1689,6 +1722,7 @@ extern "C" int ro_stft_fetch(ro_stft_t *h, int64_t max_rows, int first_col, int 
                     first_col, cols, h->out_first, h->out_cols,
                     h->cfg.tile_cols > 0 ? " (the configured tile)" : "");
     if (records_out && !h->cfg.enable_scan) return fail(RO_ERR_STATE, "scan records requested but scan is off");
+    if (rows_out && h->sink) return fail(RO_ERR_STATE, "this handle's rows go to its row sink (ro_stft_set_row_sink): pass rows_out = NULL");
     const double t0 = now_ms();
     int64_t got = 0;
     if (first_row_index) *first_row_index = h->rows_emitted;
@@ -1699,8 +1733,10 @@ extern "C" int ro_stft_fetch(ro_stft_t *h, int64_t max_rows, int first_col, int 
         { const int rc = await_batch(h, b); if (rc != RO_OK) return rc; }
         const int64_t take = std::min(max_rows - got, b->rows - b->consumed);
         for (int64_t r = 0; r < take; ++r) {
-            const float *src = b->data + (size_t)(b->consumed + r) * h->out_cols + (first_col - h->out_first);
-            if (rows_out) std::memcpy(rows_out + (size_t)(got + r) * cols, src, sizeof(float) * cols);
+            if (rows_out) {
+                const float *src = b->data + (size_t)(b->consumed + r) * h->out_cols + (first_col - h->out_first);
+                std::memcpy(rows_out + (size_t)(got + r) * cols, src, sizeof(float) * cols);
+            }
             if (records_out) records_out[got + r] = b->records[(size_t)(b->consumed + r)];
         }
         b->consumed += take;
@@ -1757,14 +1793,52 @@ extern "C" int ro_stft_fetch_ln(ro_stft_t *h, int64_t max_rows, float *tile_out,
     return RO_OK;
 }
 
+extern "C" int ro_stft_set_row_sink(ro_stft_t *h, float *base, int64_t row_stride, int64_t capacity_rows, int64_t first_slot)
+{
+    if (!h) return fail(RO_ERR_INVALID, "null handle");
+    if (!h->ready.empty() || h->staged_have > 0)
+        return fail(RO_ERR_STATE, "the row sink can only change on an idle stream (after create or ro_stft_reset)");
+    if (h->cfg.tile_ln) return fail(RO_ERR_UNSUPPORTED, "a tile_ln handle hands its rows out through ro_stft_fetch_ln");
+    HIP_TRY(hipSetDevice(h->device));
+    // (batches made with a sink hold no row buffer, batches made without one do: the pool starts over either way)
+    while (!h->batch_pool.empty()) { destroy_batch(h->batch_pool.back()); h->batch_pool.pop_back(); }
+    h->sink = nullptr;
+    if (!base) return RO_OK;
+    const int cols = h->cfg.tile_cols > 0 ? h->cfg.tile_cols : h->bins;
+    if (row_stride < cols || capacity_rows < 2 * (int64_t)h->batch_rows || first_slot < 0 || first_slot >= capacity_rows)
+        return fail(RO_ERR_INVALID, "row sink: stride %lld (rows are %d wide), %lld slots (two batches of %d rows at least), "
+                                    "first slot %lld", (long long)row_stride, cols, (long long)capacity_rows, h->batch_rows,
+                    (long long)first_slot);
+    h->sink = base;
+    h->sink_stride = row_stride;
+    h->sink_cap = capacity_rows;
+    h->sink_first = first_slot;
+    return RO_OK;
+}
+
+extern "C" void *ro_pinned_alloc(int device, size_t bytes)
+{
+    void *p = nullptr;
+    if (bytes == 0 || hipSetDevice(device) != hipSuccess) return nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void ro_pinned_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 extern "C" int ro_stft_reset(ro_stft_t *h)
 {
     if (!h) return fail(RO_ERR_INVALID, "null handle");
     if (h->s_in) (void)hipStreamSynchronize(h->s_in);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->s_out) (void)hipStreamSynchronize(h->s_out);
-    h->staged.clear();
-    h->staged_begin = 0;
+    h->staged_have = 0;
     h->stage_fmt_set = false;
     while (!h->ready.empty()) {
         release_batch(h, h->ready.front());

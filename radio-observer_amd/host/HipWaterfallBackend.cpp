@@ -20,6 +20,10 @@ int Recorder::getFFTSampleRate() const { return (int)backend_->getFFTSampleRate(
 int Recorder::fftMarkToRaw(int mark) const { return (*rawHandles_)[wrapIndex(mark, (int)rawHandles_->size())].mark; }
 WFTime Recorder::fftMarkToTime(int mark) const { return (*rawHandles_)[wrapIndex(mark, (int)rawHandles_->size())].time; }
 
+// the row ring of a GPU-fed backend lives in page-locked memory: its rows arrive by DMA (ro_stft_set_row_sink)
+static void *pinnedAlloc(void *ctx, size_t bytes) { return ro_pinned_alloc(*static_cast<int *>(ctx), bytes); }
+static void pinnedFree(void *, void *p) { ro_pinned_free(p); }
+
 WaterfallBase::WaterfallBase(const WaterfallConfig &cfg) : cfg_(cfg)
 {
     bins_ = cfg.bins;
@@ -80,11 +84,12 @@ WFTime WaterfallBase::now() const
 void WaterfallBase::pushRaw(const Complex *data, size_t n)
 {
     if (!cfg_.keep_raw || rawBuffer_.getCapacity() == 0) return;
-    for (size_t i = 0; i < n; ++i) {
-        float *row = rawBuffer_.push();                      // FFTBackend::floatToInt(Complex, float*), FFTBackend.h:258-262
-        row[0] = (float)data[i].real;
-        row[1] = (float)data[i].imag;
-    }
+    // one ring row per sample (FFTBackend::floatToInt(Complex, float*), FFTBackend.h:258-262), a call's worth at a time:
+    // push() per sample cost more than everything else Backend::process does on the host
+    rawBuffer_.pushRun((int)n, [&](float *rows, int count, int done) {
+        const double *src = &data[done].real;                // struct Complex = {double real, imag}
+        for (int i = 0; i < 2 * count; ++i) rows[i] = (float)src[i];
+    });
 }
 
 void WaterfallBase::finishStream()
@@ -100,7 +105,7 @@ void WaterfallBase::processRow(const float *row, const ro_scan_record_t *scan, D
         // written into a slot no queued snapshot covers
         std::lock_guard<std::mutex> g(bufferMutex_);
         float *dst = buffer_.push();                                             // :488
-        std::memcpy(dst, row, sizeof(float) * (size_t)bins_);
+        if (row) std::memcpy(dst, row, sizeof(float) * (size_t)bins_);           // (nullptr: already there -- the row sink)
         rawHandles_[buffer_.mark()] = RawDataHandle(rawMark, info.timeOffset);   // :507 (one slot ahead)
     }
     if (scan) currentScan_ = *scan;
@@ -109,7 +114,10 @@ void WaterfallBase::processRow(const float *row, const ro_scan_record_t *scan, D
     for (Recorder *r : recorders_) r->update();                                  // :534-536
 }
 
-HipWaterfallBackend::HipWaterfallBackend(const WaterfallConfig &cfg) : WaterfallBase(cfg) {}
+HipWaterfallBackend::HipWaterfallBackend(const WaterfallConfig &cfg) : WaterfallBase(cfg)
+{
+    buffer_.setStorage(pinnedAlloc, pinnedFree, &cfg_.device);       // (without a device: nullptr, i.e. the heap)
+}
 
 HipWaterfallBackend::~HipWaterfallBackend()
 {
@@ -160,7 +168,15 @@ void HipWaterfallBackend::startStream(StreamInfo info)
         lastError_ = ro_last_error();
         std::fprintf(stderr, "HipWaterfallBackend: %s\n", lastError_.c_str());
         stft_ = nullptr;
+        return;
     }
+    // Finished rows go from the GPU straight into the row ring's slots -- processFFT's write into buffer_->push()
+    // (src/WaterfallBackend.cpp:488-505) is the device-to-host copy itself: row r of the stream lands in slot
+    // (mark at the start of the stream + r) mod capacity, where the push() of processRow then finds it.  Without
+    // page-locked memory for the ring (or a ring shorter than two batches) the rows take the copying path
+    // (ro_stft_fetch into fetchRows_).
+    rowSink_ = buffer_.storageIsCustom() &&
+               ro_stft_set_row_sink(stft_, buffer_.data(), bins_, buffer_.getCapacity(), buffer_.mark()) == RO_OK;
 }
 
 // Times of row starts.  FFTBackend::process stamps every sample with
@@ -199,12 +215,19 @@ void HipWaterfallBackend::process(const std::vector<Complex> &data, DataInfo inf
         samplesIn_ += (int64_t)data.size();
     }
     pushRaw(data.data(), data.size());
-    // ---- the samples themselves go to the GPU path; struct Complex is two doubles (RO_IQ_F64)
+    // ---- the samples themselves go to the GPU path; struct Complex is two doubles (RO_IQ_F64), narrowed to float32
+    // on their way into the pinned buffer the upload reads
     int64_t ready = 0;
     if (ro_stft_push(stft_, data.data(), RO_IQ_F64, (int64_t)data.size(), &ready) != RO_OK) {
         lastError_ = ro_last_error();
         std::fprintf(stderr, "HipWaterfallBackend: %s\n", lastError_.c_str());
         return;
+    }
+    if (rowSink_ && ready > 0) {
+        // `ready` rows are on their way into the slots ahead of the ring's head: whoever holds a reservation there
+        // (a queued snapshot that has fallen a whole ring behind) learns it now, not when the rows are handed over
+        std::lock_guard<std::mutex> g(bufferMutex_);
+        buffer_.markAhead((int)std::min<int64_t>(ready, buffer_.getCapacity()));
     }
     drain(false);
 }
@@ -226,11 +249,11 @@ void HipWaterfallBackend::drain(bool flush)
         return;
     }
     const int64_t CH = 64;
-    fetchRows_.resize((size_t)CH * bins_);
+    if (!rowSink_) fetchRows_.resize((size_t)CH * bins_);
     fetchRecs_.resize((size_t)CH);
     for (;;) {
         int64_t first = 0, got = 0;
-        if (ro_stft_fetch(stft_, CH, 0, bins_, fetchRows_.data(), scanEnabled_ ? fetchRecs_.data() : nullptr,
+        if (ro_stft_fetch(stft_, CH, 0, bins_, rowSink_ ? nullptr : fetchRows_.data(), scanEnabled_ ? fetchRecs_.data() : nullptr,
                           &first, &got) != RO_OK) {
             lastError_ = ro_last_error();
             return;
@@ -247,7 +270,8 @@ void HipWaterfallBackend::drain(bool flush)
             // there is no overlap to move.
             const int64_t s = (overlap_ > 0 ? (r + 1) : r) * (int64_t)hop_;
             const int rawMark = (int)((s + 1) % rawCapacity_);
-            processRow(&fetchRows_[(size_t)i * bins_], scanEnabled_ ? &fetchRecs_[(size_t)i] : nullptr, di, rawMark);
+            processRow(rowSink_ ? nullptr : &fetchRows_[(size_t)i * bins_], scanEnabled_ ? &fetchRecs_[(size_t)i] : nullptr, di,
+                       rawMark);
         }
     }
 }

@@ -205,6 +205,7 @@ private:
 
     ro_stft_t *stft_ = nullptr;
     int batchRows_ = 0;
+    bool rowSink_ = false;           // rows arrive in the ring's slots by DMA (ro_stft_set_row_sink)
     std::string lastError_;
 
     // framing bookkeeping that stays on the host (timestamps, raw marks: O(1) per row)

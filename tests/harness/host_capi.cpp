@@ -32,6 +32,20 @@ int ro_host_ring_get_size(void *r) { return RING(r)->getSize(); }
 int ro_host_ring_is_full(void *r) { return RING(r)->isFull() ? 1 : 0; }
 int ro_host_ring_push(void *r) { int m = RING(r)->mark(); RING(r)->push(); return m; }
 int ro_host_ring_mark(void *r) { return RING(r)->mark(); }
+// n pushes at once (row i of the call filled with first + i in column 0); returns the mark before
+int ro_host_ring_push_run(void *r, int n, float first)
+{
+    const int m = RING(r)->mark();
+    const int w = RING(r)->getWidth();
+    RING(r)->pushRun(n, [&](float *rows, int count, int done) {
+        for (int i = 0; i < count; ++i) rows[(size_t)i * w] = first + (float)(done + i);
+    });
+    return m;
+}
+void ro_host_ring_push_written(void *r, int n) { RING(r)->pushWritten(n); }
+void ro_host_ring_mark_ahead(void *r, int n) { RING(r)->markAhead(n); }
+float ro_host_ring_at0(void *r, int mark) { return RING(r)->at(mark)[0]; }
+void ro_host_ring_set0(void *r, int mark, float x) { RING(r)->at(mark)[0] = x; }
 int ro_host_ring_normalize(void *r, int m) { return RING(r)->normalizeRowIndex(m); }
 int ro_host_ring_size_from(void *r, int s) { return RING(r)->size(s); }
 int ro_host_ring_size_between(void *r, int s, int e) { return RING(r)->size(s, e); }

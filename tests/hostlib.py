@@ -22,6 +22,16 @@ def host_library():
             for n in ("size_between", "reserve"):
                 getattr(_lib, "ro_host_ring_" + n).argtypes = [C.c_void_p, C.c_int, C.c_int]
                 getattr(_lib, "ro_host_ring_" + n).restype = C.c_int
+            _lib.ro_host_ring_push_run.argtypes = [C.c_void_p, C.c_int, C.c_float]
+            _lib.ro_host_ring_push_run.restype = C.c_int
+            _lib.ro_host_ring_push_written.argtypes = [C.c_void_p, C.c_int]
+            _lib.ro_host_ring_push_written.restype = None
+            _lib.ro_host_ring_mark_ahead.argtypes = [C.c_void_p, C.c_int]
+            _lib.ro_host_ring_mark_ahead.restype = None
+            _lib.ro_host_ring_at0.argtypes = [C.c_void_p, C.c_int]
+            _lib.ro_host_ring_at0.restype = C.c_float
+            _lib.ro_host_ring_set0.argtypes = [C.c_void_p, C.c_int, C.c_float]
+            _lib.ro_host_ring_set0.restype = None
             _lib.ro_host_ring_create.argtypes = [C.c_int, C.c_int, C.c_int]
             _lib.ro_host_ring_create.restype = C.c_void_p
             _lib.ro_host_ring_destroy.argtypes = [C.c_void_p]

@@ -138,3 +138,60 @@ def test_tile_only_transport_and_timing(ro, oracle):
     want = oracle.stft(iq, bins, overlap)[:, tile[0]:tile[0] + tile[1]]
     full = oracle.stft(iq, bins, overlap)
     assert np.abs(band.astype(np.float64) - want).max() <= 1e-5 * full.max()
+
+
+@pytest.mark.parametrize("bins,overlap,batch,slots,first_slot,tile", [(4096, 2048, 3, 8, 5, None), (32768, 24576, 4, 11, 0, None),
+                                                                      (4096, 3072, 2, 7, 6, (1000, 300))])
+def test_row_sink_receives_the_rows_in_ring_order(ro, oracle, bins, overlap, batch, slots, first_slot, tile):
+    """ro_stft_set_row_sink: the rows land in the caller's ring by DMA -- row r in slot (first_slot + r) mod capacity, the
+    batch that wraps in two pieces -- and ro_stft_fetch (rows_out = NULL) only reports them; a ring too small for two
+    batches, a changed sink on a busy stream and rows_out with a sink are refused."""
+    rng = np.random.default_rng(bins + batch)
+    hop = bins - overlap
+    R = 3 * slots + 1                                   # the ring wraps three times
+    T = bins + (R - 1) * hop + 5
+    iq = noise_iq(rng, T)
+    want = oracle.stft(iq, bins, overlap)
+    cols = tile[1] if tile else bins
+    pinned = ro.PinnedArray(slots, cols + 3)            # page-locked (ro_pinned_alloc); a stride wider than the row
+    ring = pinned.array
+    ring[:] = np.nan
+    small = ro.PinnedArray(2 * batch - 1, cols)
+    with ro.Stft(bins=bins, overlap=overlap, max_batch_rows=batch, tile=tile) as st:
+        with pytest.raises(ro.StftError):
+            st.set_row_sink(small.array)
+        st.set_row_sink(ring, first_slot)
+        seen = 0
+        for i in range(0, T, 3000):
+            st.push(iq[i:i + 3000])
+            while True:
+                first, got, _ = st.fetch_records(batch)
+                if got == 0:
+                    break
+                assert first == seen
+                for r in range(first, first + got):     # a reported row is in place (and nobody has lapped it yet)
+                    slot = (first_slot + r) % slots
+                    ref = want[r, tile[0]:tile[0] + tile[1]] if tile else want[r]
+                    assert np.abs(ring[slot, :cols] - ref).max() <= 1e-5 * want[r].max()
+                    assert np.isnan(ring[slot, cols:]).all()                     # the padding of the stride is not written
+                seen += got
+        with pytest.raises(ro.StftError):
+            st.set_row_sink(None)                       # samples are staged: not idle
+        with pytest.raises(ro.StftError):
+            st.fetch(1)                                 # rows_out with a sink
+        st.flush()
+        while True:
+            first, got, _ = st.fetch_records(1000)
+            if got == 0:
+                break
+            seen += got
+        assert seen == R
+        st.reset()
+        st.set_row_sink(None)
+        st.push(iq[:bins + hop])
+        st.flush()
+        first, rows, _ = st.fetch(10)                   # back to the copying path
+        assert first == 0 and rows.shape[0] == 2 and np.abs(rows[1, :cols] - (want[1, tile[0]:tile[0] + tile[1]] if tile else want[1])).max() <= 1e-5 * want[1].max()
+    del ring
+    pinned.close()
+    small.close()

@@ -88,3 +88,64 @@ def test_ring_quirks_used_by_recorders(ring_factory):
     h = r.reserve(0, 3)
     assert r.free_reservation(h) == 1 and r.free_reservation(99) == 0
     assert r.reserve(1, 2) == h                                  # handles are recycled (:589-591)
+
+
+def test_a_run_of_pushes_is_n_pushes():
+    """RingBuffer2D::pushRun / pushWritten / markAhead of the host mirror (what makes Backend::process cost per call, not
+    per sample, and lets the GPU write rows into the ring's slots): head, size, the slots handed out and every
+    reservation's dirty flag are those of n single push() calls -- random rings, random reservations (with the
+    reference's end = 0 quirk in them), runs that wrap."""
+    import random
+    from hostlib import HostRing, host_library
+    if host_library() is None:
+        pytest.skip("tests/harness/libro_host_harness.so is not built")
+    rng = random.Random(7)
+    for trial in range(300):
+        width = rng.choice([1, 2, 5])
+        cap_req = rng.randint(3, 40)
+        a, b = HostRing(width, 4 * width * rng.choice([1, 3, 4]), cap_req), None
+        b = HostRing(width, 1, 1)
+        b = HostRing(width, 4 * width, 1)
+        # two rings of the same geometry
+        chunk = 4 * width * rng.choice([1, 3, 4])
+        a, b = HostRing(width, chunk, cap_req), HostRing(width, chunk, cap_req)
+        cap = a.capacity()
+        assert b.capacity() == cap
+        pre = rng.randint(0, 2 * cap)
+        for i in range(pre):
+            a.push(); b.push()
+        hs = []
+        for _ in range(rng.randint(0, 4)):
+            s_, e_ = rng.randint(-cap, 2 * cap), rng.randint(-cap, 2 * cap)
+            hs.append((a.reserve(s_, e_), b.reserve(s_, e_)))
+        for step in range(rng.randint(1, 6)):
+            n = rng.randint(0, cap + 3)
+            kind = rng.choice(["run", "written", "ahead"])
+            if kind == "ahead":
+                # markAhead(n) = the dirty flags n pushes would set, nothing else
+                a.mark_ahead(n)
+                c = HostRing(width, chunk, cap_req)          # a scratch copy of b's state to push into
+                for i in range(b.mark() if b.get_size() < cap else cap + b.mark()):
+                    c.push()
+                assert c.mark() == b.mark()
+                want_dirty = []
+                for (ha, hb) in hs:
+                    want_dirty.append(b.is_dirty(hb))
+                # replay on b itself, then compare flags only (b's head moves; a's must not)
+                m_a = a.mark()
+                for i in range(min(n, cap)):
+                    b.push()
+                for (ha, hb) in hs:
+                    assert a.is_dirty(ha) == b.is_dirty(hb), (trial, step, kind, n)
+                assert a.mark() == m_a
+                a.push_written(min(n, cap))                  # bring a level with b again
+            else:
+                m = a.push_run(n, 1000.0 * step) if kind == "run" else (a.mark(), a.push_written(n))[0]
+                for i in range(n):
+                    assert b.mark() == (m + i) % cap
+                    b.push()
+                    if kind == "run" and i >= n - cap:
+                        assert a.at0((m + i) % cap) == 1000.0 * step + i
+            assert a.mark() == b.mark() and a.get_size() == b.get_size() and a.is_full() == b.is_full()
+            for (ha, hb) in hs:
+                assert a.is_dirty(ha) == b.is_dirty(hb), (trial, step, kind, n)

@@ -382,6 +382,46 @@ def check_kernel():
     print("hook rows: pass 1 q, q+1, q+16, q+17; pass 2 r, r+8, r+16, r+24")
 
 
+def check_pair():
+    """the large transform bins = 2 N on the same kernel (PAIR): half q of a stream row = bins q + 2 k'.
+    a = w0 x0 + w1 x1 (q = 0), d = w0 x0 - w1 x1 (q = 1, through the scratch); the rotation W_bins^m of q = 1 as a shift
+    of the bin index by 1/2: pass 0 twiddled with exp(-2 pi i (1/2) / 32), pass 1 / 2 stage twiddles times
+    exp(-2 pi i (1/2) / 1024), / 32768; bin q + 2 k' leaves for column q + 2 ((k' + N/2) mod N); the scratch unit k of a
+    thread = its slots k, 16 + k."""
+    rng = np.random.default_rng(5)
+    bins = 2 * N
+    x = rng.standard_normal(bins) + 1j * rng.standard_normal(bins)
+    w = rng.standard_normal(bins)
+    want = np.fft.fftshift(np.fft.fft(x * w))
+    u, vv = x[:N] * w[:N], x[N:] * w[N:]
+    for q, acc in ((0, u + vv), (1, u - vv)):
+        phi = q / 2
+        y0 = np.zeros((1024, 32), dtype=complex)                # [n1][k0]
+        tw0 = np.exp(-2j * np.pi * phi / 32)
+        for c in range(1024):
+            y0[c] = np.fft.fft(acc[c + 1024 * np.arange(32)] * tw0 ** np.arange(32))
+        for k0 in (0, 5, 31):
+            for k1 in (0, 9):
+                col = np.zeros(32, dtype=complex)
+                for a in range(32):
+                    w1 = np.exp(-2j * np.pi * k0 / 1024) * np.exp(-2j * np.pi * phi / 1024)
+                    col[a] = np.fft.fft(y0[a + 32 * np.arange(32), k0] * w1 ** np.arange(32))[k1]
+                w2 = np.exp(-2j * np.pi * (k0 + 32 * k1) / N) * np.exp(-2j * np.pi * phi / N)
+                y2 = np.fft.fft(col * w2 ** np.arange(32))
+                for k2 in range(32):
+                    kp = k0 + 32 * k1 + 1024 * k2
+                    colm = q + 2 * ((kp + N // 2) & (N - 1))
+                    assert abs(y2[k2] - want[colm]) < 1e-6 * np.abs(want).max(), (q, k0, k1, k2)
+    # the window table of block r is the ordinary layout of w[r N ..]; chunk g of block 1 = quad g: slots 2g, 2g + 16,
+    # 2g + 1, 2g + 17; the scratch: store (2 g + j) T + tid carries slots 2 g + j and 2 g + j + 16 = load k's v[k], v[16 + k]
+    for g in range(8):
+        for j in (0, 1):
+            k = 2 * g + j
+            assert (k, 16 + k) == (2 * g + j, 2 * g + j + 16) and k < 16
+    print("PAIR: a = w0 x0 + w1 x1, d = w0 x0 - w1 x1, shifted twiddles for d, columns q + 2 ((k' + N/2) mod N) == fft of the large row")
+
+
 if __name__ == "__main__":
     check_planar()
     check_kernel()
+    check_pair()
