@@ -223,7 +223,33 @@ def pmc_traffic(rows):
     return per_row * rows
 
 
-def streaming_leg(seconds, max_batch_rows):
+def pcie_copy_rates(torch, dev, mib=256):
+    """pinned host <-> device copy rates of this box, both directions at once on two streams (the streaming path
+    uploads one batch while it downloads another): GB/s host-to-device, device-to-host"""
+    n = mib << 20
+    h_in = torch.empty(n, dtype=torch.uint8).pin_memory()
+    h_out = torch.empty(n, dtype=torch.uint8).pin_memory()
+    d_in = torch.empty(n, dtype=torch.uint8, device=dev)
+    d_out = torch.empty(n, dtype=torch.uint8, device=dev)
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for timed in (False, True):
+        torch.cuda.synchronize(dev)
+        with torch.cuda.stream(s1):
+            ev[0].record(s1)
+            for _ in range(4):
+                d_in.copy_(h_in, non_blocking=True)
+            ev[1].record(s1)
+        with torch.cuda.stream(s2):
+            ev[2].record(s2)
+            for _ in range(4):
+                h_out.copy_(d_out, non_blocking=True)
+            ev[3].record(s2)
+        torch.cuda.synchronize(dev)
+    return 4 * n / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9, 4 * n / (ev[2].elapsed_time(ev[3]) * 1e-3) / 1e9
+
+
+def streaming_leg(seconds, max_batch_rows, pcie=None):
     """rows/s and GB/s of the C++ host mirror's Backend::process path (tests/harness drives it; test infrastructure)"""
     lib = os.path.join(ROOT, "tests", "harness", "libro_host_harness.so")
     if not os.path.exists(lib):
@@ -232,21 +258,42 @@ def streaming_leg(seconds, max_batch_rows):
     H.ro_host_stream_bench.restype = ctypes.c_int
     H.ro_host_stream_bench.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                        ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
-    stats = (ctypes.c_double * 8)()
+    stats = (ctypes.c_double * 16)()
     block = 4096
     rc = H.ro_host_stream_bench(BINS, OVERLAP, FS, block, seconds, max_batch_rows, 2 * (BINS // block) + 64, stats)
     if rc != 0:
         return {"error": "ro_host_stream_bench returned %d" % rc}
     secs, smp, rws = stats[0], stats[1], stats[2]
-    return {"value": rws / secs, "unit": "rows/s", "seconds": secs, "rows": int(rws), "samples": int(smp),
-            "samples_per_s": smp / secs, "real_time_factor": smp / secs / FS,
-            "GBs_in_as_delivered": smp * 16 / secs / 1e9,           # struct Complex = two doubles (src/Backend.h:26-29)
-            "GBs_rows_out": rws * BINS * 4 / secs / 1e9,
-            "process_calls": int(stats[3]), "samples_per_call": block, "rows_per_kernel_launch": int(stats[4]),
-            "ms_per_process_call_mean": stats[5], "ms_per_process_call_max": stats[6], "events_fired": int(stats[7]),
-            "path": "FrontendDriver::process -> HipWaterfallBackend::process (ro_stft_push RO_IQ_F64 -> pinned staging -> "
-                    "H2D -> kernels -> D2H of full rows -> ro_stft_fetch) -> RingBuffer2D -> BolidRecorder::update; "
-                    "startStream (handle creation) and the warm-up calls are outside the timed region, endStream inside"}
+    out = {"value": rws / secs, "unit": "rows/s", "seconds": secs, "rows": int(rws), "samples": int(smp),
+           "samples_per_s": smp / secs, "real_time_factor": smp / secs / FS,
+           "GBs_in_as_delivered": smp * 16 / secs / 1e9,           # struct Complex = two doubles (src/Backend.h:26-29)
+           "GBs_in_on_the_bus": smp * 8 / secs / 1e9,              # ... narrowed to float32 on their way into the pinned staging buffer
+           "GBs_rows_out": rws * BINS * 4 / secs / 1e9,
+           "process_calls": int(stats[3]), "samples_per_call": block, "rows_per_kernel_launch": int(stats[4]),
+           "ms_per_process_call_mean": stats[5], "ms_per_process_call_max": stats[6], "events_fired": int(stats[7]),
+           "rows_by_dma_into_the_row_ring": bool(stats[15]),
+           # ro_stft_timing of the stream's handle over the timed region (FFTBackend::logProcessingTimes' counterpart):
+           # where a Backend::process call spends its time -- push = narrowing + staging + launching a batch when one is
+           # complete; fetch = waiting for a batch's download and handing its rows to the recorders
+           "stages": {"push_ms_avg": stats[8], "push_calls": int(stats[12]), "fetch_ms_avg": stats[9],
+                      "fetch_calls": int(stats[13]), "batch_gpu_ms_avg": stats[10], "batches": int(stats[14]),
+                      "row_gpu_us_avg": stats[11],
+                      "host_us_per_row_outside_push_and_fetch":
+                          (secs * 1e6 - stats[8] * 1e3 * stats[12] - stats[9] * 1e3 * stats[13]) / max(rws, 1.0)},
+           "path": "FrontendDriver::process -> HipWaterfallBackend::process (raw ring: one bulk push per call; ro_stft_push "
+                   "RO_IQ_F64 narrowing straight into the pinned staging buffer -> H2D -> kernels -> D2H of full rows INTO "
+                   "the slots of the pinned row ring (ro_stft_set_row_sink) -> ro_stft_fetch of the scan records) -> "
+                   "RingBuffer2D::push bookkeeping -> BolidRecorder::update per row; startStream (handle creation) and the "
+                   "warm-up calls are outside the timed region, endStream inside"}
+    if pcie:
+        h2d, d2h = pcie
+        # the bus's own bound for this path: per row hop samples of 8 bytes up, bins floats down, both directions at once
+        bound = 1.0 / max(HOP * 8 / (h2d * 1e9), BINS * 4 / (d2h * 1e9))
+        out.update({"pcie_h2d_GBs": h2d, "pcie_d2h_GBs": d2h, "pcie_bound_rows_per_s": bound,
+                    "frac_of_pcie": out["value"] / bound,
+                    "pcie_note": "pinned 256 MiB copies in both directions at once, measured in this run; the bound is the "
+                                 "slower direction's time per row (hop x 8 bytes up, bins x 4 bytes down)"})
+    return out
 
 
 class ClockPowerSampler:
@@ -754,10 +801,11 @@ def main():
         # with 4096-sample vector<Complex> calls (src/RawStream.cpp:44-66) -> kernels -> full rows back to the host row
         # ring -> BolidRecorder::update per row; PCIe both ways included, handle creation and warm-up calls excluded
         if world == 1 and not a.no_streaming and not c5:
-            out["streaming"] = streaming_leg(a.stream_seconds, 0)
+            pcie = pcie_copy_rates(torch, dev)
+            out["streaming"] = streaming_leg(a.stream_seconds, 0, pcie)
             # (the Backend's own default bounds a batch by latency -- one second of rows = 6; the same path with 256 rows
             # per launch, what a file replay would ask for through WaterfallConfig::max_batch_rows)
-            out["streaming_batch256"] = streaming_leg(a.stream_seconds, 256)
+            out["streaming_batch256"] = streaming_leg(a.stream_seconds, 256, pcie)
 
         # ---- CPU baseline (rank 0, N=1 only): the oracle port on the host cores of this box.  Its FP64 transform runs
         # on libfftw3 itself (fftw_plan_dft_1d(..., FFTW_FORWARD, FFTW_ESTIMATE) + fftw_execute, the reference's call

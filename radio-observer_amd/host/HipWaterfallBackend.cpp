@@ -81,15 +81,18 @@ WFTime WaterfallBase::now() const
     return WFTime((int64_t)tv.tv_sec, (int64_t)tv.tv_usec);
 }
 
-void WaterfallBase::pushRaw(const Complex *data, size_t n)
+int WaterfallBase::pushRaw(const Complex *data, size_t n, RawSpan spans[2])
 {
-    if (!cfg_.keep_raw || rawBuffer_.getCapacity() == 0) return;
+    if (!cfg_.keep_raw || rawBuffer_.getCapacity() == 0) return 0;
     // one ring row per sample (FFTBackend::floatToInt(Complex, float*), FFTBackend.h:258-262), a call's worth at a time:
     // push() per sample cost more than everything else Backend::process does on the host
+    int ns = 0;
     rawBuffer_.pushRun((int)n, [&](float *rows, int count, int done) {
         const double *src = &data[done].real;                // struct Complex = {double real, imag}
         for (int i = 0; i < 2 * count; ++i) rows[i] = (float)src[i];
+        if (spans && ns < 2) spans[ns++] = RawSpan{rows, count};
     });
+    return ns;
 }
 
 void WaterfallBase::finishStream()
@@ -214,11 +217,20 @@ void HipWaterfallBackend::process(const std::vector<Complex> &data, DataInfo inf
         }
         samplesIn_ += (int64_t)data.size();
     }
-    pushRaw(data.data(), data.size());
-    // ---- the samples themselves go to the GPU path; struct Complex is two doubles (RO_IQ_F64), narrowed to float32
-    // on their way into the pinned buffer the upload reads
+    // ---- the samples themselves go to the GPU path.  struct Complex is two doubles; the raw ring wants them as float
+    // pairs anyway (one narrowing pass), and those rows ARE the RO_IQ_F32 wire format: the GPU path takes them from there
+    // (at most two runs of the ring).  Without a raw ring: RO_IQ_F64, narrowed on the way into the pinned staging buffer.
     int64_t ready = 0;
-    if (ro_stft_push(stft_, data.data(), RO_IQ_F64, (int64_t)data.size(), &ready) != RO_OK) {
+    RawSpan spans[2];
+    const int ns = (size_t)rawBuffer_.getCapacity() >= data.size() ? pushRaw(data.data(), data.size(), spans) : 0;
+    int rc = RO_OK;
+    if (ns > 0) {
+        for (int i = 0; i < ns && rc == RO_OK; ++i) rc = ro_stft_push(stft_, spans[i].rows, RO_IQ_F32, spans[i].count, &ready);
+    } else {
+        pushRaw(data.data(), data.size());
+        rc = ro_stft_push(stft_, data.data(), RO_IQ_F64, (int64_t)data.size(), &ready);
+    }
+    if (rc != RO_OK) {
         lastError_ = ro_last_error();
         std::fprintf(stderr, "HipWaterfallBackend: %s\n", lastError_.c_str());
         return;

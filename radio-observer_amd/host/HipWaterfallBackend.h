@@ -152,8 +152,10 @@ protected:
     float fftSampleRate_ = 0.f;
     bool  scanEnabled_ = false;
 
-    // raw samples as (float)re, (float)im, one ring row per sample (src/FFTBackend.cpp:217-223)
-    void pushRaw(const Complex *data, size_t n);
+    // raw samples as (float)re, (float)im, one ring row per sample (src/FFTBackend.cpp:217-223); `spans` (optional)
+    // receives where they went -- at most two runs of consecutive ring rows -- and the call returns how many
+    struct RawSpan { const float *rows; int count; };
+    int pushRaw(const Complex *data, size_t n, RawSpan spans[2] = nullptr);
 
     std::unique_ptr<CsvLog>    metadataFile_;
     Noise  lastNoise_;
@@ -198,6 +200,9 @@ public:
     void endStream() override;                                       // :600-607
     const std::string &lastError() const { return lastError_; }
     int batchRows() const { return batchRows_; }                     // rows per kernel launch of this stream
+    bool rowsByDma() const { return rowSink_; }                      // the rows land in the ring's slots (ro_stft_set_row_sink)
+    // FFTBackend::logProcessingTimes' numbers (src/FFTBackend.h:208-229) for this stream: ro_stft_timing of its handle
+    bool timing(ro_stft_timing_t *out, bool reset) const { return stft_ && ro_stft_timing(stft_, out, reset ? 1 : 0) == RO_OK; }
 
 private:
     void drain(bool flush);

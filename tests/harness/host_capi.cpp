@@ -501,6 +501,8 @@ int ro_host_stream_bench(int bins, int overlap, int sample_rate, int block, doub
     int64_t calls = 0;
     for (int i = 0; i < warm_calls; ++i) frontend.process(blocks[(size_t)(calls++ % NBLK)]);
     const int64_t rows0 = backend.rowsDelivered();
+    ro_stft_timing_t tm;
+    backend.timing(&tm, true);                                       // the counters of the timed region only
     auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
     const double t0 = now();
     double worst = 0.0;
@@ -513,8 +515,13 @@ int ro_host_stream_bench(int bins, int overlap, int sample_rate, int block, doub
         ++timed;
         if (a + d - t0 >= seconds) break;
     }
+    std::memset(&tm, 0, sizeof tm);
+    backend.timing(&tm, false);
     frontend.endStream();
     const double dt = now() - t0;
+    stats[8] = tm.push_ms_avg;  stats[9] = tm.fetch_ms_avg;  stats[10] = tm.batch_gpu_ms_avg;  stats[11] = tm.row_gpu_us_avg;
+    stats[12] = (double)tm.push_calls;  stats[13] = (double)tm.fetch_calls;  stats[14] = (double)tm.batches;
+    stats[15] = backend.rowsByDma() ? 1.0 : 0.0;
     stats[0] = dt;
     stats[1] = (double)timed * (double)block;
     stats[2] = (double)(backend.rowsDelivered() - rows0);
