@@ -1179,6 +1179,17 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
         return fail(RO_ERR_UNSUPPORTED, "device %d is %s; this library is built for gfx950 only",
                     cfg->device, prop.gcnArchName);
     }
+    // The N = 32768 kernel (and what is built on it) wants 132 KiB of LDS for ONE workgroup and spreads its grid over
+    // eight XCDs (blockIdx % 8, round-robin dispatch): say so here rather than with an opaque launch error later.  A
+    // partition mode with fewer XCDs per device only loses the placement (rows of one XCD's run no longer share an L2).
+    if ((prop.maxSharedMemoryPerMultiProcessor > 0 && (size_t)prop.maxSharedMemoryPerMultiProcessor < (size_t)132 * 1024) ||
+        prop.multiProcessorCount < 8) {
+        const size_t lds = (size_t)prop.maxSharedMemoryPerMultiProcessor;
+        const int cus = prop.multiProcessorCount;
+        delete h;
+        return fail(RO_ERR_UNSUPPORTED, "device %d offers %zu bytes of LDS per CU and %d CUs; the kernels need 135168 for one workgroup and 8",
+                    cfg->device, lds, cus);
+    }
 
     h->window.resize(h->bins);
     if (cfg->window_kind == RO_WINDOW_CUSTOM)

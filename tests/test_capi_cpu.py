@@ -106,6 +106,19 @@ def test_no_cpu_fallback(ro):
     assert "device" in str(e.value).lower() or "hip" in str(e.value).lower()
 
 
+def test_row_sink_entry_points_without_a_device(ro):
+    """ABI 3: the pinned allocator gives nothing without a HIP device (the host mirror's ring then lives on the heap and
+    the rows take the copying path), and the sink wants a handle."""
+    import torch
+    lib = ro.library()
+    assert lib.ro_stft_set_row_sink(None, None, 0, 0, 0) == -1           # RO_ERR_INVALID: null handle
+    lib.ro_pinned_free(None)                                              # like free(NULL)
+    if not torch.cuda.is_available():
+        assert not lib.ro_pinned_alloc(0, 4096)
+        with pytest.raises(MemoryError):
+            ro.PinnedArray(4, 4)
+
+
 def test_product_does_not_touch_the_oracle():
     """Nothing under radio-observer_amd/ may import, link or load oracle/."""
     pkg = os.path.join(ROOT, "radio-observer_amd")
