@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """GPU box: the C3 kernel on fewer CUs (spare_cus_per_xcd = 0 ... 24 of each XCD's 32 left idle): rows/s, rows/s per
-active CU, package power and sclk from rocm-smi in the middle of a long run of launches.  If the rate were bound by what
+active CU, package power and sclk (sysfs hwmon files) in the middle of a long run of launches.  If the rate were bound by what
 a CU can do, rows/s per CU would not depend on how many of them work; under a package power cap it rises as CUs are
 taken away (the clock rises)."""
-import importlib, os, re, subprocess, sys, threading, time
+import importlib, os, sys, threading, time
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 ro = importlib.import_module("radio-observer_amd")
@@ -16,10 +16,16 @@ s = torch.cuda.current_stream().cuda_stream
 
 
 def smi():
-    out = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True).stdout
-    p = re.search(r"Package Power \(W\): ([\d.]+)", out)
-    c = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
-    return (float(p.group(1)) if p else float("nan")), (int(c.group(1)) if c else -1)
+    """package power and sclk of this device from the amdgpu hwmon files in sysfs -- plain file reads (bench.py's
+    ClockPowerSampler): the first form of this script ran rocm-smi as a child of a process that holds the GPU, which
+    bench.py and tests/test_bench_cpu.py forbid (a fork + exec out of such a process is a hazard on this pool)"""
+    import bench
+    smp = bench.ClockPowerSampler(torch, 0)
+    if not smp.files:
+        return float("nan"), -1
+    mhz = smp._read(smp.files[0]) / 1e6
+    w = smp._read(smp.files[1]) / 1e6 if smp.files[1] else float("nan")
+    return w, int(mhz)
 
 
 print("spare CUs per XCD | active CUs | ms per launch | rows/s | rows/s per active CU | package W | sclk MHz")
