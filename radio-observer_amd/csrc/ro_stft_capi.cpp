@@ -763,6 +763,11 @@ int run_stream_batch(ro_stft *h, int64_t rows)
     const int64_t need = (rows - 1) * (int64_t)h->hop + h->bins;       // samples
     if ((int64_t)h->staged_have < need) return fail(RO_ERR_STATE, "internal: %lld samples staged, %lld needed",
                                                     (long long)h->staged_have, (long long)need);
+    // rows that have not been fetched sit in the sink's slots: a batch that would lap them is not launched (the caller
+    // fetches between its pushes; a push can stage at most one batch beyond this point, so nothing is lost)
+    if (h->sink && h->rows_ready + rows > h->sink_cap)
+        return fail(RO_ERR_STATE, "row sink full: %lld rows wait to be fetched in a ring of %lld slots", (long long)h->rows_ready,
+                    (long long)h->sink_cap);
     ro_stft::Slot &sl = h->slot[h->batch_seq & 1];                      // (its samples are already in sl.h_in)
     // Back-pressure: one large ro_stft_push must not queue a pinned batch per launch without bound (64 MiB each with
     // full rows).  Batches older than the newest MAX_IN_FLIGHT are waited for here -- they stay in `ready` for the

@@ -220,28 +220,36 @@ void HipWaterfallBackend::process(const std::vector<Complex> &data, DataInfo inf
     // ---- the samples themselves go to the GPU path.  struct Complex is two doubles; the raw ring wants them as float
     // pairs anyway (one narrowing pass), and those rows ARE the RO_IQ_F32 wire format: the GPU path takes them from there
     // (at most two runs of the ring).  Without a raw ring: RO_IQ_F64, narrowed on the way into the pinned staging buffer.
-    int64_t ready = 0;
-    RawSpan spans[2];
-    const int ns = (size_t)rawBuffer_.getCapacity() >= data.size() ? pushRaw(data.data(), data.size(), spans) : 0;
-    int rc = RO_OK;
-    if (ns > 0) {
-        for (int i = 0; i < ns && rc == RO_OK; ++i) rc = ro_stft_push(stft_, spans[i].rows, RO_IQ_F32, spans[i].count, &ready);
-    } else {
-        pushRaw(data.data(), data.size());
-        rc = ro_stft_push(stft_, data.data(), RO_IQ_F64, (int64_t)data.size(), &ready);
+    // A call of ordinary size goes over in one piece; a very long one (a file replayed in one block) in pieces that each
+    // complete at most a quarter of the row ring, the rows handed to the recorders in between -- the rows of a batch
+    // land in the ring's slots before they are fetched, so what is in flight has to stay well inside it.
+    const size_t piece = std::max<size_t>((size_t)hop_, (size_t)(buffer_.getCapacity() / 4) * (size_t)hop_);
+    for (size_t at = 0; at < data.size(); at += piece) {
+        const Complex *src = data.data() + at;
+        const size_t n = std::min(piece, data.size() - at);
+        int64_t ready = 0;
+        RawSpan spans[2];
+        const int ns = (size_t)rawBuffer_.getCapacity() >= n ? pushRaw(src, n, spans) : 0;
+        int rc = RO_OK;
+        if (ns > 0) {
+            for (int i = 0; i < ns && rc == RO_OK; ++i) rc = ro_stft_push(stft_, spans[i].rows, RO_IQ_F32, spans[i].count, &ready);
+        } else {
+            pushRaw(src, n);
+            rc = ro_stft_push(stft_, src, RO_IQ_F64, (int64_t)n, &ready);
+        }
+        if (rc != RO_OK) {
+            lastError_ = ro_last_error();
+            std::fprintf(stderr, "HipWaterfallBackend: %s\n", lastError_.c_str());
+            return;
+        }
+        if (rowSink_ && ready > 0) {
+            // `ready` rows are on their way into the slots ahead of the ring's head: whoever holds a reservation there
+            // (a queued snapshot that has fallen a whole ring behind) learns it now, not when the rows are handed over
+            std::lock_guard<std::mutex> g(bufferMutex_);
+            buffer_.markAhead((int)std::min<int64_t>(ready, buffer_.getCapacity()));
+        }
+        drain(false);
     }
-    if (rc != RO_OK) {
-        lastError_ = ro_last_error();
-        std::fprintf(stderr, "HipWaterfallBackend: %s\n", lastError_.c_str());
-        return;
-    }
-    if (rowSink_ && ready > 0) {
-        // `ready` rows are on their way into the slots ahead of the ring's head: whoever holds a reservation there
-        // (a queued snapshot that has fallen a whole ring behind) learns it now, not when the rows are handed over
-        std::lock_guard<std::mutex> g(bufferMutex_);
-        buffer_.markAhead((int)std::min<int64_t>(ready, buffer_.getCapacity()));
-    }
-    drain(false);
 }
 
 void HipWaterfallBackend::endStream()

@@ -187,6 +187,13 @@ def test_row_sink_receives_the_rows_in_ring_order(ro, oracle, bins, overlap, bat
             seen += got
         assert seen == R
         st.reset()
+        # rows nobody fetches stay in the ring's slots: the batch that would lap them is refused, not launched
+        with pytest.raises(ro.StftError) as e:
+            st.push(iq[:bins + (slots + batch) * hop])
+        assert "row sink full" in str(e.value)
+        first, got, _ = st.fetch_records(10 * slots)
+        assert first == 0 and 0 < got <= slots
+        st.reset()
         st.set_row_sink(None)
         st.push(iq[:bins + hop])
         st.flush()
