@@ -89,6 +89,10 @@ def parse():
     p.add_argument("--no-legs", action="store_true",
                    help="N > 1: skip the extra untimed-for-`value` runs with the other --gather modes (config.exchange_legs_rows_per_s)")
     p.add_argument("--no-strict", action="store_true", help="skip the RO_PRECISION_F64 side measurement")
+    p.add_argument("--soak-seconds", type=float, default=1.5,
+                   help="N = 1: behind the timed region, keep launching the same step for this long while the clock / "
+                        "power sampler runs (clock_power.soak): the package power the hwmon file reports is an average "
+                        "over about a second, longer than the timed region of the default run (0 = skip)")
     p.add_argument("--pmc-traffic", type=float, default=None,
                    help="HBM bytes per launch from a separate rocprofv3 --pmc run (default: profiles/*_traffic.json)")
     return p.parse_args()
@@ -606,8 +610,24 @@ def main():
     dt = time.perf_counter() - t0
     clock_power = None
     if sampler:
+        # ... and on, outside the timed region: what the package settles at under this kernel (the power reading is a
+        # slow average; the timed region of the default run is 50 ms)
+        t_soak0 = time.perf_counter()
+        soak_steps = 0
+        if world == 1 and a.soak_seconds > 0:
+            while time.perf_counter() - t_soak0 < a.soak_seconds:
+                for i in range(50):
+                    step(i)
+                torch.cuda.synchronize(dev)
+                soak_steps += 50
+        t_soak1 = time.perf_counter()
         sampler.stop()
         clock_power = sampler.summary(t0, t0 + dt)
+        if soak_steps and clock_power.get("available"):
+            tail = sampler.summary(t_soak0 + 0.6 * (t_soak1 - t_soak0), t_soak1)["timed_region"]      # the last 40 % of it
+            clock_power["soak"] = {"seconds": t_soak1 - t_soak0, "steps": soak_steps,
+                                   "ms_per_step": (t_soak1 - t_soak0) / soak_steps * 1e3,
+                                   "last_40_percent": tail}
     gpu_ms_per_step = ev_a.elapsed_time(ev_b) / a.steps       # HIP events on the launch stream, over the timed region
     if world > 1:
         dt = max_over_ranks(dt)
