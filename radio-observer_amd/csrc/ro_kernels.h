@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 #include "../../include/ro_stft.h"
 
@@ -99,6 +100,27 @@ int        f64_radices(int bins, int radices[8]); // passes of the FP64 path for
 hipError_t launch_f64_pass(int radix, bool first, bool last, int fmt, const BigArgsD &a, hipStream_t s);
 // two consecutive passes (radix 16 with a.ns, then radix r2) in one kernel through LDS; n >= 4096
 hipError_t launch_f64_pair(int r2, bool first, bool last, int fmt, const BigArgsD &a, hipStream_t s);
+
+// ---- large transforms as a four-step FFT (bins = n1 x 1024), ro_fourstep.hip
+struct FourArgs {
+    const void   *iq;          // sample 0 of the stream
+    int64_t       first_row, rows;
+    int           hop;
+    float         gain;
+    int           n1;          // bins / 1024
+    const float  *window_a;    // bins floats in the column kernel's order (fourstep_tables)
+    const float2 *tw_a;        // [32][n1 / 32]: exp(-2 pi i k_l m / n1)
+    const float2 *tw_b;        // [n1][16]: powers 2^j, j < 5, of exp(-2 pi i 32 k1 / bins) at 0.., of exp(-2 pi i k1 / bins) at 8..
+    const float2 *tw_r;        // [32][8]: powers 2^j, j < 5, of exp(-2 pi i k_r / 1024)
+    float        *z;           // scratch: rows x n1 x 2048 floats
+    float        *rows_out;    // rows x row_stride, fft-shifted magnitudes
+    int64_t       row_stride;
+};
+bool fourstep_supported(int bins);
+hipError_t launch_fourstep(int format, const FourArgs &a, hipStream_t s);
+// the tables of a size (host side), from the natural window
+void fourstep_tables(int bins, const float *window, std::vector<float> &window_a, std::vector<float2> &tw_a,
+                     std::vector<float2> &tw_b, std::vector<float2> &tw_r);
 
 // ---- large transforms (bins = dec x 32768), see the note in front of fold_kernel
 // First step of the scratch form of a large transform (bins = dec x m, decimation in frequency):

@@ -1250,7 +1250,10 @@ __global__ __launch_bounds__(256) void ln_finish_kernel(const float *part, float
 
 constexpr int SCAN_WAVES = 4;         // rows per workgroup
 
-__global__ __launch_bounds__(64 * SCAN_WAVES) void scan_kernel(ScanArgs a)
+// E: band elements a lane keeps in registers.  Bands up to 64 E columns are loaded ONCE, all loads in flight together;
+// wider ones are re-read by every pass of the radix select, one dependent trip to L2 per 64 columns -- at Ionozor's
+// 524288 bins (bands of thousands of columns) that was 245 us per launch whatever the row count, 8 % of the size's time.
+template <int E> __global__ __launch_bounds__(64 * SCAN_WAVES) void scan_kernel(ScanArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * SCAN_WAVES + (threadIdx.x >> 6);
@@ -1258,10 +1261,10 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void scan_kernel(ScanArgs a)
     const GlobalRow src{a.rows_in + row * a.row_stride};
     __shared__ __attribute__((aligned(16))) unsigned hist[SCAN_WAVES][256];
     unsigned *h = hist[threadIdx.x >> 6];
-    const bool cached = a.noise_width <= 64 * SCAN_E;
-    const float noise = cached ? scan_noise<SCAN_E>(src, a.low_noise, a.noise_width, h, lane)
+    const bool cached = a.noise_width <= 64 * E;
+    const float noise = cached ? scan_noise<E>(src, a.low_noise, a.noise_width, h, lane)
                                : scan_noise<0>(src, a.low_noise, a.noise_width, h, lane);
-    const int peak = scan_peak<SCAN_E>(src, a.low_detect, a.detect_width, lane);
+    const int peak = scan_peak<E>(src, a.low_detect, a.detect_width, lane);
     const float avg = scan_average(src, a.low_detect + peak - a.avg_bins / 2, a.avg_bins, a.bins, lane);
     if (lane == 0) {
         ro_scan_record_t rec;
@@ -1831,7 +1834,10 @@ hipError_t launch_scan(const ScanArgs &a, hipStream_t s)
 {
     if (a.rows <= 0) return hipSuccess;
     const unsigned grid = (unsigned)((a.rows + SCAN_WAVES - 1) / SCAN_WAVES);
-    hipLaunchKernelGGL(scan_kernel, dim3(grid), dim3(64 * SCAN_WAVES), 0, s, a);
+    const int widest = a.noise_width > a.detect_width ? a.noise_width : a.detect_width;
+    if (widest <= 64 * SCAN_E) hipLaunchKernelGGL(scan_kernel<SCAN_E>, dim3(grid), dim3(64 * SCAN_WAVES), 0, s, a);
+    else if (widest <= 64 * 64) hipLaunchKernelGGL(scan_kernel<64>, dim3(grid), dim3(64 * SCAN_WAVES), 0, s, a);
+    else hipLaunchKernelGGL(scan_kernel<128>, dim3(grid), dim3(64 * SCAN_WAVES), 0, s, a);
     return hipGetLastError();
 }
 

@@ -38,6 +38,11 @@
 #ifndef RO_SPEC_SCRATCH_MB
 #define RO_SPEC_SCRATCH_MB 2048
 #endif
+// the four-step form's scratch (one block of Z between its two kernels), MiB: a chunk that stays inside the 256 MiB
+// Infinity Cache keeps the trip off HBM (diagnostic builds: RO_FOUR_SCRATCH_MB)
+#ifndef RO_FOUR_SCRATCH_MB
+#define RO_FOUR_SCRATCH_MB 1024
+#endif
 // RO_PRECISION_F64: MiB per complex-double scratch block (two blocks); the passes of one chunk run back to back, and a
 // chunk that stays inside the 256 MiB Infinity Cache keeps most of the trip between them off HBM: 2.75-2.80 x 10^6
 // rows/s at the C3 shape with 128 against 2.46 with 512, 2.36 with 256, 2.50 with 64, 1.96 with 32 (too few workgroups
@@ -239,6 +244,12 @@ struct ro_stft {
     float  *d_ones = nullptr;          // ... a window of ones (the fold has applied the real one)
     int64_t spec_rows = 0;
     float2 *d_spec2 = nullptr;         // complex spectra of a large size: the sub-rows' spectra before they are interleaved
+    // bins = 262144, 524288: the magnitude rows as a four-step FFT (ro_fourstep.hip): column kernel, scratch, row kernel
+    bool    four = false;
+    float  *d_four_window = nullptr;   // the window in the column kernel's order
+    float2 *d_four_tw_a = nullptr, *d_four_tw_b = nullptr, *d_four_tw_r = nullptr;     // ro::FourArgs
+    float  *d_four_z = nullptr;        // [four_rows][bins] complex
+    int64_t four_rows = 0;
     // lengths that are not a power of two (even 258 .. 524286): Bluestein's chirp-z form on an inner handle of the
     // power-of-two length czt_m >= 2 bins - 1 (see ro::CztArgs)
     bool    czt = false;
@@ -566,6 +577,34 @@ int launch_transform(ro_stft *h, const void *d_iq, int format, int64_t first_row
         }
         ro::StftArgs a = make_stft_args(h, d_iq, first_row, rows, d_rows, row_stride, d_tile, d_records, d_ln);
         HIP_TRY(ro::launch_stft(h->bins, format, a, s));
+        return RO_OK;
+    }
+    if (h->four) {
+        if (!h->d_four_z) {
+            int64_t mib = RO_FOUR_SCRATCH_MB;
+#ifdef RO_DIAG_KNOBS
+            if (const char *e = getenv("RO_FOUR_SCRATCH_MB")) mib = std::max<int64_t>(4, atoll(e));
+#endif
+            h->four_rows = std::max<int64_t>(1, (mib << 20) / ((int64_t)h->bins * 8));
+            HIP_TRY(hipMalloc(&h->d_four_z, (size_t)h->four_rows * h->bins * 2 * sizeof(float)));
+        }
+        for (int64_t done = 0; done < rows; done += h->four_rows) {
+            ro::FourArgs f{};
+            f.iq = d_iq;
+            f.first_row = first_row + done;
+            f.rows = std::min(h->four_rows, rows - done);
+            f.hop = h->hop;
+            f.gain = (float)h->cfg.iq_gain;
+            f.n1 = h->bins / 1024;
+            f.window_a = h->d_four_window;
+            f.tw_a = h->d_four_tw_a;
+            f.tw_b = h->d_four_tw_b;
+            f.tw_r = h->d_four_tw_r;
+            f.z = h->d_four_z;
+            f.rows_out = d_rows + done * row_stride;
+            f.row_stride = row_stride;
+            HIP_TRY(ro::launch_fourstep(format, f, s));
+        }
         return RO_OK;
     }
     if (h->dec > 1 && h->fold) {
@@ -1219,6 +1258,12 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
 #ifdef RO_DIAG_KNOBS
         if (const char *e = getenv("RO_BIG_FORM")) form = std::strcmp(e, "dif") == 0 ? 1 : 2;
 #endif
+        // 262144 and 524288: the four-step form for the magnitude rows (the fold form stays for their complex spectra)
+        bool four = ro::fourstep_supported(h->bins);
+#ifdef RO_DIAG_KNOBS
+        if (const char *e = getenv("RO_BIG_FORM")) four = std::strcmp(e, "four") == 0;
+#endif
+        h->four = four;
         h->dif = form == 1;
         h->fold = form == 2;
         h->sub_bins = sub;
@@ -1326,6 +1371,19 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
         CREATE_TRY(hipMalloc(&h->d_dif_shift, sizeof(float2) * ts.size()));
         CREATE_TRY(hipMemcpy(h->d_dif_shift, ts.data(), sizeof(float2) * ts.size(), hipMemcpyHostToDevice));
     }
+    if (h->four) {
+        std::vector<float> wa;
+        std::vector<float2> ta, tb, tr;
+        ro::fourstep_tables(h->bins, h->window.data(), wa, ta, tb, tr);
+        CREATE_TRY(hipMalloc(&h->d_four_window, sizeof(float) * wa.size()));
+        CREATE_TRY(hipMemcpy(h->d_four_window, wa.data(), sizeof(float) * wa.size(), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMalloc(&h->d_four_tw_a, sizeof(float2) * ta.size()));
+        CREATE_TRY(hipMemcpy(h->d_four_tw_a, ta.data(), sizeof(float2) * ta.size(), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMalloc(&h->d_four_tw_b, sizeof(float2) * tb.size()));
+        CREATE_TRY(hipMemcpy(h->d_four_tw_b, tb.data(), sizeof(float2) * tb.size(), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMalloc(&h->d_four_tw_r, sizeof(float2) * tr.size()));
+        CREATE_TRY(hipMemcpy(h->d_four_tw_r, tr.data(), sizeof(float2) * tr.size(), hipMemcpyHostToDevice));
+    }
     if (h->czt) {
         const int N = h->bins, M = h->czt_m;
         // the inner handle: length M, overlap 0, a window of ones, no bands / tile
@@ -1411,6 +1469,11 @@ extern "C" int ro_stft_destroy(ro_stft_t *h)
     if (h->d_czt_A) (void)hipFree(h->d_czt_A);
     if (h->d_czt_mag) (void)hipFree(h->d_czt_mag);
     if (h->d_spec2) (void)hipFree(h->d_spec2);
+    if (h->d_four_window) (void)hipFree(h->d_four_window);
+    if (h->d_four_tw_a) (void)hipFree(h->d_four_tw_a);
+    if (h->d_four_tw_b) (void)hipFree(h->d_four_tw_b);
+    if (h->d_four_tw_r) (void)hipFree(h->d_four_tw_r);
+    if (h->d_four_z) (void)hipFree(h->d_four_z);
     if (h->d_mag) (void)hipFree(h->d_mag);
     if (h->d_ones) (void)hipFree(h->d_ones);
     if (h->d_dif_tw) (void)hipFree(h->d_dif_tw);

@@ -29,6 +29,15 @@ def test_stft32k_layout_reproduces_the_fft_without_bank_conflicts():
     assert "LDS bytes: 131328" in out
 
 
+def test_fourstep_maps_reproduce_the_fft():
+    """tools/r4/emu_four.py: the column kernel's sample / window / exchange / scratch addresses, the scratch order, the
+    row kernel's loads, twiddle tables and output columns of csrc/ro_fourstep.hip at 262144 and 524288 bins"""
+    out = run("emu_four.py", where="r4")
+    for bins in (262144, 524288):
+        assert "bins = %d: column kernel: samples, window table, exchange and scratch addresses" % bins in out
+        assert "bins = %d: row kernel: scratch loads, twiddle tables, fft-shifted columns of the read-back" % bins in out
+
+
 def test_the_general_form_agrees_at_32_points_per_wave_column():
     """tools/r3/emu_wl.py is the derivation of round 3's layout (ds_read_b32 gathers, rows of 1025 floats) for 32.32.S;
     it stays as the record of the experiment in tools/r3/ro_stft_wl.hip"""

@@ -9,7 +9,7 @@ Restated with numpy and checked BEFORE anything runs on a GPU:
      numpy's FFT of a windowed row;
   3. bank conflicts per wave-instruction (ds_read_b64: two groups of 32 lanes over 64 banks);
   4. 8-byte alignment of every ds_read_b64, and the M0 / offset splits of the add-TID writes (16 bits each).
-Constants must match csrc/ro_stft32k.hip (RQ, HB, XB)."""
+Constants must match csrc/ro_k32_lds.h (RQ, HB, XB)."""
 import os
 import re
 import numpy as np
@@ -211,7 +211,7 @@ def window_table(w):
 
 
 def check_kernel():
-    src = open(KRN).read()
+    src = open(os.path.join(os.path.dirname(KRN), "ro_k32_lds.h")).read()
     for name, val in (("RQ", RQ), ("HB", HB), ("XB", XB)):
         assert re.search(r"constexpr int %s = %d;" % (name, val), src), name
     rng = np.random.default_rng(1)
