@@ -298,6 +298,7 @@ template <int N> struct ImageRow {
     __device__ __forceinline__ float operator()(int c) const { return img[(c + N / 2) & (N - 1)]; }
 };
 
+constexpr int SCAN_BATCH = 16;        // loads in flight per lane where a band is re-read instead of kept
 constexpr int SCAN_E = 16;            // noise-band elements cached per lane by the CACHED form (band <= 1024)
 
 // maximum / minimum over the 64 lanes, VALU only (the same DPP ladder as wave_inclusive_sum with max in the place of
@@ -348,9 +349,17 @@ __device__ __forceinline__ float scan_noise(Row row, int low_noise, int W, unsig
             for (int e = 0; e < E; ++e)
                 if (64 * e < W) f(keys[e], lane + 64 * e < W);
         } else {
-            for (int i0 = 0; i0 < W; i0 += 64) {
-                const int i = i0 + lane;
-                f(order_key(row(low_noise + (i < W ? i : W - 1))), i < W);
+            // sixteen loads in flight at a time (one trip to the row per 1024 columns, not per 64)
+            for (int i0 = 0; i0 < W; i0 += 64 * SCAN_BATCH) {
+                float x[SCAN_BATCH];
+#pragma unroll
+                for (int b = 0; b < SCAN_BATCH; ++b) {
+                    const int i = i0 + 64 * b + lane;
+                    x[b] = row(low_noise + (i < W ? i : W - 1));
+                }
+#pragma unroll
+                for (int b = 0; b < SCAN_BATCH; ++b)
+                    if (i0 + 64 * b < W) f(order_key(x[b]), i0 + 64 * b + lane < W);
             }
         }
     };
@@ -436,9 +445,18 @@ __device__ __forceinline__ int scan_peak(Row row, int low_detect, int DW, int la
             if (i < DW && (best_i < 0 || xs[e] >= best)) { best = xs[e]; best_i = i; }
         }
     } else {
-        for (int i = lane; i < DW; i += 64) {
-            const float x = row(low_detect + i);
-            if (best_i < 0 || x >= best) { best = x; best_i = i; }
+        for (int i0 = 0; i0 < DW; i0 += 64 * SCAN_BATCH) {
+            float xs[SCAN_BATCH];
+#pragma unroll
+            for (int b = 0; b < SCAN_BATCH; ++b) {
+                const int i = i0 + 64 * b + lane;
+                xs[b] = row(low_detect + (i < DW ? i : DW - 1));
+            }
+#pragma unroll
+            for (int b = 0; b < SCAN_BATCH; ++b) {
+                const int i = i0 + 64 * b + lane;
+                if (i < DW && (best_i < 0 || xs[b] >= best)) { best = xs[b]; best_i = i; }
+            }
         }
     }
     // cross-lane: the largest value, then the largest index among the lanes that hold it (two DPP reductions)

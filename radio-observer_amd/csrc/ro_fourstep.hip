@@ -6,8 +6,14 @@
 //   n = 1024 n1 + n2          k = k1 + N1 k2                                   (n1, k1 < N1;  n2, k2 < 1024)
 //   X[k1 + N1 k2] = sum_n2 W_1024^(n2 k2) { W_M^(n2 k1) sum_n1 W_N1^(n1 k1) w[n] x[n] }
 //
+// Both kernels run as ONE workgroup of 1024 threads per CU, 32768 points per block, 32 per thread -- the row kernel's
+// shape.  (RO_FOUR_WAVES=8 builds them as workgroups of 512 threads, two to a CU, each with half the registers and
+// half the LDS, so that one can transform while the other's block is on its way: measured slower, 414 / 337 us per 256
+// rows against 397 / 269 -- the kernels move bytes at the speed of a copy either way, and the half-sized blocks of
+// the row kernel write half cache lines.  profiles/r04_fourstep.txt.)
+//
 // four_cols_kernel  (the inner sum: N1-point transforms down the columns n2).  A workgroup takes C = 32768 / N1
-//   neighbouring columns of one stream row -- 32768 points, 32 per thread, the row kernel's shape.  n1 = m + R2 l
+//   columns of one stream row (whole pairs of the scratch order, below).  n1 = m + R2 l
 //   (R2 = N1 / 32): thread (m, column) loads its 32 legs l (each wave-load 64 neighbouring samples), multiplies by the
 //   window, radix-32 over l -> k_l; an exchange over the workgroup through LDS (one component plane at a time, like
 //   exchange 1 of the row kernel); thread (k_l's, column) multiplies by W_N1^(m k_l) and finishes with radix-R2 over m
@@ -22,8 +28,8 @@
 //
 // Scratch order ("planar pairs"): row k1 = 16 x 32 quads, quad (i, a) = { re Z[a + 32 (2i)], re Z[a + 32 (2i + 1)],
 //   im ..., im ... } -- what thread (k1, a) of pass 1 holds in R[i], I[i]: one 16-byte load per register quad, no
-//   shuffling.  The column kernel gets there with one v_permlane32_swap per point (lanes c, c + 32 of its waves hold
-//   the two mates).
+//   shuffling.  The column kernel gets there with one lane swap per point: its waves hold the two mates of a pair in
+//   lanes l, l + 32 (C >= 64: v_permlane32_swap) or l, l + 16 (C = 32: v_permlane16_swap).
 //
 // HBM / Infinity Cache traffic per stream row: 8 hop (samples) + 8 M out + 8 M in (scratch) + 4 M (the row) against the
 // 28 M of the fold / transform / interleave form it replaces.
@@ -38,27 +44,57 @@
 #include <mutex>
 #include <vector>
 
-// cache policy of the scratch traffic (gfx950 aux bits: 1 = sc0, 2 = nt, 16 = sc1)
-#ifndef RO_FOUR_Z_ST_AUX
-#define RO_FOUR_Z_ST_AUX 0
-#endif
-#ifndef RO_FOUR_Z_LD_AUX
-#define RO_FOUR_Z_LD_AUX 2
+// The ONE diagnostic switch of this file: a -DRO_DIAG=1 build (tools/ab_build.sh) may set RO_FOUR_WAVES=8 (see above).
+#if !defined(RO_DIAG) || !defined(RO_FOUR_WAVES)
+#undef RO_FOUR_WAVES
+#define RO_FOUR_WAVES 16
 #endif
 
 namespace ro {
 namespace four {
 
-using k32::RQ;
-using k32::HB;
-using k32::T;
-using k32::own_write4;
-using k32::own_write_plane;
 using k32::lds_vpair;
 
+// cache policy of the scratch traffic (gfx950 aux bits: 1 = sc0, 2 = nt, 16 = sc1): the column kernel's stores plain,
+// the row kernel's loads nt -- each byte of Z is read once (172 -> 142 us per 128 rows; nt on the stores: no change with
+// scratch blocks past the Infinity Cache, 5 % slower inside it; profiles/r04_fourstep.txt)
+constexpr int Z_ST_AUX = 0, Z_LD_AUX = 2;
+
 constexpr int N2 = 1024;
-constexpr int BLOCK = 32768;                       // points per workgroup and block, both kernels
+constexpr int WAVES = RO_FOUR_WAVES, T = 64 * WAVES;   // one workgroup of 1024 per CU (8: two of 512, see the header)
+static_assert(WAVES == 16 || WAVES == 8, "workgroup shapes");
+constexpr int BLOCK = 32 * T;                      // points per workgroup and block, both kernels
 constexpr int COLS_LDS = BLOCK * 4;                // one component plane of a block
+// rows kernel: cell(q, w, l) = RQ q + 64 w + l as in ro_k32_lds.h, one territory per wave: 1026 floats per row (514 for
+// eight waves: = 2 mod 64 as well).  The add-TID writes of rows >= 16 take k32::HB into M0 where 4 RQ 31 does not fit
+// the 16 bits of the offset field (ro_k32_lds.h).
+constexpr int RQ = 64 * WAVES + 2;
+constexpr int HBQ = 4 * RQ * 31 > 65535 ? k32::HB : 0;
+static_assert(RQ != 1026 || RQ == k32::RQ, "the row kernel's layout");
+constexpr int ROWS_LDS = 32 * RQ * 4;
+constexpr int BROWS = 2 * WAVES;                   // rows k1 per block
+constexpr int ROT = 64 / WAVES;                    // pass 2's lane rotation per pair of waves (4: ro_stft32k.hip)
+
+// rows QA, QB (< 16) and QC, QD (>= 16) of the wave's own territory (M0 = mc = 256 wave, md = mc + HBQ), and a plane
+template <int QA, int QB, int QC, int QD>
+__device__ __forceinline__ void own_write4(unsigned mc, unsigned md, float sa, float sb, float sc, float sd)
+{
+    static_assert(QA < 16 && QB < 16 && QC >= 16 && QD >= 16 && QC < 32 && QD < 32, "row algebra");
+    constexpr int R = 4 * RQ;
+    static_assert(R * 15 <= 65535 && R * 31 - HBQ <= 65535 && R * 16 - HBQ >= 0 && 15 * 256 + HBQ <= 65535, "M0 / offset split");
+    addtid_write4<R * QA, R * QB, R * QC - HBQ, R * QD - HBQ>(mc, md, sa, sb, sc, sd);
+}
+template <typename F> __device__ __forceinline__ void own_write_plane(unsigned mc, unsigned md, F f)
+{
+    constexpr int R = 4 * RQ, H = HBQ;
+    addtid_write8<0 * R, 1 * R, 2 * R, 3 * R, 4 * R, 5 * R, 6 * R, 7 * R>(mc, f(0), f(1), f(2), f(3), f(4), f(5), f(6), f(7));
+    addtid_write8<8 * R, 9 * R, 10 * R, 11 * R, 12 * R, 13 * R, 14 * R, 15 * R>(mc, f(8), f(9), f(10), f(11), f(12), f(13),
+                                                                                  f(14), f(15));
+    addtid_write8<16 * R - H, 17 * R - H, 18 * R - H, 19 * R - H, 20 * R - H, 21 * R - H, 22 * R - H, 23 * R - H>(
+        md, f(16), f(17), f(18), f(19), f(20), f(21), f(22), f(23));
+    addtid_write8<24 * R - H, 25 * R - H, 26 * R - H, 27 * R - H, 28 * R - H, 29 * R - H, 30 * R - H, 31 * R - H>(
+        md, f(24), f(25), f(26), f(27), f(28), f(29), f(30), f(31));
+}
 constexpr int PIPE_UNITS = 6;                      // rows kernel: quads of the next block requested from pass 2's last level
 
 // x w for a twiddle the whole wave shares (SGPRs: no inline asm, which would want it in VGPRs)
@@ -82,19 +118,31 @@ __device__ __forceinline__ Run xcd_run(int64_t nblk)
 
 // ---------------------------------------------------------------------------------------------------------------
 // columns: Z[k1][n2] = sum_n1 W_N1^(n1 k1) w[n] x[n]
-template <int FMT, int R2> __global__ __launch_bounds__(T, 1) void four_cols_kernel(FourArgs a)
+//
+// Block cg of a stream row (1024 / C of them) and thread t = C grp + lam of the workgroup:
+//   C >= 64: columns n2 = C cg + lam: a wave holds a = lane & 31 of b, b + 1 (b even): mates in lanes l, l + 32
+//   C = 32:  a = 16 (cg & 1) + (lam & 15) of b = 2 (cg >> 1) + (lam >> 4): mates in lanes l, l + 16; a wave-load of one
+//            leg is four runs of 128 bytes
+// (fourstep_column() is the same map for the host's window table.)
+template <int C> __host__ __device__ constexpr int fourstep_column(int cg, int lam)
+{
+    return C >= 64 ? C * cg + lam : (16 * (cg & 1) + (lam & 15)) + 32 * (2 * (cg >> 1) + (lam >> 4));
+}
+
+template <int FMT, int R2> __global__ __launch_bounds__(T, 4) void four_cols_kernel(FourArgs a)   // 4 waves per SIMD: 128 VGPRs
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using S = Sample<FMT>;
-    constexpr int N1 = 32 * R2, C = T / R2, SETS = 32 / R2, M = N1 * N2;
-    static_assert(C >= 64, "a wave's lanes are 64 neighbouring columns (the mates of the scratch order are lanes c, c + 32)");
+    constexpr int N1 = 32 * R2, C = T / R2, SETS = 32 / R2, M = N1 * N2, GROUPS = N2 / C;
+    static_assert(C == 128 || C == 64 || C == 32, "the lane swaps of the scratch order");
     float *lds = reinterpret_cast<float *>(smem);
 
-    Run run = xcd_run(a.rows * R2);                                  // R2 = 1024 / C column groups per stream row
+    Run run = xcd_run(a.rows * GROUPS);
     if (run.blk >= run.end) return;
     const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = __builtin_amdgcn_readfirstlane(tid / C);         // m in front of the exchange, the k_l set behind it
+    // m in front of the exchange, the k_l set behind it (C >= 64: the wave's; C = 32: the half-wave's)
+    const int grp = C >= 64 ? __builtin_amdgcn_readfirstlane(tid / C) : tid / C;
+    const int lam = tid % C;
     const char *iq = reinterpret_cast<const char *>(a.iq);
 
     v2f v[32];
@@ -105,12 +153,12 @@ template <int FMT, int R2> __global__ __launch_bounds__(T, 1) void four_cols_ker
         int vo;
     };
     auto source = [&](int64_t blk, bool valid) {
-        const int64_t s = blk / R2;
-        const int cg = (int)(blk % R2);
+        const int64_t s = blk / GROUPS;
+        const int cg = (int)(blk % GROUPS);
         Src src;
         src.rs = make_rsrc(iq + (a.first_row + s) * (int64_t)a.hop * S::BYTES, valid ? (unsigned)M * S::BYTES : 0u);
         src.rw = make_rsrc(a.window_a + (size_t)cg * 8 * T * 4, valid ? 8 * T * 16 : 0);
-        src.vo = (N2 * grp + C * cg + (tid % C)) * S::BYTES;
+        src.vo = (N2 * grp + fourstep_column<C>(cg, lam)) * S::BYTES;
         return src;
     };
     auto load_legs = [&](const Src &src, int vo, auto lo_c, auto hi_c) {
@@ -133,6 +181,7 @@ template <int FMT, int R2> __global__ __launch_bounds__(T, 1) void four_cols_ker
         load_legs(src, src.vo, c0{}, c32{});
         load_window(src, tid * 16);
     }
+    const __amdgpu_buffer_rsrc_t rs_twa = make_rsrc(a.tw_a, 32 * R2 * 8);
 
     for (;;) {
         const int64_t blk = run.blk, next = blk + run.stride;
@@ -152,7 +201,7 @@ template <int FMT, int R2> __global__ __launch_bounds__(T, 1) void four_cols_ker
             }
         }
         dit<32>(v);                                              // result k_l at v[bitrev32(k_l)]
-        // ---- exchange: plane[k_l][tid] <- this thread's k_l; thread (set g, column) reads k_l = SETS g + h, every m
+        // ---- exchange: plane[k_l][tid] <- this thread's k_l; thread (set grp, column) reads k_l = SETS grp + h, every m
         v2f u[32];                                               // u[R2 h + m]
         wg_sync();                                               // the last block's reads of the plane are done
 #pragma unroll
@@ -161,7 +210,7 @@ template <int FMT, int R2> __global__ __launch_bounds__(T, 1) void four_cols_ker
 #pragma unroll
         for (int h = 0; h < SETS; ++h)
 #pragma unroll
-            for (int m = 0; m < R2; ++m) u[R2 * h + m].x = lds[(SETS * grp + h) * T + m * C + (tid % C)];
+            for (int m = 0; m < R2; ++m) u[R2 * h + m].x = lds[(SETS * grp + h) * T + m * C + lam];
         wg_sync();
 #pragma unroll
         for (int k = 0; k < 32; ++k) lds[k * T + tid] = v[bitrev<32>(k)].y;
@@ -169,42 +218,58 @@ template <int FMT, int R2> __global__ __launch_bounds__(T, 1) void four_cols_ker
 #pragma unroll
         for (int h = 0; h < SETS; ++h)
 #pragma unroll
-            for (int m = 0; m < R2; ++m) u[R2 * h + m].y = lds[(SETS * grp + h) * T + m * C + (tid % C)];
+            for (int m = 0; m < R2; ++m) u[R2 * h + m].y = lds[(SETS * grp + h) * T + m * C + lam];
         // The next block's samples and coefficients: v and w4 are free from here on, but 128 VGPRs do not hold them
         // next to u -- the first half of the legs now, the second when half of u has left, the window at the end.
         const Src nsrc = source(has_next ? next : blk, has_next);
         load_legs(nsrc, nsrc.vo, c0{}, c16{});
-        // ---- W_N1^(m k_l) (one table row per k_l, the same for the whole wave: scalar loads), radix-R2 over m, out
-        const int64_t s = blk / R2;
-        const int cg = (int)(blk % R2);
-        // row k1 of stream row s: 2048 floats at ((s N1 + k1) 2048); this wave's 64 columns are a = lane & 31 of
-        // b = 2 i + p, i = (C / 64) cg + (wave's half of the group), p = lane >> 5
-        const int i_quad = (C / 64) * cg + (C == 128 ? (wave & 1) : 0);
+        // ---- W_N1^(m k_l), radix-R2 over m, out
+        const int64_t s = blk / GROUPS;
+        const int cg = (int)(blk % GROUPS);
+        // row k1 of stream row s: 2048 floats at (s N1 + k1) 2048; quad (i, a) of this lane's column at (32 i + a) 4.
+        // Behind the lane swap the lanes of the mate p = 0 hold the pair of imaginary parts (floats 2, 3 of the quad),
+        // those of p = 1 the real parts.
         const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.z + (size_t)s * N1 * 2048, (unsigned)N1 * 2048u * 4u);
-        const int lane = tid & 63;
-        // lanes < 32 store the pair of imaginary parts (floats 2, 3 of the quad), lanes >= 32 the real parts
-        const int zo = ((i_quad * 32 + (lane & 31)) * 4 + (lane < 32 ? 2 : 0)) * 4;
+        const int n2 = fourstep_column<C>(cg, lam);
+        const int mate_p = (n2 >> 5) & 1;
+        // (C = 32: the half-waves' k_l sets differ -- their part of the row number is in the lane's offset)
+        const int zo = (((n2 >> 6) * 32 + (n2 & 31)) * 4 + (mate_p ? 0 : 2)) * 4 + (C == 32 ? SETS * grp * 8192 : 0);
+        const int zs = C >= 64 ? SETS * grp * 8192 : 0;
         float last = 0.0f;
 #pragma unroll
         for (int h = 0; h < SETS; ++h) {
-            const int kl = SETS * grp + h;
-            const float2 *ta = a.tw_a + kl * R2;
+            if constexpr (C >= 64) {
+                // one table row per k_l, the same for the whole wave: scalar loads
+                const float2 *ta = a.tw_a + (SETS * grp + h) * R2;
 #pragma unroll
-            for (int m = 1; m < R2; ++m) {
-                const float2 t = ta[m];
-                u[R2 * h + m] = cmul_u(u[R2 * h + m], (v2f){t.x, t.y});
+                for (int m = 1; m < R2; ++m) {
+                    const float2 t = ta[m];
+                    u[R2 * h + m] = cmul_u(u[R2 * h + m], (v2f){t.x, t.y});
+                }
+            } else {
+#pragma unroll
+                for (int m = 1; m < R2; ++m)
+                    u[R2 * h + m] = cmul(u[R2 * h + m], buf_load_f2(rs_twa, SETS * grp * R2 * 8, (h * R2 + m) * 8));
             }
             dit<R2>(&u[R2 * h]);                                 // result k_m at position bitrev_R2(k_m)
 #pragma unroll
             for (int km = 0; km < R2; ++km) {
                 const v2f z = u[R2 * h + bitrev<R2>(km)];
-                // lanes c < 32 and c + 32 hold the mates: (v0, v1) = (im, re) -> lanes < 32 (im, im'), lanes >= 32 (re, re')
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(z.y), __float_as_uint(z.x), false, false);
-                __builtin_amdgcn_raw_buffer_store_b64((u32x2){sw[0], sw[1]}, rz, zo, (kl + 32 * km) * 8192, RO_FOUR_Z_ST_AUX);
-                last = __uint_as_float(sw[1]);
+                // (v0, v1) = (im, re) -> the lanes of p = 0: (im, im'), the lanes of p = 1: (re, re')
+                u32x2 sw;
+                if constexpr (C >= 64) {
+                    const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(z.y), __float_as_uint(z.x), false, false);
+                    sw = (u32x2){t[0], t[1]};
+                } else {
+                    const auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(z.y), __float_as_uint(z.x), false, false);
+                    sw = (u32x2){t[0], t[1]};
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(sw, rz, zo, zs + (h + 32 * km) * 8192, Z_ST_AUX);
+                last = __uint_as_float(sw.y);
             }
-            if (h == SETS / 2 - 1) load_legs(nsrc, after(nsrc.vo, last), c16{}, c32{});
+            if (SETS > 1 && h == SETS / 2 - 1) load_legs(nsrc, after(nsrc.vo, last), c16{}, c32{});
         }
+        if (SETS == 1) load_legs(nsrc, after(nsrc.vo, last), c16{}, c32{});
         load_window(nsrc, after(tid * 16, last));
         if (!has_next) break;
         run.blk = next;
@@ -213,12 +278,22 @@ template <int FMT, int R2> __global__ __launch_bounds__(T, 1) void four_cols_ker
 
 // ---------------------------------------------------------------------------------------------------------------
 // rows: X[k1 + N1 k2] = sum_n2 W_1024^(n2 k2) W_M^(n2 k1) Z[k1][n2], |X| to column (k + M/2) mod M of the row
-__global__ __launch_bounds__(T, 1) void four_rows_kernel(FourArgs a)
+//
+// ro_stft32k.hip's maps (rho = k1 - BROWS g plays k0's part, k_r is k1's, k_c is k2's):
+//   pass 1:      lane (a >> 1) + 16 (a & 1) + 32 kb of wave w is thread (rho = 2 w + kb, a); slots b = 2 i, 2 i + 1 are
+//                quad (i, a) of its scratch row
+//   exchange 2:  slot k_r of that thread -> cell(k_r, w, lane); pass-2 lane l' of wave w is thread
+//                (rho = 2 w + (l' & 1), k_r = ((l' >> 1) + ROT (w >> 1)) & 31) and reads slots a = 4 u + p, 4 u + p + 2
+//                from cell(k_r, w, 2 u + 16 p + 32 kb), + 1
+//   image:       slot k_c of that thread -> cell(k_c, w, l').  The rotation (4 per pair of waves with sixteen waves, 8
+//                with eight) makes the read-back (two ds_read_b64 per lane: territories w, w + 1 = four neighbouring
+//                rho) conflict-free.  tools/r4/emu_four.py checks all of it.
+__global__ __launch_bounds__(T, 4) void four_rows_kernel(FourArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using namespace planar;
     const float *lds = reinterpret_cast<const float *>(smem);
-    const int G = a.n1 >> 5;                                         // blocks (of 32 rows k1) per stream row
+    const int G = a.n1 / BROWS;                                      // blocks per stream row
     Run run = xcd_run(a.rows * G);
     if (run.blk >= run.end) return;
     const int tid = threadIdx.x;
@@ -229,12 +304,13 @@ __global__ __launch_bounds__(T, 1) void four_rows_kernel(FourArgs a)
         asm volatile("" : "+v"(lt));
         lane = lt & 63;
     }
-    // pass 1: thread (row rho = 2 wave + kb, a): lane (a >> 1) + 16 (a & 1) + 32 kb; quads i < 16 of its row
     const int zo = ((2 * wave + (lane >> 5)) * 2048 + (2 * (lane & 15) + ((lane >> 4) & 1)) * 4) * 4;
     v2f R[16], I[16];
-    auto z_rsrc = [&](int64_t blk, bool valid) { return make_rsrc(a.z + (size_t)blk * (32 * 2048), valid ? 32u * 2048u * 4u : 0u); };
+    auto z_rsrc = [&](int64_t blk, bool valid) {
+        return make_rsrc(a.z + (size_t)blk * (BROWS * 2048), valid ? (unsigned)BROWS * 2048u * 4u : 0u);
+    };
     auto load_quad = [&](const __amdgpu_buffer_rsrc_t &rs, int off, int i) {
-        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, i * 512, RO_FOUR_Z_LD_AUX);
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, i * 512, Z_LD_AUX);
         R[i] = (v2f){__uint_as_float(t.x), __uint_as_float(t.y)};
         I[i] = (v2f){__uint_as_float(t.z), __uint_as_float(t.w)};
     };
@@ -243,15 +319,15 @@ __global__ __launch_bounds__(T, 1) void four_rows_kernel(FourArgs a)
 #pragma unroll
         for (int i = 0; i < 16; ++i) load_quad(rs, zo, i);
     }
-    // pass 2: thread (row rho = 2 wave + kbp, k_r = k1p)
-    const int k1p = ((lane >> 1) + 4 * (wave >> 1)) & 31, kbp = lane & 1;
+    const int k1p = ((lane >> 1) + ROT * (wave >> 1)) & 31, kbp = lane & 1;
     const __amdgpu_buffer_rsrc_t rs_twr = make_rsrc(a.tw_r, 32 * 8 * 8);
 
-    // the image of the block before this one: chunk q = segments k_c = 4 q + (tid >> 8), bins beta = 4 m .. 4 m + 3 of it
-    // (m = tid & 255): rows rho = 4 (m & 7) + i of k_r = m >> 3 -- four neighbouring columns
-    // 32 g + rho + N1 ((k_r + 32 k_c + 512) & 1023) of the fft-shifted row (src/WaterfallBackend.cpp:492-505)
-    int rb_base = RQ * (tid >> 8) + 128 * (tid & 7) + 2 * ((((tid & 255) >> 3) - 4 * (tid & 7)) & 31);
-    const int out_vo = (4 * (tid & 7) + a.n1 * ((tid & 255) >> 3) + a.n1 * 32 * (tid >> 8)) * 4;
+    // the image of the block before this one: chunk q = segments k_c = 4 q + t_hi (t_hi = tid / (T / 4)); m = tid mod
+    // (T / 4): rows rho = 4 j + i (j = m mod (WAVES / 2)) of k_r = m / (WAVES / 2) -- four neighbouring columns
+    // BROWS g + rho + N1 ((k_r + 32 k_c + 512) & 1023) of the fft-shifted row (src/WaterfallBackend.cpp:492-505)
+    const int t_hi = tid / (T / 4), rj = tid % (WAVES / 2), r_kr = (tid % (T / 4)) / (WAVES / 2);
+    int rb_base = RQ * t_hi + 128 * rj + 2 * ((r_kr - ROT * rj) & 31);
+    const int out_vo = (4 * rj + a.n1 * r_kr + a.n1 * 32 * t_hi) * 4;
     const float *prev_out = a.rows_out;
     unsigned prev_bytes = 0;
     auto store_chunk = [&](int q, const __amdgpu_buffer_rsrc_t &rs) {
@@ -261,7 +337,7 @@ __global__ __launch_bounds__(T, 1) void four_rows_kernel(FourArgs a)
         const v2f x01 = p[0], x23 = p[32];
         buf_store_f4(x01.x, x01.y, x23.x, x23.y, rs, out_vo, a.n1 * 128 * ((q + 4) & 7) * 4);
     };
-    const unsigned mc = (unsigned)wave * 256u, md = mc + (unsigned)HB;
+    const unsigned mc = (unsigned)wave * 256u, md = mc + (unsigned)HBQ;
 
     for (;;) {
         const int64_t blk = run.blk, next = blk + run.stride;
@@ -269,9 +345,9 @@ __global__ __launch_bounds__(T, 1) void four_rows_kernel(FourArgs a)
         const int g = (int)(blk % G);
         const int64_t s = blk / G;
         const __amdgpu_buffer_rsrc_t rs_prev = make_rsrc(prev_out, prev_bytes);
-        // stage twiddles of the wave's two rows k1 = 32 g + 2 wave (+ 1): [k1][16] = five powers 2^j of W_M^(32 k1) at
+        // stage twiddles of the wave's two rows k1 = 16 g + 2 wave (+ 1): [k1][16] = five powers 2^j of W_M^(32 k1) at
         // 0..4 and of W_M^(k1) at 8..12 -- uniform addresses: the scalar cache
-        const float2 *tb = a.tw_b + (size_t)(32 * g + 2 * wave) * 16;
+        const float2 *tb = a.tw_b + (size_t)(BROWS * g + 2 * wave) * 16;
         v2f tw1[5], tw2[5];
         {
             const bool odd = lane >= 32;
@@ -364,8 +440,8 @@ __global__ __launch_bounds__(T, 1) void four_rows_kernel(FourArgs a)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the add-TID image writes (hipcc does not count them)
             wg_sync();                                           // (e) the image of this block is complete
         }
-        prev_out = a.rows_out + s * a.row_stride + 32 * g;
-        prev_bytes = (unsigned)(a.n1 * N2 - 32 * g) * 4u;
+        prev_out = a.rows_out + s * a.row_stride + BROWS * g;
+        prev_bytes = (unsigned)(a.n1 * N2 - BROWS * g) * 4u;
         if (!has_next) break;
         run.blk = next;
     }
@@ -407,7 +483,7 @@ template <typename K> static hipError_t prepare(K kernel, int lds_bytes, int &cu
 static unsigned grid_for(int cus, int64_t nblk)
 {
     const int64_t per_xcd = (nblk + 7) / 8;
-    int64_t slots = cus / 8;
+    int64_t slots = (16 / WAVES) * (cus / 8);                    // workgroups per XCD
     if (slots < 1) slots = 1;
     if (slots > per_xcd) slots = per_xcd;
     return (unsigned)(slots * 8);
@@ -418,29 +494,30 @@ template <int FMT, int R2> static hipError_t launch_cols(const FourArgs &a, hipS
     int cus = 0;
     hipError_t e = prepare(&four_cols_kernel<FMT, R2>, COLS_LDS, cus);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((four_cols_kernel<FMT, R2>), dim3(grid_for(cus, a.rows * R2)), dim3(T), COLS_LDS, s, a);
+    hipLaunchKernelGGL((four_cols_kernel<FMT, R2>), dim3(grid_for(cus, a.rows * (N2 / (T / R2)))), dim3(T), COLS_LDS, s, a);
     return hipGetLastError();
 }
 
 }  // namespace four
 
-bool fourstep_supported(int bins) { return bins == 262144 || bins == 524288; }
+bool fourstep_supported(int bins) { return bins == 262144 || bins == 524288 || (bins == 1048576 && four::WAVES == 16); }
 
 // tables of a size (host; the C ABI uploads them): see FourArgs
 void fourstep_tables(int bins, const float *window, std::vector<float> &window_a, std::vector<float2> &tw_a,
                      std::vector<float2> &tw_b, std::vector<float2> &tw_r)
 {
-    const int n1 = bins / 1024, r2 = n1 / 32, c = 1024 / r2;
+    const int n1 = bins / 1024, r2 = n1 / 32, c = four::T / r2, groups = 1024 / c;
     const long double tau = -2.0L * 3.14159265358979323846264338327950288L;
-    // window: thread t = m c + col of column group cg reads quad q = legs l = 4 q .. 4 q + 3 at ((cg 8 + q) 1024 + t) 4:
-    // w[1024 (m + r2 l) + c cg + col]
+    // window: thread t = m c + lam of block cg reads quad q = legs l = 4 q .. 4 q + 3 at ((cg 8 + q) T + t) 4:
+    // w[1024 (m + r2 l) + column(cg, lam)]
     window_a.assign((size_t)bins, 0.0f);
-    for (int cg = 0; cg < r2; ++cg)
+    for (int cg = 0; cg < groups; ++cg)
         for (int q = 0; q < 8; ++q)
-            for (int t = 0; t < 1024; ++t)
+            for (int t = 0; t < four::T; ++t)
                 for (int e = 0; e < 4; ++e) {
-                    const int m = t / c, col = t % c, l = 4 * q + e;
-                    window_a[(((size_t)cg * 8 + q) * 1024 + t) * 4 + e] = window[(size_t)1024 * (m + r2 * l) + c * cg + col];
+                    const int m = t / c, lam = t % c, l = 4 * q + e;
+                    const int col = c >= 64 ? c * cg + lam : four::fourstep_column<32>(cg, lam);
+                    window_a[(((size_t)cg * 8 + q) * four::T + t) * 4 + e] = window[(size_t)1024 * (m + r2 * l) + col];
                 }
     tw_a.assign((size_t)32 * r2, float2{1.0f, 0.0f});
     for (int kl = 0; kl < 32; ++kl)
@@ -470,14 +547,16 @@ hipError_t launch_fourstep(int fmt, const FourArgs &a, hipStream_t s)
     if (a.rows <= 0) return hipSuccess;
     if (!fourstep_supported(a.n1 * 1024) || !a.z || !a.window_a || !a.tw_a || !a.tw_b || !a.tw_r) return hipErrorInvalidValue;
     hipError_t e;
-    if (a.n1 == 512)
-        e = fmt == RO_FMT_F32 ? launch_cols<RO_FMT_F32, 16>(a, s) : fmt == RO_FMT_I16 ? launch_cols<RO_FMT_I16, 16>(a, s) : hipErrorInvalidValue;
-    else
-        e = fmt == RO_FMT_F32 ? launch_cols<RO_FMT_F32, 8>(a, s) : fmt == RO_FMT_I16 ? launch_cols<RO_FMT_I16, 8>(a, s) : hipErrorInvalidValue;
+    if (fmt != RO_FMT_F32 && fmt != RO_FMT_I16) return hipErrorInvalidValue;
+    const bool f = fmt == RO_FMT_F32;
+    if (a.n1 == 256) e = f ? launch_cols<RO_FMT_F32, 8>(a, s) : launch_cols<RO_FMT_I16, 8>(a, s);
+    else if (a.n1 == 512) e = f ? launch_cols<RO_FMT_F32, 16>(a, s) : launch_cols<RO_FMT_I16, 16>(a, s);
+    else if constexpr (WAVES == 16) e = f ? launch_cols<RO_FMT_F32, 32>(a, s) : launch_cols<RO_FMT_I16, 32>(a, s);
+    else return hipErrorInvalidValue;
     if (e != hipSuccess) return e;
     int cus = 0;
-    if ((e = prepare(&four_rows_kernel, k32::LDS_BYTES, cus)) != hipSuccess) return e;
-    hipLaunchKernelGGL(four_rows_kernel, dim3(grid_for(cus, a.rows * (a.n1 / 32))), dim3(T), k32::LDS_BYTES, s, a);
+    if ((e = prepare(&four_rows_kernel, ROWS_LDS, cus)) != hipSuccess) return e;
+    hipLaunchKernelGGL(four_rows_kernel, dim3(grid_for(cus, a.rows * (a.n1 / BROWS))), dim3(T), ROWS_LDS, s, a);
     return hipGetLastError();
 }
 

@@ -1837,7 +1837,7 @@ hipError_t launch_scan(const ScanArgs &a, hipStream_t s)
     const int widest = a.noise_width > a.detect_width ? a.noise_width : a.detect_width;
     if (widest <= 64 * SCAN_E) hipLaunchKernelGGL(scan_kernel<SCAN_E>, dim3(grid), dim3(64 * SCAN_WAVES), 0, s, a);
     else if (widest <= 64 * 64) hipLaunchKernelGGL(scan_kernel<64>, dim3(grid), dim3(64 * SCAN_WAVES), 0, s, a);
-    else hipLaunchKernelGGL(scan_kernel<128>, dim3(grid), dim3(64 * SCAN_WAVES), 0, s, a);
+    else hipLaunchKernelGGL(scan_kernel<128>, dim3(grid), dim3(64 * SCAN_WAVES), 0, s, a);   // wider still: batched re-reads
     return hipGetLastError();
 }
 

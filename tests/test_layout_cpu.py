@@ -31,11 +31,11 @@ def test_stft32k_layout_reproduces_the_fft_without_bank_conflicts():
 
 def test_fourstep_maps_reproduce_the_fft():
     """tools/r4/emu_four.py: the column kernel's sample / window / exchange / scratch addresses, the scratch order, the
-    row kernel's loads, twiddle tables and output columns of csrc/ro_fourstep.hip at 262144 and 524288 bins"""
+    row kernel's loads, twiddle tables and output columns of csrc/ro_fourstep.hip at 262144, 524288 and 1048576 bins"""
     out = run("emu_four.py", where="r4")
-    for bins in (262144, 524288):
+    for bins in (262144, 524288, 1048576):
         assert "bins = %d: column kernel: samples, window table, exchange and scratch addresses" % bins in out
-        assert "bins = %d: row kernel: scratch loads, twiddle tables, fft-shifted columns of the read-back" % bins in out
+        assert "bins = %d: row kernel: scratch loads, twiddle tables, fft-shifted columns of the read-back; LDS reads conflict-free" % bins in out
 
 
 def test_the_general_form_agrees_at_32_points_per_wave_column():
