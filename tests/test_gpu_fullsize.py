@@ -39,7 +39,7 @@ def run(ro, torch, st, iq, first, rows, out):
                                                  (2048, 0, 65536, 7), (1024, 512, 131072, 0xC1), (512, 384, 65536, 8),
                                                  (256, 128, 262144, 9),
                                                  (65536, 49152, 4096, 10),      # Bolidozor.json:45-46: one-kernel form
-                                                 (262144, 196608, 2600, 11),    # scratch form, three chunks
+                                                 (262144, 196608, 2600, 11),    # four-step form, six scratch blocks
                                                  (32728, 24546, 2500, 12)])     # chirp-z, three chunks
 def test_full_size_properties(ro, oracle, torch_cuda, bins, overlap, R, seed):
     torch = torch_cuda

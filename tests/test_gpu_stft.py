@@ -50,7 +50,8 @@ def test_noise_rows_match_oracle(ro, oracle, torch_cuda, bins):
                                                  (524288, 262144, 3), (1048576, 786432, 2)])
 def test_large_transforms(ro, oracle, torch_cuda, bins, overlap, nrows):
     """Bolidozor.json:45-46 (65536 / 49152) and Ionozor.json:27-28 (524288 / 262144): decimation in frequency on the
-    N = 32768 kernel, in one kernel up to 131072 and through scratch above."""
+    N = 32768 kernel in one kernel up to 131072, the four-step pair of kernels (csrc/ro_fourstep.hip: N1 = 256, 512,
+    1024 columns of 1024) through scratch above."""
     rng = np.random.default_rng(bins % 1000)
     hop = bins - overlap
     iq = add_tone(noise_iq(rng, bins + (nrows - 1) * hop + 3), 10600.0, 20.0, fs=96000)
@@ -64,7 +65,7 @@ def test_large_transforms(ro, oracle, torch_cuda, bins, overlap, nrows):
 
 
 def test_large_transform_many_rows_cross_scratch_chunks(ro, oracle, torch_cuda):
-    """more rows than one scratch block holds (1024 rows at N=262144, the three-step form), and as many on the
+    """more rows than one scratch block holds (512 rows at N=262144, the four-step form), and as many on the
     one-kernel form (N=65536), whose launch is not chunked."""
     torch = torch_cuda
     for bins in (262144, 65536):
@@ -73,17 +74,18 @@ def test_large_transform_many_rows_cross_scratch_chunks(ro, oracle, torch_cuda):
         iq = noise_iq(rng, bins + (nrows - 1) * 256)
         got = gpu_rows(ro, torch, iq, bins, overlap)
         assert np.isfinite(got).all()
-        for r in (0, 1023, 1024, 1099):
+        for r in (0, 511, 512, 1023, 1024, 1099):
             want = oracle.stft(iq[r * 256:r * 256 + bins], bins, overlap)[0]
             assert rel_to_row_max(got[r][None], want[None]) <= TOL
         del got
 
 
-@pytest.mark.parametrize("bins", [65536, 262144])
+@pytest.mark.parametrize("bins", [65536, 262144, 524288, 1048576])
 def test_large_transform_int16_gain_and_custom_window(ro, oracle, torch_cuda, bins):
-    """both forms of the large transforms (one kernel at 65536, fold + transform + interleave at 262144) with WAV
-    frames, I/Q gain (src/FFTBackend.cpp:78-79) and a caller's window table"""
-    overlap, nrows = bins // 2, 4
+    """both forms of the large transforms (one kernel at 65536; the four-step pair with 128, 64 and 32 columns per
+    workgroup at 262144, 524288, 1048576) with WAV frames, I/Q gain (src/FFTBackend.cpp:78-79) and a caller's window
+    table"""
+    overlap, nrows = bins // 2, (4 if bins <= 262144 else 3)
     rng = np.random.default_rng(bins % 977)
     n = bins + (nrows - 1) * (bins - overlap) + 11
     i16 = rng.integers(-20000, 20000, size=(n, 2), dtype=np.int16)

@@ -35,7 +35,7 @@ def stream(ro, iq_chunks, bins, overlap, **kw):
 @pytest.mark.parametrize("bins,overlap,chunk,batch", [(1024, 512, 1024, 3), (4096, 2048, 4096, 0),
                                                        (4096, 3072, 333, 7), (32768, 24576, 4096, 5),
                                                        (65536, 49152, 50000, 4),     # Bolidozor.json:45-46, one kernel
-                                                       (262144, 196608, 100000, 5),  # the scratch form
+                                                       (262144, 196608, 100000, 5),  # the four-step form
                                                        (32728, 24546, 9999, 3)])     # src/BolidRecorder.h:35, chirp-z
 def test_push_fetch_float32(ro, oracle, bins, overlap, chunk, batch):
     rng = np.random.default_rng(chunk)
