@@ -64,6 +64,16 @@ __device__ __forceinline__ void buf_store_f4(float x0, float x1, float x2, float
     asm volatile("s_nop 1" ::"v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w));
 #endif
 }
+// the same store (and the same two wait states behind it) for four raw dwords and a cache policy of the caller's choice
+template <int AUX> __device__ __forceinline__ void buf_store_u4(u32x4 t, __amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, AUX);
+    // (the four dwords as ONE operand: with four scalar operands hipcc kept the registers the dwords came from alive,
+    // copied them into a fresh tuple for the store, and moved this statement in front of it)
+#if RO_STORE_NOP
+    asm volatile("s_nop 1" ::"v"(t));
+#endif
+}
 
 // value of lane (quad_perm) of the same register, DPP: no LDS, full-rate VALU
 template <int CTRL> __device__ __forceinline__ float dpp_quad(float x)
@@ -498,6 +508,12 @@ template <> struct Sample<RO_FMT_F32> {
     {
         return buf_load_f2(r, voff, soff);
     }
+    // ... with the non-temporal hint: a sample nobody reads again
+    static __device__ __forceinline__ v2f load_nt(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+    {
+        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 2);
+        return (v2f){__uint_as_float(t.x), __uint_as_float(t.y)};
+    }
     // two adjacent samples with one 16-byte load
     static __device__ __forceinline__ void load_pair(__amdgpu_buffer_rsrc_t r, int voff, int soff, v2f &s0, v2f &s1)
     {
@@ -511,6 +527,11 @@ template <> struct Sample<RO_FMT_I16> {
     static __device__ __forceinline__ v2f load(__amdgpu_buffer_rsrc_t r, int voff, int soff)
     {
         const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+        return (v2f){(float)(short)(u & 0xffffu), (float)(short)(u >> 16)};
+    }
+    static __device__ __forceinline__ v2f load_nt(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+    {
+        const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 2);
         return (v2f){(float)(short)(u & 0xffffu), (float)(short)(u >> 16)};
     }
     static __device__ __forceinline__ void load_pair(__amdgpu_buffer_rsrc_t r, int voff, int soff, v2f &s0, v2f &s1)

@@ -28,8 +28,8 @@
 //
 // Scratch order ("planar pairs"): row k1 = 16 x 32 quads, quad (i, a) = { re Z[a + 32 (2i)], re Z[a + 32 (2i + 1)],
 //   im ..., im ... } -- what thread (k1, a) of pass 1 holds in R[i], I[i]: one 16-byte load per register quad, no
-//   shuffling.  The column kernel gets there with one lane swap per point: its waves hold the two mates of a pair in
-//   lanes l, l + 32 (C >= 64: v_permlane32_swap) or l, l + 16 (C = 32: v_permlane16_swap).
+//   shuffling.  The column kernel gets there with one lane swap per point and 16-byte stores: its waves hold the two
+//   mates of a pair in lanes l, l + 32 (C >= 64: v_permlane32_swap) or l, l + 16 (C = 32: v_permlane16_swap).
 //
 // HBM / Infinity Cache traffic per stream row: 8 hop (samples) + 8 M out + 8 M in (scratch) + 4 M (the row) against the
 // 28 M of the fold / transform / interleave form it replaces.
@@ -55,10 +55,12 @@ namespace four {
 
 using k32::lds_vpair;
 
-// cache policy of the scratch traffic (gfx950 aux bits: 1 = sc0, 2 = nt, 16 = sc1): the column kernel's stores plain,
-// the row kernel's loads nt -- each byte of Z is read once (172 -> 142 us per 128 rows; nt on the stores: no change with
-// scratch blocks past the Infinity Cache, 5 % slower inside it; profiles/r04_fourstep.txt)
-constexpr int Z_ST_AUX = 0, Z_LD_AUX = 2;
+// Cache policy (gfx950 aux bits: 1 = sc0, 2 = nt, 16 = sc1).  Everything that is touched once carries the nt hint --
+// the stores and the loads of Z, the row stores, and the legs of a stream row that no later row reads again (the first
+// 32 hop / M of them) -- so that an XCD's L2 keeps what IS read again: the legs the next stream row shares and the
+// window table.  Column kernel at Ionozor's shape: 5.2 -> 3.5 MiB fetched per stream row (FETCH_SIZE), 402 -> 357 us per
+// 256 rows; nt loads of Z: 172 -> 142 us per 128 rows in the row kernel (profiles/r04_fourstep.txt).
+constexpr int Z_ST_AUX = 2, Z_LD_AUX = 2;
 
 constexpr int N2 = 1024;
 constexpr int WAVES = RO_FOUR_WAVES, T = 64 * WAVES;   // one workgroup of 1024 per CU (8: two of 512, see the header)
@@ -129,7 +131,7 @@ template <int C> __host__ __device__ constexpr int fourstep_column(int cg, int l
     return C >= 64 ? C * cg + lam : (16 * (cg & 1) + (lam & 15)) + 32 * (2 * (cg >> 1) + (lam >> 4));
 }
 
-template <int FMT, int R2> __global__ __launch_bounds__(T, 4) void four_cols_kernel(FourArgs a)   // 4 waves per SIMD: 128 VGPRs
+template <int FMT, int R2, int NT> __global__ __launch_bounds__(T, 4) void four_cols_kernel(FourArgs a)   // 4 waves per SIMD: 128 VGPRs
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using S = Sample<FMT>;
@@ -147,6 +149,11 @@ template <int FMT, int R2> __global__ __launch_bounds__(T, 4) void four_cols_ker
 
     v2f v[32];
     v4f w4[8];
+    // legs whose samples no later stream row contains: leg l is samples [1024 R2 l, 1024 R2 (l + 1)) of the row, the next
+    // row starts at hop
+    // (a template parameter: the launcher rounds 32 hop / M down to 32, 16, 8 or 0.  As a run-time value, one uniform
+    // branch per leg, the kernel took 385 us per 256 rows at Ionozor's shape instead of 357)
+    constexpr int nt_legs = NT;
     // a block's samples (legs [L0, L1)) and its window coefficients in this kernel's order (fourstep_tables)
     struct Src {
         __amdgpu_buffer_rsrc_t rs, rw;
@@ -164,7 +171,10 @@ template <int FMT, int R2> __global__ __launch_bounds__(T, 4) void four_cols_ker
     auto load_legs = [&](const Src &src, int vo, auto lo_c, auto hi_c) {
         constexpr int L0 = decltype(lo_c)::value, L1 = decltype(hi_c)::value;
 #pragma unroll
-        for (int l = L0; l < L1; ++l) v[l] = S::load(src.rs, vo, l * (N2 * R2) * S::BYTES);
+        for (int l = L0; l < L1; ++l) {
+            if (l < nt_legs) v[l] = S::load_nt(src.rs, vo, l * (N2 * R2) * S::BYTES);
+            else v[l] = S::load(src.rs, vo, l * (N2 * R2) * S::BYTES);
+        }
     };
     auto load_window = [&](const Src &src, int to) {
 #pragma unroll
@@ -220,20 +230,22 @@ template <int FMT, int R2> __global__ __launch_bounds__(T, 4) void four_cols_ker
 #pragma unroll
             for (int m = 0; m < R2; ++m) u[R2 * h + m].y = lds[(SETS * grp + h) * T + m * C + lam];
         // The next block's samples and coefficients: v and w4 are free from here on, but 128 VGPRs do not hold them
-        // next to u -- the first half of the legs now, the second when half of u has left, the window at the end.
+        // next to u -- the first half of the legs now (N1 = 1024, one set of 32 in u: when a quarter of it has left),
+        // the second when half of u has left, the window at the end.
         const Src nsrc = source(has_next ? next : blk, has_next);
-        load_legs(nsrc, nsrc.vo, c0{}, c16{});
+        if constexpr (SETS > 1) load_legs(nsrc, nsrc.vo, c0{}, c16{});
         // ---- W_N1^(m k_l), radix-R2 over m, out
         const int64_t s = blk / GROUPS;
         const int cg = (int)(blk % GROUPS);
         // row k1 of stream row s: 2048 floats at (s N1 + k1) 2048; quad (i, a) of this lane's column at (32 i + a) 4.
-        // Behind the lane swap the lanes of the mate p = 0 hold the pair of imaginary parts (floats 2, 3 of the quad),
-        // those of p = 1 the real parts.
         const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.z + (size_t)s * N1 * 2048, (unsigned)N1 * 2048u * 4u);
         const int n2 = fourstep_column<C>(cg, lam);
         const int mate_p = (n2 >> 5) & 1;
-        // (C = 32: the half-waves' k_l sets differ -- their part of the row number is in the lane's offset)
-        const int zo = (((n2 >> 6) * 32 + (n2 & 31)) * 4 + (mate_p ? 0 : 2)) * 4 + (C == 32 ? SETS * grp * 8192 : 0);
+        // Two rows k_m = 2 kp (A) and 2 kp + 1 (B) leave together.  The lane swap of one component with vdst = B, src = A
+        // gives the lanes of p = 0 (B, B') and the lanes of p = 1 (A, A'): a lane stores a whole quad, 16 bytes, of row
+        // B resp. A (32 rows of 8192 bytes further down).  (C = 32: the half-waves' k_l sets differ -- their part of the
+        // row number is in the lane's offset too.)
+        const int zo = ((n2 >> 6) * 32 + (n2 & 31)) * 16 + (mate_p ? 0 : 32 * 8192) + (C == 32 ? SETS * grp * 8192 : 0);
         const int zs = C >= 64 ? SETS * grp * 8192 : 0;
         float last = 0.0f;
 #pragma unroll
@@ -253,19 +265,21 @@ template <int FMT, int R2> __global__ __launch_bounds__(T, 4) void four_cols_ker
             }
             dit<R2>(&u[R2 * h]);                                 // result k_m at position bitrev_R2(k_m)
 #pragma unroll
-            for (int km = 0; km < R2; ++km) {
-                const v2f z = u[R2 * h + bitrev<R2>(km)];
-                // (v0, v1) = (im, re) -> the lanes of p = 0: (im, im'), the lanes of p = 1: (re, re')
-                u32x2 sw;
+            for (int kp = 0; kp < R2 / 2; ++kp) {
+                const v2f zA = u[R2 * h + bitrev<R2>(2 * kp)], zB = u[R2 * h + bitrev<R2>(2 * kp + 1)];
+                u32x4 q;
                 if constexpr (C >= 64) {
-                    const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(z.y), __float_as_uint(z.x), false, false);
-                    sw = (u32x2){t[0], t[1]};
+                    const auto tr = __builtin_amdgcn_permlane32_swap(__float_as_uint(zB.x), __float_as_uint(zA.x), false, false);
+                    const auto ti = __builtin_amdgcn_permlane32_swap(__float_as_uint(zB.y), __float_as_uint(zA.y), false, false);
+                    q = (u32x4){tr[0], tr[1], ti[0], ti[1]};
                 } else {
-                    const auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(z.y), __float_as_uint(z.x), false, false);
-                    sw = (u32x2){t[0], t[1]};
+                    const auto tr = __builtin_amdgcn_permlane16_swap(__float_as_uint(zB.x), __float_as_uint(zA.x), false, false);
+                    const auto ti = __builtin_amdgcn_permlane16_swap(__float_as_uint(zB.y), __float_as_uint(zA.y), false, false);
+                    q = (u32x4){tr[0], tr[1], ti[0], ti[1]};
                 }
-                __builtin_amdgcn_raw_buffer_store_b64(sw, rz, zo, zs + (h + 32 * km) * 8192, Z_ST_AUX);
-                last = __uint_as_float(sw.y);
+                buf_store_u4<Z_ST_AUX>(q, rz, zo, zs + (h + 32 * 2 * kp) * 8192);
+                last = __uint_as_float(q.w);
+                if (SETS == 1 && kp == R2 / 4 - 1) load_legs(nsrc, after(nsrc.vo, last), c0{}, c16{});
             }
             if (SETS > 1 && h == SETS / 2 - 1) load_legs(nsrc, after(nsrc.vo, last), c16{}, c32{});
         }
@@ -489,13 +503,25 @@ static unsigned grid_for(int cus, int64_t nblk)
     return (unsigned)(slots * 8);
 }
 
-template <int FMT, int R2> static hipError_t launch_cols(const FourArgs &a, hipStream_t s)
+template <int FMT, int R2, int NT> static hipError_t launch_cols_nt(const FourArgs &a, hipStream_t s)
 {
     int cus = 0;
-    hipError_t e = prepare(&four_cols_kernel<FMT, R2>, COLS_LDS, cus);
+    hipError_t e = prepare(&four_cols_kernel<FMT, R2, NT>, COLS_LDS, cus);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((four_cols_kernel<FMT, R2>), dim3(grid_for(cus, a.rows * (N2 / (T / R2)))), dim3(T), COLS_LDS, s, a);
+    hipLaunchKernelGGL((four_cols_kernel<FMT, R2, NT>), dim3(grid_for(cus, a.rows * (N2 / (T / R2)))), dim3(T), COLS_LDS, s, a);
     return hipGetLastError();
+}
+template <int FMT, int R2> static hipError_t launch_cols(const FourArgs &a, hipStream_t s)
+{
+    // legs of a stream row that no later row contains (see the kernel): float32 samples only -- the int16 kernel is
+    // built without the hint
+    const int nt = FMT == RO_FMT_F32 ? a.hop / (N2 * R2) : 0;
+    if constexpr (FMT == RO_FMT_F32) {
+        if (nt >= 32) return launch_cols_nt<FMT, R2, 32>(a, s);
+        if (nt >= 16) return launch_cols_nt<FMT, R2, 16>(a, s);
+        if (nt >= 8) return launch_cols_nt<FMT, R2, 8>(a, s);
+    }
+    return launch_cols_nt<FMT, R2, 0>(a, s);
 }
 
 }  // namespace four

@@ -68,8 +68,8 @@ def test_lds_traffic_between_consecutive_barriers(isa):
     # one-kernel large transform on the N = 32768 plan x 2 formats
     assert len(stft) == 32
     assert len([k for k in ks if "stft32k_kernel" in k]) == 2
-    # the four-step large transforms: the column kernel for N1 = 256, 512, 1024 x 2 sample formats, one row kernel
-    assert len([k for k in ks if "four_cols_kernel" in k]) == 6 and len([k for k in ks if "four_rows_kernel" in k]) == 1
+    # the four-step large transforms: the column kernel for N1 = 256, 512, 1024 x (float32 with 0, 8, 16, 32 legs nt + int16), one row kernel
+    assert len([k for k in ks if "four_cols_kernel" in k]) == 15 and len([k for k in ks if "four_rows_kernel" in k]) == 1
     for name, body in ks.items():
         seen, lds = False, False
         for i, line in enumerate(body):

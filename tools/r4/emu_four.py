@@ -103,19 +103,19 @@ def check(bins, seed):
                 u = np.array([plane[kl * T + m * C + lam] for m in range(R2)]) * tw_a[kl]
                 z = np.fft.fft(u)                                                        # [k_m]
                 for km in range(R2):
-                    k1 = kl + 32 * km
-                    assert abs(z[km] - Ztrue[k1, n2]) < 1e-9 * zmax
-                    # what the lane stores after the lane swap of (im, re): two floats at zo of row k1
-                    zo = ((n2 >> 6) * 32 + (n2 & 31)) * 4 + (2 if p0 else 0)
-                    mate = n2 + 32 if p0 else n2 - 32
-                    if p0:
-                        pair = (Ztrue[k1, n2].imag, Ztrue[k1, mate].imag)
-                        where = (zfloat(k1, n2, 1), zfloat(k1, mate, 1))
-                    else:
-                        pair = (Ztrue[k1, mate].real, Ztrue[k1, n2].real)
-                        where = (zfloat(k1, mate, 0), zfloat(k1, n2, 0))
-                    assert where == (k1 * 2048 + zo, k1 * 2048 + zo + 1), (tid, h, km, where, zo)
-                    for wq, val in zip(where, pair):
+                    assert abs(z[km] - Ztrue[kl + 32 * km, n2]) < 1e-9 * zmax
+                # Two rows k_m = 2 kp (A), 2 kp + 1 (B) leave together: behind the lane swaps (vdst = B, src = A, one per
+                # component) a lane of p = 0 holds (B, B') and stores the whole quad of row B, a lane of p = 1 that of
+                # row A: 16 bytes at zo + soffset
+                for kp in range(R2 // 2):
+                    k1 = kl + 32 * (2 * kp + (1 if p0 else 0))
+                    lo, hi = (n2, n2 + 32) if p0 else (n2 - 32, n2)                      # the columns of p = 0, p = 1
+                    quad = (Ztrue[k1, lo].real, Ztrue[k1, hi].real, Ztrue[k1, lo].imag, Ztrue[k1, hi].imag)
+                    where = (zfloat(k1, lo, 0), zfloat(k1, hi, 0), zfloat(k1, lo, 1), zfloat(k1, hi, 1))
+                    zo = ((n2 >> 6) * 32 + (n2 & 31)) * 4 + (32 * 2048 if p0 else 0)      # floats; + the half-wave's rows if C = 32
+                    so = (kl + 64 * kp) * 2048
+                    assert where == tuple(zo + so + j for j in range(4)), (tid, h, kp, where, zo, so)
+                    for wq, val in zip(where, quad):
                         assert wq not in scratch
                         scratch[wq] = val
         assert len(scratch) == 2 * 32 * T
