@@ -494,10 +494,10 @@ template <typename K> static hipError_t prepare(K kernel, int lds_bytes, int &cu
     return hipSuccess;
 }
 
-static unsigned grid_for(int cus, int64_t nblk)
+static unsigned grid_for(int cus, int spare_cus, int64_t nblk)
 {
     const int64_t per_xcd = (nblk + 7) / 8;
-    int64_t slots = (16 / WAVES) * (cus / 8);                    // workgroups per XCD
+    int64_t slots = (16 / WAVES) * (cus / 8 - (spare_cus > 0 ? spare_cus : 0));     // workgroups per XCD
     if (slots < 1) slots = 1;
     if (slots > per_xcd) slots = per_xcd;
     return (unsigned)(slots * 8);
@@ -508,7 +508,7 @@ template <int FMT, int R2, int NT> static hipError_t launch_cols_nt(const FourAr
     int cus = 0;
     hipError_t e = prepare(&four_cols_kernel<FMT, R2, NT>, COLS_LDS, cus);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((four_cols_kernel<FMT, R2, NT>), dim3(grid_for(cus, a.rows * (N2 / (T / R2)))), dim3(T), COLS_LDS, s, a);
+    hipLaunchKernelGGL((four_cols_kernel<FMT, R2, NT>), dim3(grid_for(cus, a.spare_cus, a.rows * (N2 / (T / R2)))), dim3(T), COLS_LDS, s, a);
     return hipGetLastError();
 }
 template <int FMT, int R2> static hipError_t launch_cols(const FourArgs &a, hipStream_t s)
@@ -582,7 +582,7 @@ hipError_t launch_fourstep(int fmt, const FourArgs &a, hipStream_t s)
     if (e != hipSuccess) return e;
     int cus = 0;
     if ((e = prepare(&four_rows_kernel, ROWS_LDS, cus)) != hipSuccess) return e;
-    hipLaunchKernelGGL(four_rows_kernel, dim3(grid_for(cus, a.rows * (a.n1 / BROWS))), dim3(T), ROWS_LDS, s, a);
+    hipLaunchKernelGGL(four_rows_kernel, dim3(grid_for(cus, a.spare_cus, a.rows * (a.n1 / BROWS))), dim3(T), ROWS_LDS, s, a);
     return hipGetLastError();
 }
 

@@ -115,6 +115,7 @@ struct FourArgs {
     float        *z;           // scratch: rows x n1 x 2048 floats
     float        *rows_out;    // rows x row_stride, fft-shifted magnitudes
     int64_t       row_stride;
+    int           spare_cus;   // CUs per XCD both persistent grids leave to other kernels (ro_stft_config_t)
 };
 bool fourstep_supported(int bins);
 hipError_t launch_fourstep(int format, const FourArgs &a, hipStream_t s);

@@ -603,6 +603,7 @@ int launch_transform(ro_stft *h, const void *d_iq, int format, int64_t first_row
             f.z = h->d_four_z;
             f.rows_out = d_rows + done * row_stride;
             f.row_stride = row_stride;
+            f.spare_cus = h->cfg.spare_cus_per_xcd;
             HIP_TRY(ro::launch_fourstep(format, f, s));
         }
         return RO_OK;

@@ -96,6 +96,17 @@ def test_large_transform_int16_gain_and_custom_window(ro, oracle, torch_cuda, bi
     assert rel_to_row_max(got, want) <= TOL
 
 
+@pytest.mark.parametrize("bins,overlap,nrows", [(32768, 24576, 300), (262144, 131072, 40), (524288, 262144, 19)])
+def test_cus_left_to_other_kernels_do_not_change_a_bit(ro, torch_cuda, bins, overlap, nrows):
+    """ro_stft_config_t::spare_cus_per_xcd shrinks the persistent grids (N = 32768 kernel; both kernels of the four-step
+    form): the rows are the same bits whatever the grid"""
+    rng = np.random.default_rng(bins % 991)
+    iq = noise_iq(rng, bins + (nrows - 1) * (bins - overlap))
+    full = gpu_rows(ro, torch_cuda, iq, bins, overlap)
+    for spare in (5, 16):
+        assert np.array_equal(gpu_rows(ro, torch_cuda, iq, bins, overlap, spare_cus_per_xcd=spare), full), spare
+
+
 @pytest.mark.parametrize("bins,overlap,nrows", [(258, 0, 9), (1000, 600, 7), (12000, 9000, 5), (32728, 24546, 5),
                                                  (100000, 50000, 3), (524286, 262143, 2)])
 def test_lengths_that_are_not_a_power_of_two(ro, oracle, torch_cuda, bins, overlap, nrows):
