@@ -137,16 +137,8 @@ struct FoldArgs {
     float         gain;
 };
 hipError_t launch_fold(int format, const FoldArgs &a, hipStream_t s);
-// Last step: out[row][q + dec j] = in[(row dec + q) m + j] -- the dec sub-rows of a stream row
-// (each already fft-shifted in itself, which is the large row's own shift) interleaved into the row.
-struct InterleaveArgs {
-    const float *in;           // [rows][dec][m]
-    float       *out;          // [rows][row_stride]
-    int64_t      rows, row_stride;
-    int          m, dec;
-};
-hipError_t launch_interleave(const InterleaveArgs &a, hipStream_t s);
-// the same for rows of float2 (complex spectra of a large transform: bin q + dec j from sub-row q, element j)
+// Last step: out[row][q + dec j] = in[(row dec + q) m + j] -- the dec sub-rows of a stream row interleaved into the
+// row, float2 elements (complex spectra of a large transform: bin q + dec j from sub-row q, element j)
 struct Interleave2Args {
     const float2 *in;          // [rows][dec][m]
     float2       *out;         // [rows][out_stride >= dec m]

@@ -854,9 +854,10 @@ __global__ __launch_bounds__(PL::T, (plan_min_waves<PL, FMT, MODE>())) void stft
 //   X[q + dec k'] = sum_m W_N^(m k') { W_bins^(m q) sum_r W_dec^(r q) w[m + N r] x[m + N r] }
 // dec <= 4: ONE kernel, stft_kernel MODE 3 -- the braces are summed in its window stage (every workgroup reads the
 //   whole row: dec x the loads, from L2), bins leave `dec` floats apart.  HBM sees the algorithmic bytes only.
-// dec >= 8: the strided 4-byte stores of that form cost one 64-byte L2 write request per lane and residue, so three
-//   steps through scratch, every access a run of consecutive elements: fold_kernel (the braces, 8 B per bin),
-//   the N = 32768 kernel on its rows (4 B per bin), interleave_kernel.  30 B of HBM traffic per bin, at copy speed.
+// dec >= 8: the strided 4-byte stores of that form cost one 64-byte L2 write request per lane and residue: the
+//   magnitude rows come from the four-step pair of kernels in ro_fourstep.hip.
+// Complex spectra of every large size: three steps through scratch, every access a run of consecutive elements:
+//   fold_kernel (the braces, 8 B per bin), the N = 32768 kernel on its rows in spectra mode, interleave2_kernel.
 // ---------------------------------------------------------------------------
 // ---------------------------------------------------------------------------
 // fold_kernel: first step of the scratch form of a large transform (see FoldArgs).  One thread owns two neighbouring
@@ -1547,41 +1548,8 @@ bool big_supported(int bins)
     return bins > 32768 && bins <= (1 << 20) && (bins & (bins - 1)) == 0;
 }
 
-// interleave_kernel: [dec][m] -> [m][dec] per stream row through an LDS tile of 256 columns (reads: dec runs of 1 KiB,
-// writes: one run of dec KiB).  Bound: HBM, 4 B per bin each way.
-template <int R> __global__ __launch_bounds__(256) void interleave_kernel(InterleaveArgs a)
-{
-    __shared__ float tile[R][257];
-    const int j0 = blockIdx.x * 256, t = threadIdx.x;
-    const int64_t row = blockIdx.y;
-    const float *in = a.in + row * (int64_t)R * a.m + j0;
-#pragma unroll
-    for (int q = 0; q < R; ++q) tile[q][t] = __builtin_nontemporal_load(in + (int64_t)q * a.m + t);
-    __syncthreads();
-    float *out = a.out + row * a.row_stride + (int64_t)j0 * R;
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        const int e = t + 256 * i;                                 // element of the tile's output run: column j0 R + e
-        __builtin_nontemporal_store(tile[e % R][e / R], out + e);
-    }
-}
-
-hipError_t launch_interleave(const InterleaveArgs &a, hipStream_t s)
-{
-    if (a.rows <= 0) return hipSuccess;
-    if (a.m % 256 != 0 || a.rows > 65535) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)(a.m / 256), (unsigned)a.rows);
-    switch (a.dec) {
-    case 2:  hipLaunchKernelGGL(interleave_kernel<2>, grid, dim3(256), 0, s, a); break;
-    case 4:  hipLaunchKernelGGL(interleave_kernel<4>, grid, dim3(256), 0, s, a); break;
-    case 8:  hipLaunchKernelGGL(interleave_kernel<8>, grid, dim3(256), 0, s, a); break;
-    case 16: hipLaunchKernelGGL(interleave_kernel<16>, grid, dim3(256), 0, s, a); break;
-    case 32: hipLaunchKernelGGL(interleave_kernel<32>, grid, dim3(256), 0, s, a); break;
-    default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
+// interleave2_kernel: [dec][m] -> [m][dec] per stream row through an LDS tile (reads: dec runs of 1 KiB, writes: one run of
+// dec KiB), complex elements.  Bound: HBM, 8 B per bin each way.
 template <int R> __global__ __launch_bounds__(256) void interleave2_kernel(Interleave2Args a)
 {
     __shared__ float2 tile[R][129];

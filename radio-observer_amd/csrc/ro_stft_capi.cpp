@@ -238,9 +238,7 @@ struct ro_stft {
     float  *d_window_dif = nullptr;    // ... [dec][sub_bins]: window block r in the sub-plan's kernel order
     float2 *d_dif_tw = nullptr;        // ... exp(-2 pi i j / dec)
     float2 *d_dif_shift = nullptr;     // ... [dec][16]: the bin shift q / dec as the stages' twiddles (StftArgs::dif_shift)
-    bool    fold = false;              // else fold_kernel to scratch, the N = 32768 kernel on its rows, interleave_kernel
     float2 *d_spec = nullptr;          // ... the folded sub-rows, [spec_rows][dec][sub_bins] float2
-    float  *d_mag = nullptr;           // ... their magnitudes, [spec_rows][dec][sub_bins]
     float  *d_ones = nullptr;          // ... a window of ones (the fold has applied the real one)
     int64_t spec_rows = 0;
     float2 *d_spec2 = nullptr;         // complex spectra of a large size: the sub-rows' spectra before they are interleaved
@@ -415,15 +413,14 @@ int ensure_ln_part(ro_stft *h, int64_t rows)
 }
 
 // scratch of the large sizes' scratch form (and of their complex spectra): rows per chunk and the blocks
-int ensure_big_scratch(ro_stft *h, bool mag, bool spec2)
+int ensure_big_scratch(ro_stft *h)
 {
     if (!h->spec_rows) {
         h->spec_rows = std::max<int64_t>(1, ((int64_t)RO_SPEC_SCRATCH_MB << 20) / ((int64_t)h->bins * 8));
         if (h->spec_rows > 65535) h->spec_rows = 65535;
     }
     if (!h->d_spec) HIP_TRY(hipMalloc(&h->d_spec, (size_t)h->spec_rows * h->bins * sizeof(float2)));
-    if (mag && !h->d_mag) HIP_TRY(hipMalloc(&h->d_mag, (size_t)h->spec_rows * h->bins * sizeof(float)));
-    if (spec2 && !h->d_spec2) HIP_TRY(hipMalloc(&h->d_spec2, (size_t)h->spec_rows * h->bins * sizeof(float2)));
+    if (!h->d_spec2) HIP_TRY(hipMalloc(&h->d_spec2, (size_t)h->spec_rows * h->bins * sizeof(float2)));
     return RO_OK;
 }
 
@@ -432,7 +429,7 @@ int ensure_big_scratch(ro_stft *h, bool mag, bool spec2)
 int launch_spectra_big(ro_stft *h, const void *d_iq, int format, int64_t first_row, int64_t rows, float2 *d_out,
                        int64_t out_stride, hipStream_t s)
 {
-    int rc = ensure_big_scratch(h, false, true);
+    int rc = ensure_big_scratch(h);
     if (rc != RO_OK) return rc;
     for (int64_t done = 0; done < rows; done += h->spec_rows) {
         const int64_t n = std::min(h->spec_rows, rows - done);
@@ -605,45 +602,6 @@ int launch_transform(ro_stft *h, const void *d_iq, int format, int64_t first_row
             f.row_stride = row_stride;
             f.spare_cus = h->cfg.spare_cus_per_xcd;
             HIP_TRY(ro::launch_fourstep(format, f, s));
-        }
-        return RO_OK;
-    }
-    if (h->dec > 1 && h->fold) {
-        // three steps through scratch, in chunks that fit it: fold_kernel (8 B per bin), the N = 32768 kernel on its
-        // rows -- no overlap, a window of ones -- (4 B per bin), interleave_kernel into the caller's rows
-        {
-            int rc = ensure_big_scratch(h, true, false);
-            if (rc != RO_OK) return rc;
-        }
-        for (int64_t done = 0; done < rows; done += h->spec_rows) {
-            const int64_t n = std::min(h->spec_rows, rows - done);
-            ro::FoldArgs f{};
-            f.iq = d_iq;
-            f.window = h->d_window;
-            f.rot = h->d_tw_combine;
-            f.out = h->d_spec;
-            f.first_row = first_row + done;
-            f.rows = n;
-            f.hop = h->hop;
-            f.m = h->sub_bins;
-            f.dec = h->dec;
-            f.gain = (float)h->cfg.iq_gain;
-            HIP_TRY(ro::launch_fold(format, f, s));
-            ro::StftArgs a = make_stft_args(h, h->d_spec, 0, n * h->dec, h->d_mag, h->sub_bins);
-            a.window = h->d_ones;
-            a.window_k = h->d_ones;
-            a.window_k32 = h->d_ones;
-            a.hop = h->sub_bins;
-            a.gain = 0.0f;
-            HIP_TRY(ro::launch_stft(h->sub_bins, RO_FMT_F32, a, s));
-            ro::InterleaveArgs t{};
-            t.in = h->d_mag;
-            t.out = d_rows + done * row_stride;
-            t.rows = n;
-            t.row_stride = row_stride;
-            t.m = h->sub_bins;
-            t.dec = h->dec;
-            HIP_TRY(ro::launch_interleave(t, s));
         }
         return RO_OK;
     }
@@ -1248,25 +1206,21 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
     if (h->big && !h->f64) {
         // bins = dec x 32768, decimation in frequency on the largest single-pass plan:
         //   X[q + dec k'] = sum_m W_N^(m k') { W_bins^(m q) sum_r W_dec^(r q) w[m + N r] x[m + N r] }
-        // dec <= RO_DIF_MAX_DEC: ONE kernel (ro::stft_kernel MODE 3) that sums the row's dec blocks itself -- dec x the
-        // row through L2 per output row, nothing extra through HBM (0.27 / 0.19 of the HBM peak at 65536 / 131072;
-        // 0.11 / 0.06 at 262144 / 524288, where its 4-byte stores `dec` floats apart cost an L2 write request each).
-        // Above: fold_kernel writes the braces to scratch (8 B per bin), the N = 32768 kernel transforms those rows,
-        // interleave_kernel puts the bins in place: 0.12 of the peak at every size, i.e. the speed of a copy.
-        // (Diagnostic builds: RO_BIG_FORM=dif|fold for A/B runs.)
+        // 65536, 131072: ONE kernel (ro::stft_kernel MODE 3) that sums the row's dec blocks itself -- dec x the row
+        // through L2 per output row, nothing extra through HBM (0.27 / 0.19 of the HBM peak; it was 0.11 / 0.06 at
+        // 262144 / 524288, where its 4-byte stores `dec` floats apart cost an L2 write request each).
+        // 262144 ... 1048576: the four-step pair of kernels (ro_fourstep.hip) for the magnitude rows.
+        // Complex spectra of every large size: fold_kernel writes the braces to scratch, the N = 32768 kernel transforms
+        // those rows, interleave2_kernel puts the bins in place (launch_spectra_big).  Rounds 2 and 3 made the magnitude
+        // rows of dec >= 8 that way too (0.10-0.13 of the peak; profiles/r04_fourstep.txt has the A/B).
+        // (Diagnostic builds: RO_BIG_FORM=dif forces the one-kernel form.)
         const int sub = 32768, dec = h->bins / sub;
-        int form = dec <= RO_DIF_MAX_DEC ? 1 : 2;
-#ifdef RO_DIAG_KNOBS
-        if (const char *e = getenv("RO_BIG_FORM")) form = std::strcmp(e, "dif") == 0 ? 1 : 2;
-#endif
-        // 262144 and 524288: the four-step form for the magnitude rows (the fold form stays for their complex spectra)
         bool four = ro::fourstep_supported(h->bins);
 #ifdef RO_DIAG_KNOBS
-        if (const char *e = getenv("RO_BIG_FORM")) four = std::strcmp(e, "four") == 0;
+        if (const char *e = getenv("RO_BIG_FORM")) four = std::strcmp(e, "dif") != 0 && four;
 #endif
         h->four = four;
-        h->dif = form == 1;
-        h->fold = form == 2;
+        h->dif = !four;
         h->sub_bins = sub;
         h->dec = dec;
     }
@@ -1475,7 +1429,6 @@ extern "C" int ro_stft_destroy(ro_stft_t *h)
     if (h->d_four_tw_b) (void)hipFree(h->d_four_tw_b);
     if (h->d_four_tw_r) (void)hipFree(h->d_four_tw_r);
     if (h->d_four_z) (void)hipFree(h->d_four_z);
-    if (h->d_mag) (void)hipFree(h->d_mag);
     if (h->d_ones) (void)hipFree(h->d_ones);
     if (h->d_dif_tw) (void)hipFree(h->d_dif_tw);
     if (h->d_dif_shift) (void)hipFree(h->d_dif_shift);
