@@ -163,8 +163,8 @@ int     ro_gather_rows(void *nccl_comm, const void *d_local, int64_t local_rows,
 int     ro_stitch_rows_device(const void *d_gathered, int64_t total_rows, int world, size_t row_bytes, void *d_out,
                               void *stream);
 /* 1 if `bins` has a kernel in this build: powers of two 256 .. 1048576 (one kernel up to
- * 131072; above, three kernels through HBM scratch that the handle allocates on first use:
- * 12 bytes per bin and row for up to 2 GiB / (8 bins) rows at a time), and every other EVEN
+ * 131072; above, two kernels and one trip through HBM scratch that the handle allocates on first
+ * use: 8 bytes per bin and row for up to 1 GiB / (8 bins) rows at a time), and every other EVEN
  * length 258 .. 524286 (FFTW takes any N, src/FFTBackend.cpp:120; src/BolidRecorder.h:35
  * suggests 32728) as a chirp-z transform on the power-of-two length M >= 2 bins - 1 (scratch:
  * 20 M bytes per row for up to 1 GiB / (8 M) rows at a time).  Odd lengths have no defined
