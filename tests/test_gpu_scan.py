@@ -72,14 +72,34 @@ def test_scan_duplicates_and_quartile_index(ro, oracle, torch_cuda):
 
 @pytest.mark.parametrize("bins,nw,dw,avg", [(4096, 51, 51, 3), (4096, 1, 1, 1), (32768, 1024, 777, 27),
                                            (32768, 1025, 64, 2), (32768, 5000, 3000, 101),
-                                           (1024, 63, 65, 5), (32768, 16384, 16384, 27)])
+                                           (1024, 63, 65, 5), (32768, 16384, 16384, 27),
+                                           (32768, 4096, 4096, 5), (32768, 4097, 100, 5), (32768, 8192, 8193, 3),
+                                           (524288, 3277, 6554, 55), (524288, 20000, 9000, 7)])
 def test_scan_band_shapes(ro, oracle, torch_cuda, bins, nw, dw, avg):
-    """cached (<= 1024 elements) and streaming noise-band paths, odd widths, wide bands."""
+    """bands kept in registers (scan_kernel<E>: up to 1024, 4096, 8192 columns) and bands re-read in batches, odd
+    widths, the limits between the forms, Ionozor-sized rows."""
     rng = np.random.default_rng(nw * 7 + dw)
     ln = int(rng.integers(0, bins - nw + 1))
     ld = int(rng.integers(avg, bins - dw - avg + 1))
     bands = ro.Bands(low_noise=ln, noise_width=nw, low_detect=ld, detect_width=dw, avg_bins=avg)
     rows = np.abs(rng.standard_normal((33, bins))).astype(np.float32)
+    check(ro, oracle, torch_cuda, rows, bands)
+
+
+@pytest.mark.parametrize("dw", [3000, 8192, 20000])
+def test_scan_ties_and_duplicates_in_wide_bands(ro, oracle, torch_cuda, dw):
+    """the >= rule (last index of the maximum) and the quartile among many equal values where a lane holds 47, 128 or
+    a batched 313 columns of the band"""
+    rng = np.random.default_rng(dw)
+    bins = 65536
+    bands = ro.Bands(low_noise=1000, noise_width=dw, low_detect=30000, detect_width=dw, avg_bins=9)
+    rows = rng.integers(0, 9, size=(24, bins)).astype(np.float32)
+    for r in range(24):
+        rows[r, 30000 + rng.choice(dw, size=1 + r % 7, replace=False)] = 11.0
+    got = scan_gpu(ro, torch_cuda, rows, bands)
+    for r in range(24):
+        band = rows[r, 30000:30000 + dw]
+        assert got["peak"][r] == np.flatnonzero(band == 11.0).max()
     check(ro, oracle, torch_cuda, rows, bands)
 
 

@@ -19,18 +19,29 @@ for f in glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")):
             print("  %-70s calls %4s  avg %10.1f us  min %10.1f  max %10.1f" % (
                 row["Name"][:70], row["Calls"], float(row["AverageNs"]) / 1e3, float(row["MinNs"]) / 1e3,
                 float(row["MaxNs"]) / 1e3))
-# per-launch durations from the trace itself: bench.py issues W warm-up steps, K timed steps, then K launches
-# inside ro_stft_time_resident (the HIP-event kernel time of the roofline); the device needs ~20 launches after
-# idle to reach its steady clocks, so the --stats average over ALL launches sits above the steady-state figure
+# per-launch durations from the trace itself.  bench.py issues, in this order: the untimed launches (pre-warm + warm-up),
+# the K timed steps, the soak behind them (clock_power.soak, ~1.5 s), and K launches inside ro_stft_time_resident
+# (roofline.kernel_ms_posthoc).  The device needs ~20 launches after idle to reach its steady clocks, so the --stats
+# average over ALL launches is not the steady-state figure; the timed steps' own mean is printed next to it.
+untimed, timed = 55, 50
+bj0 = os.path.join(d, "bench_trace.json")
+if os.path.exists(bj0):
+    for line in open(bj0):
+        if line.startswith("{"):
+            j0 = json.loads(line)
+            timed = int(j0.get("steps", timed))
+            untimed = int(j0.get("roofline", {}).get("untimed_launches_before_the_timed_region", j0.get("warmup", 30) + 25))
 for f in glob.glob(os.path.join(d, "trace", "*", "*_kernel_trace.csv")):
     dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(f))
            if "stft_kernel" in r["Kernel_Name"] or "stft32k_kernel" in r["Kernel_Name"]]
-    if dur:
-        n = len(dur)
-        k = (n - 55) // 2 if n > 70 else n // 2
+    if len(dur) >= untimed + 2 * timed:
+        mean = lambda x: sum(x) / max(len(x), 1)
+        t = dur[untimed:untimed + timed]
+        soak = dur[untimed + timed:len(dur) - timed]
         print("  stft_kernel launches in issue order, us: first 12 = %s" % [round(x) for x in dur[:12]])
-        print("  mean of the last %d launches (the ones bench.py's HIP events time): %.1f us; of the %d before them "
-              "(the timed steps): %.1f us" % (k, sum(dur[-k:]) / k, k, sum(dur[-2 * k:-k]) / k))
+        print("  %d launches: %d untimed (mean %.1f us), the %d TIMED steps: %.1f us, %d of the soak behind them: %.1f us, "
+              "the last %d (ro_stft_time_resident): %.1f us" % (len(dur), untimed, mean(dur[:untimed]), timed, mean(t),
+                                                                 len(soak), mean(soak), timed, mean(dur[-timed:])))
 bj = os.path.join(d, "bench_trace.json")
 if os.path.exists(bj):
     for line in open(bj):
