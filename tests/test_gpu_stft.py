@@ -107,6 +107,28 @@ def test_cus_left_to_other_kernels_do_not_change_a_bit(ro, torch_cuda, bins, ove
         assert np.array_equal(gpu_rows(ro, torch_cuda, iq, bins, overlap, spare_cus_per_xcd=spare), full), spare
 
 
+@pytest.mark.parametrize("bins,overlap,nrows", [(4096, 2048, 50), (32768, 24576, 40), (65536, 49152, 12), (524288, 262144, 9)])
+def test_row_stride_and_base_need_no_alignment(ro, torch_cuda, bins, overlap, nrows):
+    """the 16-byte row stores of every form at a row stride and a base that are multiples of 4 bytes only: the same
+    bits, and not a float outside the rows"""
+    torch = torch_cuda
+    rng = np.random.default_rng(bins % 983)
+    iq = noise_iq(rng, bins + (nrows - 1) * (bins - overlap))
+    ref = gpu_rows(ro, torch, iq, bins, overlap)
+    d_iq = torch.from_numpy(np.ascontiguousarray(iq)).cuda()
+    with ro.Stft(bins=bins, overlap=overlap) as st:
+        for extra, off in ((1, 0), (3, 1), (5, 3)):
+            stride = bins + extra
+            buf = torch.full((nrows * stride + 8,), float("nan"), dtype=torch.float32, device="cuda")
+            out = buf[off:off + nrows * stride]
+            st.run_resident(d_iq, ro.RO_IQ_F32, iq.shape[0], 0, nrows, out.data_ptr(), row_stride=stride,
+                            stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            got = out.view(nrows, stride).cpu().numpy()
+            assert np.array_equal(got[:, :bins], ref), (extra, off)
+            assert np.isnan(got[:, bins:]).all() and np.isnan(buf[:off].cpu().numpy()).all(), (extra, off)
+
+
 @pytest.mark.parametrize("bins,overlap,nrows", [(258, 0, 9), (1000, 600, 7), (12000, 9000, 5), (32728, 24546, 5),
                                                  (100000, 50000, 3), (524286, 262143, 2)])
 def test_lengths_that_are_not_a_power_of_two(ro, oracle, torch_cuda, bins, overlap, nrows):
