@@ -58,18 +58,19 @@ __device__ __forceinline__ void buf_store_f4(float x0, float x1, float x2, float
     // wait state.  What was observed here departs from the exemption: with the SGPR-soffset form used for every row
     // store and the data registers recycled at once by the butterflies around the pipelined stores, one row in ten left
     // with lanes 12..15 of every 16 carrying the NEXT values of those registers; two real wait states behind the store
-    // ended it.  The asm keeps the four registers alive across them; tests/test_isa_cpu.py checks the emitted ISA of
-    // every kernel for the pattern (and that it would see it: a build without this s_nop is red).
+    // ended it.  The asm keeps the store's register tuple alive across them -- the tuple as ONE operand: given the four
+    // dwords as four operands, hipcc has kept the registers they came from alive instead, copied them into a fresh
+    // tuple for the store and moved the statement in front of it (seen in ro_fourstep.hip's first 16-byte stores);
+    // tests/test_isa_cpu.py checks the emitted ISA of every kernel for the pattern (and that it would see it: a build
+    // without this s_nop is red).
 #if RO_STORE_NOP
-    asm volatile("s_nop 1" ::"v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w));
+    asm volatile("s_nop 1" ::"v"(t));
 #endif
 }
 // the same store (and the same two wait states behind it) for four raw dwords and a cache policy of the caller's choice
 template <int AUX> __device__ __forceinline__ void buf_store_u4(u32x4 t, __amdgpu_buffer_rsrc_t r, int voff, int soff)
 {
     __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, AUX);
-    // (the four dwords as ONE operand: with four scalar operands hipcc kept the registers the dwords came from alive,
-    // copied them into a fresh tuple for the store, and moved this statement in front of it)
 #if RO_STORE_NOP
     asm volatile("s_nop 1" ::"v"(t));
 #endif
