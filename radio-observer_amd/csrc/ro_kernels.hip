@@ -1119,7 +1119,10 @@ __global__ __launch_bounds__(256) void f64_pair_kernel(BigArgsD a)
 #pragma unroll
             for (int k = 0; k < R2; ++k) {
                 const v2d x = v[bitrev<R2>(k)];
-                out[(j0 + k * ns2 + a.n / 2) & (a.n - 1)] = (float)sqrt(x.x * x.x + x.y * x.y);   // WaterfallBackend.cpp:492-505
+                // (the rows are write-once: nt, like every other kernel's row stores -- 4 % on this path; the scratch
+                // between the two kernels stays on the default policy, nt there loses the Infinity Cache: -7 ... -20 %)
+                __builtin_nontemporal_store((float)sqrt(x.x * x.x + x.y * x.y),
+                                            &out[(j0 + k * ns2 + a.n / 2) & (a.n - 1)]);       // WaterfallBackend.cpp:492-505
             }
         } else {
             double2 *out = a.out + row * (int64_t)a.n;
