@@ -51,6 +51,9 @@ def test_bench_line_has_the_contract_fields(ro, torch_cuda):
     sp = d["strict_precision"]
     assert sp["dtype"] == "f64" and sp["parity"]["max_err_per_bin_relative"] <= 1e-5
     assert sp["roofline"]["frac"] == pytest.approx(sp["roofline"]["achieved"] / 8000.0) and "f64_pair_kernel" in sp["roofline"]["kernel"]
+    io = d["ionozor"]                   # the four-step form at Ionozor.json:27-28, never the headline
+    assert io["unit"] == "rows/s" and io["value"] > 0 and io["parity"]["max_err_rel_to_row_max"] <= 1e-5
+    assert io["roofline"]["frac"] == pytest.approx(io["roofline"]["achieved"] / 8000.0) and "four_cols_kernel" in io["roofline"]["kernel"]
     for k in ("streaming", "streaming_batch256"):
         st = d[k]
         assert "error" not in st, st
