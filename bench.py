@@ -89,7 +89,7 @@ def parse():
     p.add_argument("--no-legs", action="store_true",
                    help="N > 1: skip the extra untimed-for-`value` runs with the other --gather modes (config.exchange_legs_rows_per_s)")
     p.add_argument("--no-strict", action="store_true", help="skip the RO_PRECISION_F64 side measurement")
-    p.add_argument("--no-large", action="store_true", help="skip the side measurement at Ionozor's shape (bins 524288)")
+    p.add_argument("--no-large", action="store_true", help="skip the side measurements at the station configs' shapes (bins 524288, 65536)")
     p.add_argument("--soak-seconds", type=float, default=1.5,
                    help="N = 1: behind the timed region, keep launching the same step for this long while the clock / "
                         "power sampler runs (clock_power.soak): the package power the hwmon file reports is an average "
@@ -254,11 +254,11 @@ def pcie_copy_rates(torch, dev, mib=256):
     return 4 * n / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9, 4 * n / (ev[2].elapsed_time(ev[3]) * 1e-3) / 1e9
 
 
-def large_leg(torch, ro, dev, local_rank, parity):
-    """Ionozor.json:27-28 (bins 524288, overlap 262144) on the resident path: rows/s and the fraction of the HBM peak its
-    algorithmic bytes (hop 8 + bins 4 per row) make, all kernels of the size included (two four-step kernels + the
-    band scan), HIP events by ro_stft_time_resident."""
-    bins, overlap, rows, fs = 524288, 262144, 1024, 96000
+def large_leg(torch, ro, dev, local_rank, parity, bins, overlap, rows, cite, kernels, traffic):
+    """A station config's shape above 32768 bins on the resident path: rows/s and the fraction of the HBM peak its
+    algorithmic bytes (hop 8 + bins 4 per row) make, all kernels of the size included (the transform's + the band
+    scan), HIP events by ro_stft_time_resident."""
+    fs = 96000
     hop = bins - overlap
     samples = bins + hop * (rows - 1)
     iq = synth_iq(torch, samples, 0x10, dev)
@@ -271,18 +271,18 @@ def large_leg(torch, ro, dev, local_rank, parity):
                      avg_bins=max(f2b(JSON_BOLID["avg_freq_range"]) - f2b(0.0), 1))
     sptr = torch.cuda.current_stream(dev).cuda_stream
     with ro.Stft(bins=bins, overlap=overlap, sample_rate=fs, device=local_rank, bands=bands) as st:
-        ms, _, _ = st.time_resident(iq, ro.RO_IQ_F32, samples, 0, rows, out_rows, 8, d_records=recs, stream=sptr)
+        # (the device has idled through the previous leg's host work: 40-60 ms of launches, the second half timed)
+        iters = 24
+        ms, _, _ = st.time_resident(iq, ro.RO_IQ_F32, samples, 0, rows, out_rows, iters, d_records=recs, stream=sptr)
         torch.cuda.synchronize(dev)
-        step_ms = float(np.mean(ms[3:]))
+        step_ms = float(np.mean(ms[iters // 2:]))
         alg = hop * 8 + bins * 4
-        entry = {"workload": "bins 524288, overlap 262144 (Ionozor.json:27-28), %d rows per launch, band scan included" % rows,
+        entry = {"workload": "bins %d, overlap %d (%s), %d rows per launch, band scan included" % (bins, overlap, cite, rows),
                  "value": rows / (step_ms * 1e-3), "unit": "rows/s", "ms_per_step": step_ms, "dtype": "f32",
                  "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                               "achieved": alg * rows / (step_ms * 1e-3) / 1e9,
                               "frac": alg * rows / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              "kernel": "four_cols_kernel + four_rows_kernel + scan_kernel (csrc/ro_fourstep.hip)",
-                              "algorithmic_bytes_per_row": alg,
-                              "traffic": "13.5 MiB per row by FETCH_SIZE / WRITE_SIZE (profiles/r04_fourstep.txt)"}}
+                              "kernel": kernels, "algorithmic_bytes_per_row": alg, "traffic": traffic}}
         if parity:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import ro_oracle as O
@@ -860,10 +860,14 @@ def main():
                                        "tolerance_per_bin": 1e-5}
             out["strict_precision"] = entry
 
-        # ---- Ionozor's shape next to the headline (never the headline): bins 524288, overlap 262144 (Ionozor.json:27-28),
-        # the four-step pair of kernels + scan_kernel, 1024 rows per launch, inputs resident
+        # ---- the station configs' own shapes next to the headline (never the headline), inputs resident:
+        # Ionozor.json:27-28 on the four-step pair of kernels, Bolidozor.json:45-46 on the one-kernel large form
         if world == 1 and not a.no_large and not c5 and BINS == 32768:
-            out["ionozor"] = large_leg(torch, ro, dev, local_rank, not a.no_parity)
+            out["ionozor"] = large_leg(torch, ro, dev, local_rank, not a.no_parity, 524288, 262144, 1024, "Ionozor.json:27-28",
+                                       "four_cols_kernel + four_rows_kernel + scan_kernel (csrc/ro_fourstep.hip)",
+                                       "13.5 MiB per row by FETCH_SIZE / WRITE_SIZE (profiles/r04_fourstep.txt)")
+            out["bolidozor"] = large_leg(torch, ro, dev, local_rank, not a.no_parity, 65536, 49152, 8192, "Bolidozor.json:45-46",
+                                         "stft_kernel<Plan32768, ., 3> (two workgroups per stream row) + scan_kernel", None)
 
         # ---- the drop-in path at full speed (never the headline): Frontend::process -> HipWaterfallBackend::process
         # with 4096-sample vector<Complex> calls (src/RawStream.cpp:44-66) -> kernels -> full rows back to the host row

@@ -54,6 +54,8 @@ def test_bench_line_has_the_contract_fields(ro, torch_cuda):
     io = d["ionozor"]                   # the four-step form at Ionozor.json:27-28, never the headline
     assert io["unit"] == "rows/s" and io["value"] > 0 and io["parity"]["max_err_rel_to_row_max"] <= 1e-5
     assert io["roofline"]["frac"] == pytest.approx(io["roofline"]["achieved"] / 8000.0) and "four_cols_kernel" in io["roofline"]["kernel"]
+    bo = d["bolidozor"]                 # Bolidozor.json:45-46 on the one-kernel large form
+    assert bo["value"] > io["value"] and bo["parity"]["max_err_rel_to_row_max"] <= 1e-5 and "65536" in bo["workload"]
     for k in ("streaming", "streaming_batch256"):
         st = d[k]
         assert "error" not in st, st
