@@ -368,6 +368,8 @@ class ClockPowerSampler:
         except Exception:
             self.files = None
         self._stop = threading.Event()
+        self._go = threading.Event()           # cleared while the timed region runs: no reads, no GIL, no SMU queries
+        self._go.set()
         self._thread = threading.Thread(target=self._run, daemon=True) if self.files else None
 
     def _read(self, f):
@@ -377,13 +379,30 @@ class ClockPowerSampler:
         except Exception:
             return float("nan")
 
-    def _run(self):
-        while not self._stop.is_set():
+    def read_once(self):
+        if self.files:
             t = time.perf_counter()
             mhz = self._read(self.files[0]) / 1e6
             w = self._read(self.files[1]) / 1e6 if self.files[1] else float("nan")
             self.samples.append((t, mhz, w))
+
+    def _run(self):
+        while not self._stop.is_set():
+            self._go.wait()
+            if self._stop.is_set():
+                break
+            self.read_once()
             time.sleep(0.002)
+
+    def pause(self):
+        """entering the timed region: the thread parks (it neither takes the GIL from the launch loop nor makes the
+        firmware answer a power query while the kernel under test runs); ONE read brackets the region on each side"""
+        self._go.clear()
+        self.read_once()
+
+    def resume(self):
+        self.read_once()
+        self._go.set()
 
     def start(self):
         if self._thread:
@@ -392,6 +411,7 @@ class ClockPowerSampler:
     def stop(self):
         if self._thread:
             self._stop.set()
+            self._go.set()
             self._thread.join()
 
     def summary(self, t0, t1):
@@ -405,7 +425,9 @@ class ClockPowerSampler:
             return None if x.size == 0 else {"mean": float(x.mean()), "min": float(x.min()), "max": float(x.max())}
         inside = [r for r in self.samples if t0 <= r[0] <= t1]
         before = [r for r in self.samples if r[0] < t0]
-        return {"available": True, "card": self.card, "source": "hwmon freq1_input / power1_input, one read per ~2 ms",
+        return {"available": True, "card": self.card,
+                "source": "hwmon freq1_input / power1_input: one read per ~2 ms during warm-up and soak; the sampler is parked "
+                          "inside the timed region, which is bracketed by one read just before and one just after it",
                 "timed_region": {"samples": len(inside), "sclk_mhz": stats(inside, 1), "package_watts": stats(inside, 2)},
                 "warmup": {"samples": len(before), "sclk_mhz": stats(before, 1), "package_watts": stats(before, 2)}}
 
@@ -644,6 +666,9 @@ def main():
         step(i)
     fence()
     ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t_bracket0 = time.perf_counter()
+    if sampler:
+        sampler.pause()
     t0 = time.perf_counter()
     ev_a.record(stream)
     for i in range(a.steps):
@@ -651,6 +676,9 @@ def main():
     ev_b.record(stream)
     fence()
     dt = time.perf_counter() - t0
+    if sampler:
+        sampler.resume()
+    t_bracket1 = time.perf_counter()
     clock_power = None
     if sampler:
         # ... and on, outside the timed region: what the package settles at under this kernel (the power reading is a
@@ -665,7 +693,7 @@ def main():
                 soak_steps += 50
         t_soak1 = time.perf_counter()
         sampler.stop()
-        clock_power = sampler.summary(t0, t0 + dt)
+        clock_power = sampler.summary(t_bracket0, t_bracket1)
         if soak_steps and clock_power.get("available"):
             tail = sampler.summary(t_soak0 + 0.6 * (t_soak1 - t_soak0), t_soak1)["timed_region"]      # the last 40 % of it
             clock_power["soak"] = {"seconds": t_soak1 - t_soak0, "steps": soak_steps,
@@ -805,7 +833,7 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import ro_oracle as O
             pick = [0, 1, R // 2, R - 1]
-            worst = 0.0
+            worst, pb_max, pb_over, pb_bins = 0.0, 0.0, 0, 0
             scan_ok = True
             rec_host = recs[0].cpu().numpy().view(np.uint8).reshape(R, 12)
             rec_host = np.frombuffer(rec_host.tobytes(), dtype=ro.capi.SCAN_DTYPE)
@@ -814,11 +842,19 @@ def main():
                 want = O.stft(seg, BINS, OVERLAP, w=st.window)[0]
                 got = rows[r].cpu().numpy()
                 worst = max(worst, float(np.abs(got.astype(np.float64) - want).max() / want.max()))
+                pb = np.abs(got.astype(np.float64) - want) / np.maximum(want, 1e-300)
+                pb_max = max(pb_max, float(pb.max()))
+                pb_over += int((pb > 1e-5).sum())
+                pb_bins += pb.size
                 n, p, av = O.scan_rows(got[None, :], bands.low_noise, bands.noise_width, bands.low_detect,
                                        bands.detect_width, bands.avg_bins)
                 scan_ok &= (n[0] == rec_host["noise"][r] and p[0] == rec_host["peak"][r]
                             and av[0] == rec_host["average"][r])
             out["parity"] = {"rows_checked": pick, "max_err_rel_to_row_max": worst, "tolerance": 1e-5,
+                             # the other reading of north_star's "1e-5 relative": every bin against its own magnitude.
+                             # The float32 default does not meet it on the weakest bins of a row (reported, and pinned by
+                             # tests/test_gpu_strict.py); strict_precision below is the mode that does.
+                             "per_bin": {"max_rel": pb_max, "frac_over_1e-5": pb_over / max(1, pb_bins), "met": pb_max <= 1e-5},
                              "scan_records_bit_exact": bool(scan_ok)}
 
         # ---- the strict-precision mode next to the headline (never the headline): same input, fewer rows

@@ -285,8 +285,12 @@ int ro_stft_fetch(ro_stft_t *h, int64_t max_rows, int first_col, int cols,
  * sink the device-to-host copy of a batch is that write, and the ring's only copy.  Row r of the stream (counted from
  * ro_stft_create / ro_stft_reset) lands at  base + ((first_slot + r) mod capacity_rows) * row_stride  floats: the
  * handle's full rows, or its tile's columns when one is configured.  The ring has to be page-locked memory from
- * ro_pinned_alloc (the copies are asynchronous) and has to stay allocated until the sink is removed (base = NULL) or
- * the handle destroyed.  A row is in place once ro_stft_fetch has reported it
+ * ro_pinned_alloc (the copies are asynchronous; hipPointerGetAttributes is asked about its first and last byte and
+ * anything that is not a host allocation of this process's HIP runtime -- heap memory, a numpy array -- is refused with
+ * RO_ERR_INVALID) and has to stay allocated until the sink is removed (base = NULL) or
+ * the handle destroyed.  With a sink ro_stft_push is ALL OR NOTHING: a call whose samples would complete more rows than
+ * the ring has free slots (capacity_rows - rows waiting to be fetched) returns RO_ERR_STATE having consumed nothing;
+ * fetch, then push the same buffer again.  A row is in place once ro_stft_fetch has reported it
  * (rows_out = NULL from then on: RO_ERR_STATE otherwise; the scan records still come through records_out), and the
  * handle writes up to a batch of slots AHEAD of what has been fetched: capacity_rows >= 2 x max_batch_rows, and
  * whoever reads old rows of the ring (snapshot writers) has to stay that far behind the head, as it has to for push().
@@ -295,6 +299,10 @@ int ro_stft_set_row_sink(ro_stft_t *h, float *base, int64_t row_stride, int64_t 
 /* page-locked host memory for such a ring (hipHostMalloc on `device`'s context); NULL when there is none to be had */
 void *ro_pinned_alloc(int device, size_t bytes);
 void  ro_pinned_free(void *p);
+/* 1 when [p, p + bytes) is host memory page-locked by this process's HIP runtime (what ro_stft_set_row_sink accepts:
+ * the target of the DMA that stands in for processFFT's write into buffer_->push(), src/WaterfallBackend.cpp:488-505),
+ * 0 for anything else -- heap or stack memory, device memory, or no HIP device in the process. */
+int   ro_pinned_check(const void *p, size_t bytes);
 /* ro_stft_fetch for a handle with tile_ln = 1: the whole tile of each row, its log, the row's min / max of the log
  * (2 floats) and the scan record -- any of the four may be NULL. */
 int ro_stft_fetch_ln(ro_stft_t *h, int64_t max_rows, float *tile_out, float *ln_out, float *minmax_out,

@@ -13,7 +13,7 @@ entry points raise.
 from . import build as _build  # noqa: F401
 from . import capi  # noqa: F401
 from .capi import (  # noqa: F401
-    Stft, StftError, Bands, ScanRecord, PinnedArray, library, library_path,
+    Stft, StftError, Bands, ScanRecord, PinnedArray, library, library_path, hip_runtimes, require_one_hip_runtime,
     clamp_overlap, fft_sample_rate, frequency_to_bin, bin_to_frequency, time_to_fft_samples,
     row_count, window_table, bins_supported, device_count, shard_rows, shard_samples, shard_max_rows,
     stitch_rows, ln_levels,

@@ -113,6 +113,7 @@ _EXPORTS = {
     "ro_stft_set_row_sink": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]),
     "ro_pinned_alloc": (C.c_void_p, [C.c_int, C.c_size_t]),
     "ro_pinned_free": (None, [C.c_void_p]),
+    "ro_pinned_check": (C.c_int, [C.c_void_p, C.c_size_t]),
     "ro_stft_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "ro_stft_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                 C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
@@ -127,6 +128,32 @@ def library_path():
 
 def exported_symbols():
     return sorted(_EXPORTS)
+
+
+def hip_runtimes():
+    """Paths of every libamdhip64 mapped into this process.  libro_stft.so asks the loader for `libamdhip64.so.7`; a
+    copy some other package has already loaded under that SONAME (torch bundles one) is reused, so a process that
+    imports torch FIRST holds one runtime.  The other order leaves two -- torch asks for its own copy by file name --
+    and then a device pointer, a stream or page-locked memory of one runtime means nothing to the other."""
+    found = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(None, 1)[-1]
+                if "libamdhip64" in os.path.basename(path):
+                    found.add(os.path.realpath(path))
+    except OSError:
+        pass
+    return sorted(found)
+
+
+def require_one_hip_runtime():
+    """Raise when two HIP runtimes share the process (see hip_runtimes): handles are refused rather than handed
+    pointers the other runtime owns."""
+    rts = hip_runtimes()
+    if len(rts) > 1:
+        raise StftError(-5, "two HIP runtimes are mapped into this process (%s): import torch BEFORE radio-observer_amd "
+                            "loads libro_stft.so, so that both use the same one" % ", ".join(rts))
 
 
 def library():
@@ -297,7 +324,9 @@ class Stft:
         cfg.precision = precision
         cfg.tile_ln = 1 if tile_ln else 0
         self._h = C.c_void_p()
-        _check(library().ro_stft_create(C.byref(cfg), C.byref(self._h)))
+        lib = library()
+        require_one_hip_runtime()
+        _check(lib.ro_stft_create(C.byref(cfg), C.byref(self._h)))
         self.bins = bins
         self.hop = library().ro_stft_hop(self._h)
         self.scan_enabled = bands is not None

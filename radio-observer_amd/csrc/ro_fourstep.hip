@@ -474,7 +474,10 @@ struct DevicePlan {
     int  cus = 0;
 };
 
-template <typename K> static hipError_t prepare(K kernel, int lds_bytes, int &cus)
+// One table PER KERNEL (the kernel is a template argument: every four_cols_kernel variant and four_rows_kernel have the
+// same function type, a table keyed by the type was shared between them and only the first kernel launched on a device
+// got its dynamic-LDS attribute).
+template <auto KERNEL> static hipError_t prepare(int lds_bytes, int &cus)
 {
     static std::mutex lock;
     static DevicePlan table[64];
@@ -485,7 +488,7 @@ template <typename K> static hipError_t prepare(K kernel, int lds_bytes, int &cu
     std::lock_guard<std::mutex> g(lock);
     DevicePlan &d = table[dev];
     if (!d.ready) {
-        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) != hipSuccess)
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) != hipSuccess)
             return e;
         if ((e = hipDeviceGetAttribute(&d.cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
         d.ready = true;
@@ -506,7 +509,7 @@ static unsigned grid_for(int cus, int spare_cus, int64_t nblk)
 template <int FMT, int R2, int NT> static hipError_t launch_cols_nt(const FourArgs &a, hipStream_t s)
 {
     int cus = 0;
-    hipError_t e = prepare(&four_cols_kernel<FMT, R2, NT>, COLS_LDS, cus);
+    hipError_t e = prepare<&four_cols_kernel<FMT, R2, NT>>(COLS_LDS, cus);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((four_cols_kernel<FMT, R2, NT>), dim3(grid_for(cus, a.spare_cus, a.rows * (N2 / (T / R2)))), dim3(T), COLS_LDS, s, a);
     return hipGetLastError();
@@ -581,7 +584,7 @@ hipError_t launch_fourstep(int fmt, const FourArgs &a, hipStream_t s)
     else return hipErrorInvalidValue;
     if (e != hipSuccess) return e;
     int cus = 0;
-    if ((e = prepare(&four_rows_kernel, ROWS_LDS, cus)) != hipSuccess) return e;
+    if ((e = prepare<&four_rows_kernel>(ROWS_LDS, cus)) != hipSuccess) return e;
     hipLaunchKernelGGL(four_rows_kernel, dim3(grid_for(cus, a.spare_cus, a.rows * (a.n1 / BROWS))), dim3(T), ROWS_LDS, s, a);
     return hipGetLastError();
 }

@@ -38,8 +38,10 @@
 #ifndef RO_SPEC_SCRATCH_MB
 #define RO_SPEC_SCRATCH_MB 2048
 #endif
-// the four-step form's scratch (one block of Z between its two kernels), MiB: a chunk that stays inside the 256 MiB
-// Infinity Cache keeps the trip off HBM (diagnostic builds: RO_FOUR_SCRATCH_MB)
+// the four-step form's scratch (one block of Z between its two kernels), MiB AT MOST: the block grows to what a
+// launch asks for (a streaming handle at Ionozor's shape launches a handful of rows and holds a few MiB, not the
+// limit).  1 GiB measured best for resident launches -- blocks inside the 256 MiB Infinity Cache were 3 % faster for the
+// row kernel and 13 % slower for the column kernel (profiles/r04_fourstep.txt).  Diagnostic builds: RO_FOUR_SCRATCH_MB
 #ifndef RO_FOUR_SCRATCH_MB
 #define RO_FOUR_SCRATCH_MB 1024
 #endif
@@ -577,13 +579,24 @@ int launch_transform(ro_stft *h, const void *d_iq, int format, int64_t first_row
         return RO_OK;
     }
     if (h->four) {
-        if (!h->d_four_z) {
+        {
             int64_t mib = RO_FOUR_SCRATCH_MB;
 #ifdef RO_DIAG_KNOBS
             if (const char *e = getenv("RO_FOUR_SCRATCH_MB")) mib = std::max<int64_t>(4, atoll(e));
 #endif
-            h->four_rows = std::max<int64_t>(1, (mib << 20) / ((int64_t)h->bins * 8));
-            HIP_TRY(hipMalloc(&h->d_four_z, (size_t)h->four_rows * h->bins * 2 * sizeof(float)));
+            const int64_t limit = std::max<int64_t>(1, (mib << 20) / ((int64_t)h->bins * 8));
+            const int64_t want = std::min(limit, rows);
+            if (want > h->four_rows) {
+                // (launches on one handle are ordered on the caller's stream; the old block may still be in use there)
+                if (h->d_four_z) {
+                    HIP_TRY(hipStreamSynchronize(s));
+                    HIP_TRY(hipFree(h->d_four_z));
+                    h->d_four_z = nullptr;
+                    h->four_rows = 0;
+                }
+                HIP_TRY(hipMalloc(&h->d_four_z, (size_t)want * h->bins * 2 * sizeof(float)));
+                h->four_rows = want;
+            }
         }
         for (int64_t done = 0; done < rows; done += h->four_rows) {
             ro::FourArgs f{};
@@ -761,8 +774,9 @@ int run_stream_batch(ro_stft *h, int64_t rows)
     const int64_t need = (rows - 1) * (int64_t)h->hop + h->bins;       // samples
     if ((int64_t)h->staged_have < need) return fail(RO_ERR_STATE, "internal: %lld samples staged, %lld needed",
                                                     (long long)h->staged_have, (long long)need);
-    // rows that have not been fetched sit in the sink's slots: a batch that would lap them is not launched (the caller
-    // fetches between its pushes; a push can stage at most one batch beyond this point, so nothing is lost)
+    // rows that have not been fetched sit in the sink's slots: a batch that would lap them is not launched.  ro_stft_push
+    // never gets here in that state (it refuses such a call whole, before staging); ro_stft_flush does, and leaves the
+    // staged samples where they are, so a flush repeated after a fetch loses nothing
     if (h->sink && h->rows_ready + rows > h->sink_cap)
         return fail(RO_ERR_STATE, "row sink full: %lld rows wait to be fetched in a ring of %lld slots", (long long)h->rows_ready,
                     (long long)h->sink_cap);
@@ -1694,6 +1708,25 @@ extern "C" int ro_stft_push(ro_stft_t *h, const void *iq, int format, int64_t sa
         for (size_t i = h->staged_have * 2; i-- > 0;) dst[i] = (float)src[i];
         h->stage_fmt = RO_IQ_F32;
     }
+    // With a row sink a push is all or nothing: the batches this call would complete are counted BEFORE anything is
+    // staged, and a call whose rows would lap rows that still wait to be fetched is refused whole -- no sample taken,
+    // no counter moved -- so the caller fetches and pushes the same buffer again (the streaming analogue of
+    // RingBuffer2D::push never overwriting a reserved row silently, src/RingBuffer.h:482-509).
+    if (h->sink) {
+        const size_t spent = (size_t)h->batch_rows * h->hop;               // samples a batch retires
+        size_t have = h->staged_have;
+        int64_t batches = 0;
+        for (int64_t left = samples; left > 0;) {
+            const int64_t take = std::min<int64_t>(left, (int64_t)(cap - have));
+            have += (size_t)take;
+            left -= take;
+            if (have == cap) { ++batches; have -= spent; }
+        }
+        if (h->rows_ready + batches * (int64_t)h->batch_rows > h->sink_cap)
+            return fail(RO_ERR_STATE, "row sink full: this push would complete %lld rows with %lld waiting to be fetched in a "
+                                      "ring of %lld slots; nothing was consumed -- fetch, then push the same samples again",
+                        (long long)(batches * h->batch_rows), (long long)h->rows_ready, (long long)h->sink_cap);
+    }
     const size_t sb = stage_sample_bytes(h);
     const size_t isb = format == RO_IQ_F64 ? 16 : format == RO_IQ_F32 ? 8 : 4;       // bytes per sample as delivered
     const char *in = static_cast<const char *>(iq);
@@ -1842,11 +1875,38 @@ extern "C" int ro_stft_set_row_sink(ro_stft_t *h, float *base, int64_t row_strid
         return fail(RO_ERR_INVALID, "row sink: stride %lld (rows are %d wide), %lld slots (two batches of %d rows at least), "
                                     "first slot %lld", (long long)row_stride, cols, (long long)capacity_rows, h->batch_rows,
                     (long long)first_slot);
+    // The downloads into the ring are asynchronous DMA: the whole range has to be host memory page-locked by THIS
+    // process's HIP runtime.  Heap memory is refused here rather than discovered by a copy engine later.
+    {
+        const size_t bytes = ((size_t)(capacity_rows - 1) * (size_t)row_stride + (size_t)cols) * sizeof(float);
+        if (ro_pinned_check(base, bytes) != 1)
+            return fail(RO_ERR_INVALID, "row sink: [%p, +%zu bytes) is not page-locked host memory of this process's HIP runtime "
+                                        "(use ro_pinned_alloc)", (const void *)base, bytes);
+    }
     h->sink = base;
     h->sink_stride = row_stride;
     h->sink_cap = capacity_rows;
     h->sink_first = first_slot;
     return RO_OK;
+}
+
+// 1: [p, p + bytes) is host memory page-locked by this process's HIP runtime (ro_pinned_alloc, hipHostMalloc,
+// hipHostRegister) -- first and last byte are both known to the runtime as host allocations and lie in ONE mapping
+// (equal distance in the runtime's view); 0: it is not (heap, stack, a numpy array, device memory, no device at all).
+extern "C" int ro_pinned_check(const void *p, size_t bytes)
+{
+    if (!p || bytes == 0) return 0;
+    const char *lo = static_cast<const char *>(p), *hi = lo + bytes - 1;
+    hipPointerAttribute_t a0{}, a1{};
+    const hipError_t e0 = hipPointerGetAttributes(&a0, lo);
+    const hipError_t e1 = e0 == hipSuccess ? hipPointerGetAttributes(&a1, hi) : e0;
+    if (e0 != hipSuccess || e1 != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return a0.type == hipMemoryTypeHost && a1.type == hipMemoryTypeHost && a0.hostPointer && a1.hostPointer &&
+                   static_cast<const char *>(a1.hostPointer) - static_cast<const char *>(a0.hostPointer) == hi - lo
+               ? 1 : 0;
 }
 
 extern "C" void *ro_pinned_alloc(int device, size_t bytes)

@@ -228,6 +228,19 @@ void HipWaterfallBackend::process(const std::vector<Complex> &data, DataInfo inf
         const Complex *src = data.data() + at;
         const size_t n = std::min(piece, data.size() - at);
         int64_t ready = 0;
+        if (rowSink_) {
+            // The rows this piece completes may be on their way into the slots ahead of the ring's head as soon as
+            // ro_stft_push has queued their batch: whoever holds a reservation there (a queued snapshot that has
+            // fallen a whole ring behind) has to learn it BEFORE the DMA can start, not when the rows are handed
+            // over.  (Rows that complete without filling a batch are marked a batch early: conservative.)
+            const int64_t upTo = samplesIn_ - (int64_t)data.size() + (int64_t)(at + n);
+            const int64_t complete = upTo >= bins_ ? (upTo - bins_) / hop_ + 1 : 0;
+            const int64_t ahead = complete - rowsDelivered_;
+            if (ahead > 0) {
+                std::lock_guard<std::mutex> g(bufferMutex_);
+                buffer_.markAhead((int)std::min<int64_t>(ahead, buffer_.getCapacity()));
+            }
+        }
         RawSpan spans[2];
         const int ns = (size_t)rawBuffer_.getCapacity() >= n ? pushRaw(src, n, spans) : 0;
         int rc = RO_OK;
@@ -241,12 +254,6 @@ void HipWaterfallBackend::process(const std::vector<Complex> &data, DataInfo inf
             lastError_ = ro_last_error();
             std::fprintf(stderr, "HipWaterfallBackend: %s\n", lastError_.c_str());
             return;
-        }
-        if (rowSink_ && ready > 0) {
-            // `ready` rows are on their way into the slots ahead of the ring's head: whoever holds a reservation there
-            // (a queued snapshot that has fallen a whole ring behind) learns it now, not when the rows are handed over
-            std::lock_guard<std::mutex> g(bufferMutex_);
-            buffer_.markAhead((int)std::min<int64_t>(ready, buffer_.getCapacity()));
         }
         drain(false);
     }

@@ -129,6 +129,14 @@ void SnapshotRecorder::threadMethod()
                     if (s.includeRawData) writeRaw(s);                                              // :80-81
                 }
                 std::lock_guard<std::mutex> g(*bufferMutex_);
+                // The reference keeps the reservation's dirty flag and never reads it (src/RingBuffer.h:482-495, :617-620).
+                // Here a writer that has been lapped says so: with the row sink the ring's slots are written by DMA up to
+                // a batch ahead of push(), so a snapshot that fell a ring behind may hold rows newer than its header.
+                if (buffer_->isDirty(s.reservation)) {
+                    dirtySnapshots_++;
+                    std::fprintf(stderr, "SnapshotRecorder: %s was lapped by the row ring while it waited to be written; "
+                                         "its oldest rows are newer than its header says\n", s.fileName.c_str());
+                }
                 buffer_->freeReservation(s.reservation);                                            // :87-90
             } else if (open) {
                 keep.push_back(s);                     // rows still to come; at the end an unfinished one is dropped

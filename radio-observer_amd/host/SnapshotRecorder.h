@@ -5,6 +5,7 @@
 // so a slow disk never stalls Backend::process.
 #pragma once
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -84,6 +85,7 @@ public:
     // (copies taken under the lock: the worker appends to the lists while the stream runs)
     std::vector<std::string> filesWritten() const { std::lock_guard<std::mutex> g(listMutex_); return written_; }
     std::vector<std::string> rawFilesWritten() const { std::lock_guard<std::mutex> g(listMutex_); return writtenRaw_; }
+    int dirtySnapshots() const { return dirtySnapshots_.load(); }     // snapshots written after the ring had lapped them
     const std::vector<Snapshot> &snapshotsQueued() const { return queued_; }
     int snapshotRows() const { return snapshotRows_; }
     int leftBin() const { return leftBin_; }
@@ -104,6 +106,7 @@ protected:
     Snapshot nextSnapshot_;
     std::vector<Snapshot> queued_;       // everything startWriting() has queued so far (inspection)
     std::vector<std::string> written_, writtenRaw_;
+    std::atomic<int> dirtySnapshots_{0};
     mutable std::mutex listMutex_;
     Channel<Snapshot> snapshots_;
     std::thread worker_;

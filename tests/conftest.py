@@ -14,15 +14,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def pytest_collection_modifyitems(config, items):
-    # torch bundles its own libamdhip64: when GPU tests are in the run it has to be the FIRST HIP runtime the process
-    # loads -- a test that loads libro_host.so / libro_stft.so (linked against /opt/rocm's copy) before the first torch
-    # test would leave torch with a second runtime that sees no device
-    if any(it.get_closest_marker("gpu") for it in items):
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+# torch bundles its own libamdhip64 (SONAME libamdhip64.so.7, the name libro_stft.so / libro_host.so ask the loader for):
+# imported FIRST, its copy is the one every later library resolves against and the process holds ONE HIP runtime.  The
+# other order maps a second copy (torch asks for its own by file name) -- capi.require_one_hip_runtime refuses handles
+# then; tests/test_capi_cpu.py::test_two_hip_runtimes_are_refused covers both orders in child processes.
+try:
+    import torch  # noqa: F401,E402
+except ImportError:
+    pass
 
 
 @pytest.fixture(scope="session")

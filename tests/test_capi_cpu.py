@@ -4,6 +4,8 @@ entry point fails loudly (RO_ERR_HIP) when there is no GPU -- there is no CPU fa
 import ctypes as C
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -117,6 +119,39 @@ def test_row_sink_entry_points_without_a_device(ro):
         assert not lib.ro_pinned_alloc(0, 4096)
         with pytest.raises(MemoryError):
             ro.PinnedArray(4, 4)
+
+
+def test_pinned_check_refuses_heap_memory(ro):
+    """ro_pinned_check is what ro_stft_set_row_sink asks before it lets a DMA near the caller's ring: heap memory, NULL
+    and empty ranges are not page-locked memory of this process's HIP runtime (with no device nothing is)."""
+    import numpy as np
+    lib = ro.library()
+    heap = np.zeros(1 << 20, np.float32)
+    assert lib.ro_pinned_check(heap.ctypes.data, heap.nbytes) == 0
+    assert lib.ro_pinned_check(heap.ctypes.data, 4) == 0
+    assert lib.ro_pinned_check(None, 4096) == 0 and lib.ro_pinned_check(heap.ctypes.data, 0) == 0
+
+
+def test_two_hip_runtimes_are_refused():
+    """Import order decides how many HIP runtimes a process holds (capi.hip_runtimes): torch first -> libro_stft.so
+    reuses torch's copy through the SONAME; the product first -> torch maps its own second copy, and handles are
+    refused from then on instead of mixing pointers of two runtimes."""
+    code = ("import importlib, sys; sys.path.insert(0, %r)\n"
+            "%s\n"
+            "ro = importlib.import_module('radio-observer_amd')\n"
+            "ro.library()\n"
+            "%s\n"
+            "n = len(ro.hip_runtimes())\n"
+            "try:\n"
+            "    ro.require_one_hip_runtime(); ok = True\n"
+            "except ro.StftError as e:\n"
+            "    ok = False; assert e.code == -5 and 'two HIP runtimes' in str(e)\n"
+            "print(n, ok)\n")
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="")       # nothing here needs the device
+    good = subprocess.check_output([sys.executable, "-c", code % (ROOT, "import torch", "")], env=env, text=True).split()
+    assert good == ["1", "True"], good
+    bad = subprocess.check_output([sys.executable, "-c", code % (ROOT, "", "import torch")], env=env, text=True).split()
+    assert bad == ["2", "False"], bad
 
 
 def test_product_does_not_touch_the_oracle():

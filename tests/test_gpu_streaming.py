@@ -160,6 +160,14 @@ def test_row_sink_receives_the_rows_in_ring_order(ro, oracle, bins, overlap, bat
     with ro.Stft(bins=bins, overlap=overlap, max_batch_rows=batch, tile=tile) as st:
         with pytest.raises(ro.StftError):
             st.set_row_sink(small.array)
+        # heap memory is refused before any copy engine sees it; page-locked memory of this runtime is accepted
+        heap = np.zeros((slots, cols + 3), np.float32)
+        assert ro.library().ro_pinned_check(heap.ctypes.data, heap.nbytes) == 0
+        assert ro.library().ro_pinned_check(ring.ctypes.data, ring.nbytes) == 1
+        assert ro.library().ro_pinned_check(ring.ctypes.data, ring.nbytes + 4096 * 1024) == 0    # runs off the allocation
+        with pytest.raises(ro.StftError) as e:
+            st.set_row_sink(heap, first_slot)
+        assert e.value.code == -1 and "page-locked" in str(e.value)
         st.set_row_sink(ring, first_slot)
         seen = 0
         for i in range(0, T, 3000):
@@ -187,12 +195,30 @@ def test_row_sink_receives_the_rows_in_ring_order(ro, oracle, bins, overlap, bat
             seen += got
         assert seen == R
         st.reset()
-        # rows nobody fetches stay in the ring's slots: the batch that would lap them is refused, not launched
+        # rows nobody fetches stay in the ring's slots: a push that would lap them is refused WHOLE -- nothing consumed,
+        # nothing launched -- and the same samples pushed again in pieces with a fetch in between arrive without a gap
+        big = iq[:bins + (slots + batch) * hop]
+        before = st.stats()["samples_in"]
         with pytest.raises(ro.StftError) as e:
-            st.push(iq[:bins + (slots + batch) * hop])
-        assert "row sink full" in str(e.value)
+            st.push(big)
+        assert "row sink full" in str(e.value) and "nothing was consumed" in str(e.value)
+        assert st.stats()["samples_in"] == before and st.fetch_records(10 * slots)[1] == 0
+        ring[:] = np.nan
+        seen, cut = 0, bins + (batch - 1) * hop + 7
+        for piece in (big[:cut], big[cut:]):
+            st.push(piece)
+            while True:
+                first, got, _ = st.fetch_records(10 * slots)
+                if got == 0:
+                    break
+                assert first == seen
+                for r in range(first, first + got):
+                    ref = want[r, tile[0]:tile[0] + tile[1]] if tile else want[r]
+                    assert np.abs(ring[(first_slot + r) % slots, :cols] - ref).max() <= 1e-5 * want[r].max()
+                seen += got
+        st.flush()
         first, got, _ = st.fetch_records(10 * slots)
-        assert first == 0 and 0 < got <= slots
+        assert first == seen and seen + got == slots + batch + 1
         st.reset()
         st.set_row_sink(None)
         st.push(iq[:bins + hop])
@@ -202,3 +228,14 @@ def test_row_sink_receives_the_rows_in_ring_order(ro, oracle, bins, overlap, bat
     del ring
     pinned.close()
     small.close()
+
+
+def test_one_hip_runtime_in_the_test_process(ro, torch_cuda):
+    """The GPU tests import torch first (conftest), so libro_stft.so resolves `libamdhip64.so.7` against the copy torch
+    has loaded: ONE HIP runtime in the process, device pointers, streams and page-locked memory mean the same thing to
+    torch and to the product."""
+    ro.library()
+    import hostlib
+    hostlib.host_library()                              # libro_host.so + the harness: linked against the same SONAME
+    assert len(ro.hip_runtimes()) == 1, ro.hip_runtimes()
+    ro.require_one_hip_runtime()

@@ -53,7 +53,11 @@ def test_c3_carrier_60db_per_bin(ro, oracle, torch_cuda):
         torch_cuda.cuda.synchronize()
     f = per_bin(d_rows.cpu().numpy(), want)
     print("float32 mode, same input: per-bin rel err max %.3g, frac > 1e-5: %.4f" % (f.max(), (f > PER_BIN).mean()))
-    assert (f > PER_BIN).mean() < 0.2                        # ... while its rel-to-row-max error is 1e-7 (test_gpu_stft)
+    # ... while its rel-to-row-max error is 1e-7 (test_gpu_stft).  What the float32 mode does per bin on this input is
+    # pinned, not just printed: measured 2.5 % of the bins over 1e-5 and a worst bin at 9.1e-4 (the weakest bins of a row
+    # whose carrier is 60 dB above them); bench.py's `parity` carries the same two numbers next to the norm-wise one.
+    assert (f > PER_BIN).mean() <= 0.03
+    assert f.max() <= 2e-3
 
 
 @pytest.mark.parametrize("bins,overlap", [(256, 128), (512, 0), (1024, 512), (2048, 1536), (4096, 2048),
