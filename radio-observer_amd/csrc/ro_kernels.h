@@ -101,6 +101,14 @@ hipError_t launch_f64_pass(int radix, bool first, bool last, int fmt, const BigA
 // two consecutive passes (radix 16 with a.ns, then radix r2) in one kernel through LDS; n >= 4096
 hipError_t launch_f64_pair(int r2, bool first, bool last, int fmt, const BigArgsD &a, hipStream_t s);
 
+// all four passes of a row in one persistent launch, the intermediate in one XCD's L2 (ro_f64fused.hip):
+// bins = 16 x 16 x 16 x r2.  ring = 8 x ring_rows x n complex doubles, ctl = f64_fused_ctl_bytes() bytes (zeroed by the
+// launch); a.in / a.out / a.ns are not used.  ctl word [1] != 0 after the launch: a bounded wait gave up.
+bool       f64_fused_supported(int bins);
+size_t     f64_fused_ctl_bytes();
+int        f64_fused_max_ring_rows();
+hipError_t launch_f64_fused(int fmt, const BigArgsD &a, double2 *ring, unsigned *ctl, int ring_rows, int wgs_per_cu, hipStream_t s);
+
 // ---- large transforms as a four-step FFT (bins = n1 x 1024), ro_fourstep.hip
 struct FourArgs {
     const void   *iq;          // sample 0 of the stream

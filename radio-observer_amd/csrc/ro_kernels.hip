@@ -15,6 +15,7 @@
 #include "ro_kernels.h"
 #include "ro_fft_device.h"
 #include "ro_device_util.h"
+#include "ro_f64_device.h"
 
 #include <cstdlib>
 #include <mutex>
@@ -939,49 +940,6 @@ template <int R, int FMT> __global__ __launch_bounds__(256) void fold_kernel(Fol
 // rows agree with the oracle's FP64 radix-2 transform to a few 1e-16 of the row maximum, i.e. per bin to ~1e-12 at
 // 60 dB of dynamic range -- the per-bin reading of "1e-5 relative" that fp32 butterflies cannot meet.
 // ---------------------------------------------------------------------------
-typedef double v2d __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ v2d cmul_d(v2d a, v2d w) { return (v2d){a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
-
-// exp(-2 pi i M / 16) for M = 0..7 (the rest by symmetry inside dif_d)
-template <int M> __device__ __forceinline__ v2d mul_w16_d(v2d d)
-{
-    constexpr double C1 = 0.92387953251128675613, C2 = 0.70710678118654752440, C3 = 0.38268343236508977173;
-    if constexpr (M == 0) return d;
-    else if constexpr (M == 4) return (v2d){d.y, -d.x};                       // * (-i)
-    else {
-        constexpr double c = (M == 1) ? C1 : (M == 2) ? C2 : (M == 3) ? C3 : (M == 5) ? -C3 : (M == 6) ? -C2 : -C1;
-        constexpr double sn = (M == 1) ? C3 : (M == 2) ? C2 : (M == 3) ? C1 : (M == 5) ? C1 : (M == 6) ? C2 : C3;
-        return (v2d){d.x * c + d.y * sn, d.y * c - d.x * sn};                 // d * (c - i sn)
-    }
-}
-
-// in-place decimation-in-frequency DFT of R points (R in {2,4,8,16}); result k sits at v[bitrev_R(k)]
-template <int R> __device__ __forceinline__ void dif_d(v2d *v)
-{
-    if constexpr (R >= 2) {
-#pragma unroll
-        for (int i = 0; i < R / 2; ++i) {
-            const v2d a = v[i], b = v[i + R / 2];
-            v[i] = a + b;
-            const v2d d = a - b;
-            // twiddle W_R^i = W_16^(i * 16 / R)
-            switch (i * (16 / R)) {
-            case 0: v[i + R / 2] = d; break;
-            case 1: v[i + R / 2] = mul_w16_d<1>(d); break;
-            case 2: v[i + R / 2] = mul_w16_d<2>(d); break;
-            case 3: v[i + R / 2] = mul_w16_d<3>(d); break;
-            case 4: v[i + R / 2] = mul_w16_d<4>(d); break;
-            case 5: v[i + R / 2] = mul_w16_d<5>(d); break;
-            case 6: v[i + R / 2] = mul_w16_d<6>(d); break;
-            default: v[i + R / 2] = mul_w16_d<7>(d); break;
-            }
-        }
-        dif_d<R / 2>(v);
-        dif_d<R / 2>(v + R / 2);
-    }
-}
-
 template <int R, bool FIRST, bool LAST, int FMT>
 __global__ __launch_bounds__(256) void f64_pass_kernel(BigArgsD a)
 {
@@ -1035,104 +993,20 @@ __global__ __launch_bounds__(256) void f64_pass_kernel(BigArgsD a)
         }
     }
 }
-// Two passes of the recurrence in one kernel: pass p (radix 16, sub-length ns) and pass p+1 (radix R2, sub-length 16 ns)
-// share a tile of 16 R2 points -- the R2 butterflies j = (b + k' N/(16 R2 ns)) ns + c of pass p produce exactly the
-// inputs of the 16 butterflies j' = 16 b ns + s ns + c of pass p+1 (s < 16), for every (b, c) -- so a workgroup takes
-// 4096 / (16 R2) neighbouring tiles, runs pass p, transposes through 64 KiB of LDS and runs pass p+1: one trip through
-// HBM (16 B per point each way) instead of two.  Same butterflies, same table entries, same order as f64_pass_kernel
-// twice: bit-identical results.
+// Two passes of the recurrence in one kernel (f64_pair_tile, ro_f64_device.h): one trip through HBM (16 B per point
+// each way) instead of two.  Same butterflies, same table entries, same order as f64_pass_kernel twice: bit-identical
+// results.
 template <int R2, bool FIRST, bool LAST, int FMT>
 __global__ __launch_bounds__(256) void f64_pair_kernel(BigArgsD a)
 {
-    constexpr int R1 = 16, TPW = 4096 / (R1 * R2), NB2 = 16 / R2;     // tiles per workgroup; pass-(p+1) butterflies per thread
+    constexpr int TPW = 4096 / (16 * R2);
     extern __shared__ __attribute__((aligned(16))) char smem_d[];
     double2 *lds = reinterpret_cast<double2 *>(smem_d);               // [slot s][k'][tile]: 16 x R2 x TPW
-    const int t = threadIdx.x;
-    const int tiles_per_row = a.n / (R1 * R2);
+    const int tiles_per_row = a.n / (16 * R2);
     const int64_t wg = blockIdx.x;
     const int64_t row = wg / (tiles_per_row / TPW);
     const int tile0 = (int)(wg - row * (tiles_per_row / TPW)) * TPW;
-    const int ns = a.ns;
-    {
-        // ---- pass p: thread = butterfly k' of tile tile0 + (t % TPW)
-        const int tl = t % TPW, kp = t / TPW;
-        const int tile = tile0 + tl, b = tile / ns, c = tile - b * ns;
-        const int j = (b + kp * (a.n / (R1 * R2 * ns))) * ns + c;
-        const int per_row = a.n / R1;
-        v2d v[R1];
-        if constexpr (FIRST) {
-            using S = Sample<FMT>;
-            const int64_t s0 = (a.first_row + row) * (int64_t)a.hop;
-            const __amdgpu_buffer_rsrc_t rs =
-                make_rsrc(reinterpret_cast<const char *>(a.iq) + s0 * S::BYTES, (unsigned)a.n * S::BYTES);
-#pragma unroll
-            for (int k = 0; k < R1; ++k) {
-                const int n = j + k * per_row;
-                const double w = (double)a.window[n];
-                const v2f x = S::load(rs, n * S::BYTES, 0);
-                v[k] = (v2d){(double)x.x * w, ((double)x.y + a.gain) * w};       // src/FFTBackend.cpp:78-79, :229-232
-            }
-        } else {
-            const double2 *in = a.in + row * (int64_t)a.n;
-            const int kk = j & (ns - 1);
-            const int step = a.n / (ns * R1);
-#pragma unroll
-            for (int k = 0; k < R1; ++k) {
-                const double2 x = in[j + k * per_row];
-                v[k] = (v2d){x.x, x.y};
-                if (k > 0) {
-                    const double2 w = a.tw[(int64_t)k * kk * step];
-                    v[k] = cmul_d(v[k], (v2d){w.x, w.y});
-                }
-            }
-        }
-        dif_d<R1>(v);
-#pragma unroll
-        for (int k = 0; k < R1; ++k) {
-            const v2d x = v[bitrev<R1>(k)];
-            lds[(k * R2 + kp) * TPW + tl] = make_double2(x.x, x.y);
-        }
-    }
-    __syncthreads();
-    // ---- pass p+1: butterfly u = (s, tile): reads slot s of the tile's R2 pass-p butterflies
-    const int ns2 = ns * R1;
-    const int step2 = a.n / (ns2 * R2);
-#pragma unroll
-    for (int i = 0; i < NB2; ++i) {
-        const int u = t + 256 * i, tl = u % TPW, sl = u / TPW;
-        const int tile = tile0 + tl, b = tile / ns, c = tile - b * ns;
-        const int kk = sl * ns + c;                                   // j' mod (16 ns),  j' = 16 b ns + kk
-        v2d v[R2];
-#pragma unroll
-        for (int k = 0; k < R2; ++k) {
-            const double2 x = lds[(sl * R2 + k) * TPW + tl];
-            v[k] = (v2d){x.x, x.y};
-            if (k > 0) {
-                const double2 w = a.tw[(int64_t)k * kk * step2];
-                v[k] = cmul_d(v[k], (v2d){w.x, w.y});
-            }
-        }
-        dif_d<R2>(v);
-        const int j0 = b * ns2 * R2 + kk;
-        if constexpr (LAST) {
-            float *out = a.rows_out + row * a.row_stride;
-#pragma unroll
-            for (int k = 0; k < R2; ++k) {
-                const v2d x = v[bitrev<R2>(k)];
-                // (the rows are write-once: nt, like every other kernel's row stores -- 4 % on this path; the scratch
-                // between the two kernels stays on the default policy, nt there loses the Infinity Cache: -7 ... -20 %)
-                __builtin_nontemporal_store((float)sqrt(x.x * x.x + x.y * x.y),
-                                            &out[(j0 + k * ns2 + a.n / 2) & (a.n - 1)]);       // WaterfallBackend.cpp:492-505
-            }
-        } else {
-            double2 *out = a.out + row * (int64_t)a.n;
-#pragma unroll
-            for (int k = 0; k < R2; ++k) {
-                const v2d x = v[bitrev<R2>(k)];
-                out[j0 + k * ns2] = make_double2(x.x, x.y);
-            }
-        }
-    }
+    f64_pair_tile<R2, FIRST, LAST, FMT, false>(a, lds, row, tile0, a.in + row * (int64_t)a.n, a.out + row * (int64_t)a.n);
 }
 
 

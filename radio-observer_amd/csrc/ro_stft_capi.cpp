@@ -52,6 +52,17 @@
 #ifndef RO_F64_SCRATCH_MB
 #define RO_F64_SCRATCH_MB 128
 #endif
+// RO_PRECISION_F64 at 8192 ... 65536 bins: the one-launch form (ro_f64fused.hip) with a ring of this many rows of
+// 32768 bins per XCD (scaled so that the ring's bytes stay the same at the other sizes) and this many workgroups per CU
+#ifndef RO_F64_FUSED
+#define RO_F64_FUSED 1
+#endif
+#ifndef RO_F64_RING_ROWS
+#define RO_F64_RING_ROWS 6
+#endif
+#ifndef RO_F64_WGS_PER_CU
+#define RO_F64_WGS_PER_CU 2
+#endif
 
 namespace {
 
@@ -270,6 +281,12 @@ struct ro_stft {
     double2 *d_tw_f64 = nullptr;
     double2 *d_scratch_d[2] = {nullptr, nullptr};
     int64_t  scratch_rows_d = 0;
+    // ... or, for bins = 16^3 r2, all four passes in one launch with the intermediate in an XCD's L2 (ro_f64fused.hip):
+    // 8 rings of f64_ring_rows rows, the launch's control block, and its give-up word mirrored into pinned host memory
+    double2  *d_f64_ring = nullptr;
+    unsigned *d_f64_ctl = nullptr;
+    unsigned *h_f64_err = nullptr;
+    int       f64_ring_rows = 0, f64_wgs_per_cu = 0;
 };
 
 namespace {
@@ -516,10 +533,60 @@ int launch_transform_czt(ro_stft *h, const void *d_iq, int format, int64_t first
     return RO_OK;
 }
 
+// RO_PRECISION_F64 at bins = 16^3 r2 (8192 ... 65536): one persistent launch, the complex-double intermediate of a row
+// in the L2 of the XCD that makes it (ro_f64fused.hip).  The launch's give-up word travels to pinned host memory behind
+// the kernel; a launch that gave up is reported by the NEXT call on the handle (and by ro_stft_destroy's caller never:
+// tests and bench compare rows).
+int launch_transform_f64_fused(ro_stft *h, const void *d_iq, int format, int64_t first_row, int64_t rows, float *d_rows,
+                               int64_t row_stride, hipStream_t s)
+{
+    if (h->h_f64_err && *h->h_f64_err != 0) {
+        const unsigned code = *h->h_f64_err;
+        *h->h_f64_err = 0;
+        return fail(RO_ERR_HIP, "the previous RO_PRECISION_F64 launch gave up waiting for another workgroup (code %u: 1 = row "
+                                "map, 2 = ring slot still being read, 3 = row's first half not complete); its rows are incomplete", code);
+    }
+    if (!h->d_f64_ring) {
+        int ring = RO_F64_RING_ROWS * 32768 / h->bins, wgs = RO_F64_WGS_PER_CU;
+#ifdef RO_DIAG_KNOBS
+        if (const char *e = getenv("RO_F64_RING_ROWS")) ring = atoi(e);
+        if (const char *e = getenv("RO_F64_WGS")) wgs = atoi(e);
+#endif
+        h->f64_ring_rows = std::max(2, std::min(ring, ro::f64_fused_max_ring_rows()));
+        h->f64_wgs_per_cu = std::max(1, std::min(wgs, 2));
+        HIP_TRY(hipMalloc(&h->d_f64_ring, (size_t)8 * h->f64_ring_rows * h->bins * sizeof(double2)));
+        HIP_TRY(hipMalloc(&h->d_f64_ctl, ro::f64_fused_ctl_bytes()));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->h_f64_err), sizeof(unsigned), hipHostMallocDefault));
+        *h->h_f64_err = 0;
+    }
+    ro::BigArgsD b{};
+    b.iq = d_iq;
+    b.window = h->d_window;
+    b.tw = h->d_tw_f64;
+    b.first_row = first_row;
+    b.rows = rows;
+    b.row_stride = row_stride;
+    b.hop = h->hop;
+    b.n = h->bins;
+    b.gain = h->cfg.iq_gain;
+    b.rows_out = d_rows;
+    HIP_TRY(ro::launch_f64_fused(format, b, h->d_f64_ring, h->d_f64_ctl, h->f64_ring_rows, h->f64_wgs_per_cu, s));
+    HIP_TRY(hipMemcpyAsync(h->h_f64_err, h->d_f64_ctl + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    return RO_OK;
+}
+
 // RO_PRECISION_F64: every size as radix-16 passes in double through HBM scratch, in chunks that fit it
 int launch_transform_f64(ro_stft *h, const void *d_iq, int format, int64_t first_row, int64_t rows, float *d_rows,
                          int64_t row_stride, hipStream_t s)
 {
+    {
+        bool fused = RO_F64_FUSED != 0;
+#ifdef RO_DIAG_KNOBS
+        if (const char *e = getenv("RO_F64_FUSED")) fused = atoi(e) != 0;
+#endif
+        if (fused && ro::f64_fused_supported(h->bins))
+            return launch_transform_f64_fused(h, d_iq, format, first_row, rows, d_rows, row_stride, s);
+    }
     if (!h->d_scratch_d[0]) {
         int64_t mib = RO_F64_SCRATCH_MB;
 #ifdef RO_DIAG
@@ -1450,6 +1517,9 @@ extern "C" int ro_stft_destroy(ro_stft_t *h)
     if (h->d_ln_part) (void)hipFree(h->d_ln_part);
     for (int i = 0; i < 2; ++i)
         if (h->d_scratch_d[i]) (void)hipFree(h->d_scratch_d[i]);
+    if (h->d_f64_ring) (void)hipFree(h->d_f64_ring);
+    if (h->d_f64_ctl) (void)hipFree(h->d_f64_ctl);
+    if (h->h_f64_err) (void)hipHostFree(h->h_f64_err);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);

@@ -108,3 +108,55 @@ def test_scan_records_and_tile_in_strict_mode(ro, oracle, torch_cuda):
                                bands.avg_bins)
     rec = recs.cpu().numpy().view(ro.capi.SCAN_DTYPE).reshape(-1)
     assert np.array_equal(rec["peak"], p) and np.array_equal(rec["noise"], n) and np.array_equal(rec["average"], a)
+
+
+def test_one_launch_form_many_rows_and_any_split(ro, oracle, torch_cuda):
+    """bins = 16^3 r2 run all four passes in ONE persistent launch, a row's complex-double intermediate handed from the
+    workgroups of its first two passes to those of its last two through the L2 of the XCD they share
+    (csrc/ro_f64fused.hip).  Enough rows that every workgroup draws many tickets and every ring slot is reused dozens of
+    times: every bin of every row against the oracle (any stale or torn hand-off is a wrong bin), and the same bits
+    whatever the launch's row range (rows are handed out dynamically: row r must not depend on who made it)."""
+    torch = torch_cuda
+    bins, overlap, R = 32768, 24576, 1500
+    hop = bins - overlap
+    rng = np.random.default_rng(0xF64)
+    iq = add_tone(noise_iq(rng, bins + (R - 1) * hop), 10600.0, 30.0)
+    got = strict_rows(ro, torch, iq, bins, overlap)
+    want = oracle.stft(iq, bins, overlap)
+    assert per_bin(got, want).max() <= 2e-7
+    d_iq = torch.from_numpy(iq).cuda()
+    with ro.Stft(bins=bins, overlap=overlap, precision=ro.RO_PRECISION_F64) as st:
+        s = torch.cuda.current_stream().cuda_stream
+        for first, n in ((0, 1), (1, 7), (8, 700), (708, R - 708)):
+            part = torch.full((n, bins), float("nan"), dtype=torch.float32, device="cuda")
+            st.run_resident(d_iq, ro.RO_IQ_F32, iq.shape[0], first, n, part, stream=s)
+            torch.cuda.synchronize()
+            assert np.array_equal(part.cpu().numpy(), got[first:first + n])
+
+
+def test_one_launch_form_beside_another_kernel(ro, oracle, torch_cuda):
+    """The hand-offs must not depend on all workgroups being resident or evenly placed: the same launch while the
+    float32 transform of another handle keeps the CUs busy on a second stream (workgroups of the FP64 launch start
+    late and unevenly over the XCDs), three sizes; every bin against the oracle."""
+    torch = torch_cuda
+    rng = np.random.default_rng(77)
+    busy_bins, busy_rows = 32768, 4096
+    busy_iq = torch.from_numpy(noise_iq(rng, busy_bins + 8192 * (busy_rows - 1))).cuda()
+    busy_out = torch.empty((busy_rows, busy_bins), dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    with ro.Stft(bins=busy_bins, overlap=24576) as busy:
+        for bins, overlap, R in ((32768, 24576, 600), (8192, 4096, 900), (65536, 49152, 200)):
+            hop = bins - overlap
+            iq = add_tone(noise_iq(rng, bins + (R - 1) * hop), 7000.0, 300.0)
+            d_iq = torch.from_numpy(iq).cuda()
+            out = torch.full((R, bins), float("nan"), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            with ro.Stft(bins=bins, overlap=overlap, precision=ro.RO_PRECISION_F64) as st:
+                for _ in range(3):
+                    busy.run_resident(busy_iq, ro.RO_IQ_F32, busy_iq.shape[0], 0, busy_rows, busy_out, stream=side.cuda_stream)
+                st.run_resident(d_iq, ro.RO_IQ_F32, iq.shape[0], 0, R, out, stream=torch.cuda.current_stream().cuda_stream)
+                for _ in range(2):
+                    busy.run_resident(busy_iq, ro.RO_IQ_F32, busy_iq.shape[0], 0, busy_rows, busy_out, stream=side.cuda_stream)
+                torch.cuda.synchronize()
+            want = oracle.stft(iq, bins, overlap)
+            assert per_bin(out.cpu().numpy(), want).max() <= 2e-7, bins
