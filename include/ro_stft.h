@@ -52,8 +52,13 @@ enum { RO_IQ_F32 = 0, RO_IQ_I16 = 1, RO_IQ_F64 = 2 };
  *  F64: the reference's own arithmetic type -- double window multiply, double transform, double sqrt, one
  *       narrowing to the float row (src/FFTBackend.cpp:117-120,229-236, src/WaterfallBackend.cpp:492-505) -- as a
  *       multi-pass transform through HBM scratch.  Rows within 1e-5 of the reference PER BIN (measured ~1e-12 at
- *       60 dB of dynamic range); several times slower.  Complex-spectra output is F32 only. */
-enum { RO_PRECISION_F32 = 0, RO_PRECISION_F64 = 1 };
+ *       60 dB of dynamic range); several times slower.  Complex-spectra output is F32 only.
+ *  F64_ONE_LAUNCH: F64's arithmetic and bits with all four passes of a row in ONE persistent launch, the
+ *       complex-double intermediate handed between workgroups of one XCD through that XCD's L2 (8192 ... 65536
+ *       bins; other sizes run as F64).  Measured SLOWER than F64's two launches (profiles/r05_f64_one_launch.txt:
+ *       the L2 keeps the hand-off only while at most two rows per XCD are in flight); kept selectable for that
+ *       record and its tests, never a default. */
+enum { RO_PRECISION_F32 = 0, RO_PRECISION_F64 = 1, RO_PRECISION_F64_ONE_LAUNCH = 2 };
 
 /* bin ranges of BolidRecorder::start (src/BolidRecorder.cpp:84-102), in
  * fft-shifted row columns. */

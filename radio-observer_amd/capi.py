@@ -13,7 +13,7 @@ from . import build as _build
 
 RO_WINDOW_NUTTALL, RO_WINDOW_HANN, RO_WINDOW_CUSTOM = 0, 1, 2
 RO_IQ_F32, RO_IQ_I16, RO_IQ_F64 = 0, 1, 2
-RO_PRECISION_F32, RO_PRECISION_F64 = 0, 1
+RO_PRECISION_F32, RO_PRECISION_F64, RO_PRECISION_F64_ONE_LAUNCH = 0, 1, 2
 
 RO_OK = 0
 _ERR_NAMES = {-1: "RO_ERR_INVALID", -2: "RO_ERR_UNSUPPORTED", -3: "RO_ERR_HIP", -4: "RO_ERR_NOMEM",

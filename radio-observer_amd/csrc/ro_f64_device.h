@@ -10,6 +10,12 @@
 #include "ro_fft_device.h"
 #include "ro_device_util.h"
 
+// cache policy of the loads of an intermediate that OTHER workgroups of the same launch wrote (gfx950 aux bits: 1 = sc0,
+// 2 = nt, 16 = sc1); tools/r5/f64f_loads.sh measures them
+#ifndef RO_F64F_LOAD_AUX
+#define RO_F64F_LOAD_AUX 16
+#endif
+
 namespace ro {
 
 typedef double v2d __attribute__((ext_vector_type(2)));
@@ -97,7 +103,7 @@ __device__ __forceinline__ void f64_pair_tile(const BigArgsD &a, double2 *lds, i
 #pragma unroll
             for (int k = 0; k < R1; ++k) {
                 if constexpr (SC1IN) {
-                    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(ri, (j + k * per_row) * 16, 0, 16);     // sc1
+                    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(ri, (j + k * per_row) * 16, 0, RO_F64F_LOAD_AUX);
                     v[k] = (v2d){__hiloint2double((int)q.y, (int)q.x), __hiloint2double((int)q.w, (int)q.z)};
                 } else {
                     const double2 x = in_row[j + k * per_row];

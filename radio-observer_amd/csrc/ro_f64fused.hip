@@ -43,7 +43,18 @@ constexpr int THREADS = 256, TILE = 4096, LDS_BYTES = TILE * 16;
 // workgroup holds one ticket): 64 + 32 + 1 at the most, so an entry is never reused while somebody still polls it
 constexpr int MAPN = 256;
 constexpr unsigned NULLROW = 0xffffffffu;
-constexpr unsigned SPIN_LIMIT = 1u << 22;        // x ~0.6 us of s_sleep: ~2.5 s, then the launch gives up (ctl->error)
+#ifndef RO_F64F_SPIN_LIMIT
+#define RO_F64F_SPIN_LIMIT (1u << 22)
+#endif
+constexpr unsigned SPIN_LIMIT = RO_F64F_SPIN_LIMIT;   // x ~0.6 us of s_sleep: ~2.5 s, then the launch gives up (ctl->error)
+// tools/r5/f64f_debug.cpp only: thread 0 of every workgroup leaves a trace of where it is in 8 words behind the control block
+#ifdef RO_F64F_DEBUG
+#define F64F_DBG(i, v) dbg[i] = (v)
+#define F64F_T(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc[k] += now_ - t_last; t_last = now_; } while (0)
+#else
+#define F64F_DBG(i, v) ((void)0)
+#define F64F_T(k) ((void)0)
+#endif
 
 // control block (unsigned words; zeroed by hipMemsetAsync before every launch).  One 128-byte line per hot word.
 //   [0]                      next_row     launch-wide row counter
@@ -77,18 +88,34 @@ __global__ __launch_bounds__(THREADS) void f64_fused_kernel(BigArgsD a, double2 
     BigArgsD pa = a, pb = a;                                          // phase A: passes 0, 1 (ns = 1); phase B: passes 2, 3
     pa.ns = 1;
     pb.ns = 256;
+#ifdef RO_F64F_DEBUG
+    unsigned *dbg = ctl + XCD0 + 8 * XCD_WORDS + blockIdx.x * 16;
+    unsigned drawn = 0;
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) dbg[0] = xcc + 100;
+#endif
 
-    for (;;) {
+    // no launch hands out more tickets on one XCD than it has tiles (two groups of null rows behind the last one at most)
+    const unsigned ticket_cap = (unsigned)min((int64_t)0xfffffff0ll, (a.rows + 4) * 2 * (int64_t)tpr);
+    bool running = true;
+    while (running) {
         // ---- draw a ticket, learn its row, wait for what it depends on: thread 0; the others wait at the barrier
         if (threadIdx.x == 0) {
+            F64F_DBG(3, 1u);
             const unsigned tk = __hip_atomic_fetch_add(xc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned g = tk / (unsigned)tpr, tile = tk - g * (unsigned)tpr;
             const bool phase_a = g == 0 || (g & 1u);
             const unsigned j = g == 0 ? 0u : phase_a ? (g + 1) / 2 : g / 2 - 1;
+            F64F_T(0);                                               // ticket atomic
+            F64F_DBG(1, ++drawn);
+            F64F_DBG(2, tk);
+            F64F_DBG(3, 2u);
             unsigned long long *mp = reinterpret_cast<unsigned long long *>(xc + 160) + (j % MAPN);
             unsigned row = NULLROW;
             bool go = true;
-            if (phase_a && tile == 0) {
+            if (tk >= ticket_cap) {
+                go = false;                                          // (cannot happen; never poll for such a ticket)
+            } else if (phase_a && tile == 0) {
                 const unsigned r = __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 row = (int64_t)r < a.rows ? r : NULLROW;
                 __hip_atomic_store(mp, ((unsigned long long)(j + 1) << 32) | (unsigned long long)(row + 1u), __ATOMIC_RELAXED,
@@ -108,10 +135,14 @@ __global__ __launch_bounds__(THREADS) void f64_fused_kernel(BigArgsD a, double2 
                 }
                 row = (unsigned)m - 1u;
             }
+            F64F_T(1);                                               // row map (leader: row counter atomic + publish)
             if (go && row != NULLROW) {
                 const unsigned slot = j % (unsigned)ring_rows, gen = j / (unsigned)ring_rows;
                 const unsigned *cnt = xc + 32 + 2 * slot + (phase_a ? 1 : 0);      // A waits on b_cnt, B on a_cnt
                 const unsigned want = (unsigned)tpr * (phase_a ? gen : gen + 1);
+                F64F_DBG(3, 3u);
+                F64F_DBG(5, want);
+                F64F_DBG(6, (unsigned)(cnt - ctl));
                 for (unsigned spins = 0; ld_relaxed(cnt) < want; ++spins) {
                     if (spins >= SPIN_LIMIT || ld_relaxed(err) != 0) {
                         unsigned zero = 0;
@@ -123,36 +154,51 @@ __global__ __launch_bounds__(THREADS) void f64_fused_kernel(BigArgsD a, double2 
                     __builtin_amdgcn_s_sleep(20);
                 }
             }
+            F64F_T(2);                                               // dependency wait
+            F64F_DBG(3, go ? 4u : 6u);
+            F64F_DBG(4, row);
             s_ctrl[0] = tk;
             s_ctrl[1] = row;
             s_ctrl[2] = go ? 1u : 0u;
         }
         __syncthreads();
-        const unsigned tk = s_ctrl[0], row = s_ctrl[1], go = s_ctrl[2];
+        // (wave-uniform by construction; said so, the branches below are scalar)
+        const unsigned tk = __builtin_amdgcn_readfirstlane(s_ctrl[0]), row = __builtin_amdgcn_readfirstlane(s_ctrl[1]),
+                       go = __builtin_amdgcn_readfirstlane(s_ctrl[2]);
         const unsigned g = tk / (unsigned)tpr, tile = tk - g * (unsigned)tpr;
         const bool phase_a = g == 0 || (g & 1u);
         const unsigned j = g == 0 ? 0u : phase_a ? (g + 1) / 2 : g / 2 - 1;
-        if (!go) break;                                              // a wait gave up (ctl->error says which)
-        if (row == NULLROW) {
+        // what this ticket asks for: 0 = leave (a wait gave up, or a B tile past the last row: this XCD is done; or the
+        // ticket is beyond anything a launch of this size hands out), 1 = nothing (an A tile past the last row), 2 = a tile
+        const int action = (!go || tk >= ticket_cap) ? 0 : row == NULLROW ? (phase_a ? 1 : 0) : 2;
+        if (action == 2) {
+            const unsigned slot = j % (unsigned)ring_rows;
+            double2 *srow = xring + (size_t)slot * (size_t)a.n;
             if (phase_a) {
-                __syncthreads();                                     // (s_ctrl is rewritten by the next draw)
-                continue;
+                f64_pair_tile<16, true, false, FMT, false>(pa, lds, (int64_t)row, (int)tile * (TILE / 256), nullptr, srow);
+                // the tile is in this XCD's L2 once every wave's stores have been acknowledged
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+#if defined(RO_F64F_INV) && RO_F64F_INV
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // buffer_inv sc1: this CU's L1 forgets what it holds
+#endif
+                f64_pair_tile<R2, false, true, RO_FMT_F32, true>(pb, lds, (int64_t)row, (int)tile * (TILE / (16 * R2)), srow, nullptr);
             }
-            break;                                                   // a B tile past the last row: this XCD is done
         }
-        const unsigned slot = j % (unsigned)ring_rows;
-        double2 *srow = xring + (size_t)slot * (size_t)a.n;
-        if (phase_a) {
-            f64_pair_tile<16, true, false, FMT, false>(pa, lds, (int64_t)row, (int)tile * (TILE / 256), nullptr, srow);
-            // the tile is in this XCD's L2 once every wave's stores have been acknowledged
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            f64_pair_tile<R2, false, true, RO_FMT_F32, true>(pb, lds, (int64_t)row, (int)tile * (TILE / (16 * R2)), srow, nullptr);
-        }
-        __syncthreads();                                             // all waves: stores drained / slot read, LDS free
-        if (threadIdx.x == 0)
+        __syncthreads();                     // every path: stores drained / slot read, LDS and s_ctrl free for the next draw
+        if (threadIdx.x == 0) { F64F_T(action == 2 ? (phase_a ? 3 : 4) : 5); }
+        if (action == 2 && threadIdx.x == 0) {
+            const unsigned slot = j % (unsigned)ring_rows;
             __hip_atomic_fetch_add(xc + 32 + 2 * slot + (phase_a ? 0 : 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        running = action != 0;
     }
+#ifdef RO_F64F_DEBUG
+    if (threadIdx.x == 0) {
+        dbg[3] = 5u;
+        for (int k = 0; k < 6; ++k) dbg[8 + k] = (unsigned)(acc[k] >> 6);      // units of 64 cycles
+    }
+#endif
 }
 
 struct DevicePlan {
@@ -200,7 +246,14 @@ template <int R2, int FMT> static hipError_t launch_t(const BigArgsD &a, double2
 
 // the sizes whose four passes are (16, 16 | 16, r2): two pair tiles per row and phase-A tiles of whole 256-point blocks
 bool f64_fused_supported(int bins) { return bins == 8192 || bins == 16384 || bins == 32768 || bins == 65536; }
-size_t f64_fused_ctl_bytes() { return (size_t)(f64f::XCD0 + 8 * f64f::XCD_WORDS) * sizeof(unsigned); }
+size_t f64_fused_ctl_bytes()
+{
+    size_t words = (size_t)(f64f::XCD0 + 8 * f64f::XCD_WORDS);
+#ifdef RO_F64F_DEBUG
+    words += 16 * 1024;                              // 16 words per workgroup, up to 1024 workgroups
+#endif
+    return words * sizeof(unsigned);
+}
 int f64_fused_max_ring_rows() { return f64f::RING_MAX; }
 
 // a.in / a.out / a.ns are ignored; ring = 8 x ring_rows x n complex doubles, ctl = f64_fused_ctl_bytes() of device memory

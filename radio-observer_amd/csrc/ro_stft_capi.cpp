@@ -52,16 +52,14 @@
 #ifndef RO_F64_SCRATCH_MB
 #define RO_F64_SCRATCH_MB 128
 #endif
-// RO_PRECISION_F64 at 8192 ... 65536 bins: the one-launch form (ro_f64fused.hip) with a ring of this many rows of
-// 32768 bins per XCD (scaled so that the ring's bytes stay the same at the other sizes) and this many workgroups per CU
-#ifndef RO_F64_FUSED
-#define RO_F64_FUSED 1
-#endif
+// RO_PRECISION_F64_ONE_LAUNCH (ro_f64fused.hip): a ring of this many rows of 32768 bins per XCD (scaled so that the
+// ring's bytes stay the same at the other sizes), this many workgroups per CU.  4 rows is the least that keeps an XCD's
+// 32 workgroups busy, and all its L2 serves (profiles/r05_f64_one_launch.txt)
 #ifndef RO_F64_RING_ROWS
-#define RO_F64_RING_ROWS 6
+#define RO_F64_RING_ROWS 4
 #endif
 #ifndef RO_F64_WGS_PER_CU
-#define RO_F64_WGS_PER_CU 2
+#define RO_F64_WGS_PER_CU 1
 #endif
 
 namespace {
@@ -287,6 +285,7 @@ struct ro_stft {
     unsigned *d_f64_ctl = nullptr;
     unsigned *h_f64_err = nullptr;
     int       f64_ring_rows = 0, f64_wgs_per_cu = 0;
+    bool      f64_one_launch = false;
 };
 
 namespace {
@@ -580,12 +579,11 @@ int launch_transform_f64(ro_stft *h, const void *d_iq, int format, int64_t first
                          int64_t row_stride, hipStream_t s)
 {
     {
-        bool fused = RO_F64_FUSED != 0;
+        bool fused = h->f64_one_launch;
 #ifdef RO_DIAG_KNOBS
-        if (const char *e = getenv("RO_F64_FUSED")) fused = atoi(e) != 0;
+        if (const char *e = getenv("RO_F64_FUSED")) fused = atoi(e) != 0 && ro::f64_fused_supported(h->bins);
 #endif
-        if (fused && ro::f64_fused_supported(h->bins))
-            return launch_transform_f64_fused(h, d_iq, format, first_row, rows, d_rows, row_stride, s);
+        if (fused) return launch_transform_f64_fused(h, d_iq, format, first_row, rows, d_rows, row_stride, s);
     }
     if (!h->d_scratch_d[0]) {
         int64_t mib = RO_F64_SCRATCH_MB;
@@ -1212,14 +1210,14 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
     std::memcpy(&cfg_full, cfg_in, cfg_in->struct_size);
     cfg_full.struct_size = sizeof(ro_stft_config_t);
     cfg = &cfg_full;
-    if (cfg->precision != RO_PRECISION_F32 && cfg->precision != RO_PRECISION_F64)
+    if (cfg->precision != RO_PRECISION_F32 && cfg->precision != RO_PRECISION_F64 && cfg->precision != RO_PRECISION_F64_ONE_LAUNCH)
         return fail(RO_ERR_INVALID, "unknown precision %d", cfg->precision);
     if (cfg->tile_ln != 0 && cfg->tile_ln != 1) return fail(RO_ERR_INVALID, "tile_ln must be 0 or 1");
     if (cfg->tile_ln && cfg->tile_cols <= 0) return fail(RO_ERR_INVALID, "tile_ln needs a tile (tile_cols > 0)");
     if (!ro_bins_supported(cfg->bins))
         return fail(RO_ERR_UNSUPPORTED, "bins = %d has no kernel (powers of two 256..1048576, other even lengths "
                                         "258..524286)", cfg->bins);
-    if (czt_length(cfg->bins) && cfg->precision == RO_PRECISION_F64)
+    if (czt_length(cfg->bins) && cfg->precision != RO_PRECISION_F32)
         return fail(RO_ERR_UNSUPPORTED, "RO_PRECISION_F64 is available for power-of-two bins only");
     if (cfg->iq_phase_shift != 0)
         return fail(RO_ERR_UNSUPPORTED, "iq_phase_shift != 0 is undefined behaviour in the reference "
@@ -1281,7 +1279,8 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
     else
         build_window(cfg->window_kind, h->bins, h->window.data());
     h->big = ro::big_supported(h->bins);
-    h->f64 = cfg->precision == RO_PRECISION_F64;
+    h->f64 = cfg->precision != RO_PRECISION_F32;
+    h->f64_one_launch = cfg->precision == RO_PRECISION_F64_ONE_LAUNCH && ro::f64_fused_supported(cfg->bins);
     h->czt_m = czt_length(h->bins);
     h->czt = h->czt_m > 0;
     if (h->big && !h->f64) {

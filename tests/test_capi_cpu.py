@@ -78,7 +78,8 @@ def test_config_is_validated_before_any_device_work(ro):
     """Argument errors come back as RO_ERR_INVALID / RO_ERR_UNSUPPORTED with or without a GPU."""
     for kw, code in ((dict(bins=1001), -2), (dict(bins=1000, precision=1), -2), (dict(bins=1024, iq_phase_shift=1), -2),
                      (dict(bins=1024, sample_rate=0), -1), (dict(bins=1024, spare_cus_per_xcd=17), -1),
-                     (dict(bins=1024, spare_cus_per_xcd=-1), -1), (dict(bins=1024, precision=2), -1)):
+                     (dict(bins=1024, spare_cus_per_xcd=-1), -1), (dict(bins=1024, precision=3), -1),
+                     (dict(bins=1000, precision=2), -2)):
         with pytest.raises(ro.StftError) as e:
             ro.Stft(**kw)
         assert e.value.code == code, (kw, str(e.value))

@@ -204,9 +204,9 @@ def test_row_sink_receives_the_rows_in_ring_order(ro, oracle, bins, overlap, bat
         assert "row sink full" in str(e.value) and "nothing was consumed" in str(e.value)
         assert st.stats()["samples_in"] == before and st.fetch_records(10 * slots)[1] == 0
         ring[:] = np.nan
-        seen, cut = 0, bins + (batch - 1) * hop + 7
-        for piece in (big[:cut], big[cut:]):
-            st.push(piece)
+        seen, step = 0, batch * hop + 7                   # pieces that complete a batch or so: always room after a fetch
+        for at in range(0, len(big), step):
+            st.push(big[at:at + step])
             while True:
                 first, got, _ = st.fetch_records(10 * slots)
                 if got == 0:

@@ -16,12 +16,13 @@ pytestmark = pytest.mark.gpu
 PER_BIN = 1e-5
 
 
-def strict_rows(ro, torch, iq, bins, overlap, fmt=None, **kw):
+def strict_rows(ro, torch, iq, bins, overlap, fmt=None, precision=None, **kw):
     fmt = ro.RO_IQ_F32 if fmt is None else fmt
+    precision = ro.RO_PRECISION_F64 if precision is None else precision
     d_iq = torch.from_numpy(np.ascontiguousarray(iq)).cuda()
     rows = ro.row_count(iq.shape[0], bins, overlap)
     d_rows = torch.full((rows, bins), float("nan"), dtype=torch.float32, device="cuda")
-    with ro.Stft(bins=bins, overlap=overlap, precision=ro.RO_PRECISION_F64, **kw) as st:
+    with ro.Stft(bins=bins, overlap=overlap, precision=precision, **kw) as st:
         st.run_resident(d_iq, fmt, iq.shape[0], 0, rows, d_rows, stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
     return d_rows.cpu().numpy()
@@ -111,7 +112,7 @@ def test_scan_records_and_tile_in_strict_mode(ro, oracle, torch_cuda):
 
 
 def test_one_launch_form_many_rows_and_any_split(ro, oracle, torch_cuda):
-    """bins = 16^3 r2 run all four passes in ONE persistent launch, a row's complex-double intermediate handed from the
+    """RO_PRECISION_F64_ONE_LAUNCH: bins = 16^3 r2 run all four passes in ONE persistent launch, a row's complex-double intermediate handed from the
     workgroups of its first two passes to those of its last two through the L2 of the XCD they share
     (csrc/ro_f64fused.hip).  Enough rows that every workgroup draws many tickets and every ring slot is reused dozens of
     times: every bin of every row against the oracle (any stale or torn hand-off is a wrong bin), and the same bits
@@ -121,11 +122,12 @@ def test_one_launch_form_many_rows_and_any_split(ro, oracle, torch_cuda):
     hop = bins - overlap
     rng = np.random.default_rng(0xF64)
     iq = add_tone(noise_iq(rng, bins + (R - 1) * hop), 10600.0, 30.0)
-    got = strict_rows(ro, torch, iq, bins, overlap)
+    got = strict_rows(ro, torch, iq, bins, overlap, precision=ro.RO_PRECISION_F64_ONE_LAUNCH)
     want = oracle.stft(iq, bins, overlap)
     assert per_bin(got, want).max() <= 2e-7
+    assert np.array_equal(got, strict_rows(ro, torch, iq, bins, overlap))          # the two-launch form: the same bits
     d_iq = torch.from_numpy(iq).cuda()
-    with ro.Stft(bins=bins, overlap=overlap, precision=ro.RO_PRECISION_F64) as st:
+    with ro.Stft(bins=bins, overlap=overlap, precision=ro.RO_PRECISION_F64_ONE_LAUNCH) as st:
         s = torch.cuda.current_stream().cuda_stream
         for first, n in ((0, 1), (1, 7), (8, 700), (708, R - 708)):
             part = torch.full((n, bins), float("nan"), dtype=torch.float32, device="cuda")
@@ -151,7 +153,7 @@ def test_one_launch_form_beside_another_kernel(ro, oracle, torch_cuda):
             d_iq = torch.from_numpy(iq).cuda()
             out = torch.full((R, bins), float("nan"), dtype=torch.float32, device="cuda")
             torch.cuda.synchronize()
-            with ro.Stft(bins=bins, overlap=overlap, precision=ro.RO_PRECISION_F64) as st:
+            with ro.Stft(bins=bins, overlap=overlap, precision=ro.RO_PRECISION_F64_ONE_LAUNCH) as st:
                 for _ in range(3):
                     busy.run_resident(busy_iq, ro.RO_IQ_F32, busy_iq.shape[0], 0, busy_rows, busy_out, stream=side.cuda_stream)
                 st.run_resident(d_iq, ro.RO_IQ_F32, iq.shape[0], 0, R, out, stream=torch.cuda.current_stream().cuda_stream)

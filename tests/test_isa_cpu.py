@@ -13,7 +13,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SOURCES = [os.path.join(ROOT, "radio-observer_amd", "csrc", f) for f in ("ro_kernels.hip", "ro_stft32k.hip", "ro_fourstep.hip")]
+SOURCES = [os.path.join(ROOT, "radio-observer_amd", "csrc", f) for f in ("ro_kernels.hip", "ro_stft32k.hip", "ro_fourstep.hip", "ro_f64fused.hip")]
 
 
 def compile_isa(dirname, sources, extra=()):
