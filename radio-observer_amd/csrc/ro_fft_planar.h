@@ -33,7 +33,15 @@ template <int MB> __host__ __device__ constexpr int hf(int p) { return (p >> MB)
 __device__ __forceinline__ void leash() { __builtin_amdgcn_sched_barrier(0x4 | 0x10 | 0x80); }
 
 // ---- joint: (A, B) <- (A + e B, A - e B), e = w (MI = false) or -i w = (w.y, -w.x) (MI = true), both halves alike
-template <bool MI> __device__ __forceinline__ void bf_joint(v2f &AR, v2f &AI, v2f &BR, v2f &BI, v2f w)
+// RO_PLANAR_ABLATE (a -DRO_DIAG=1 build only, tools/r5/radix4_bound.sh): the joint butterflies of levels 0 and 1 of
+// every head() leave out their last packed FMA -- 16 per stage, what an FMA radix-4 butterfly (22 instead of 24 real
+// FMAs per four points) would save on those two pairs of levels.  The rows are wrong; only the time is of interest.
+#if defined(RO_DIAG) && defined(RO_PLANAR_ABLATE)
+#define RO_PLANAR_DROP(L, n) ((L) < 2)
+#else
+#define RO_PLANAR_DROP(L, n) false
+#endif
+template <bool MI, bool DROP = false> __device__ __forceinline__ void bf_joint(v2f &AR, v2f &AI, v2f &BR, v2f &BI, v2f w)
 {
     // (the six operations in THIS order, a leash behind each: two dependent packed operations back to back cost an
     // s_nop on gfx950 -- hipcc's hazard recognizer pads it -- and left alone the scheduler pairs them up)
@@ -50,7 +58,8 @@ template <bool MI> __device__ __forceinline__ void bf_joint(v2f &AR, v2f &AI, v2
         si = __builtin_elementwise_fma(BR, -w.xx, ui); leash();
     }
     BR = __builtin_elementwise_fma(AR, (v2f){2.0f, 2.0f}, -sr); leash();
-    BI = __builtin_elementwise_fma(AI, (v2f){2.0f, 2.0f}, -si);
+    if constexpr (!DROP) BI = __builtin_elementwise_fma(AI, (v2f){2.0f, 2.0f}, -si);
+    else BI = AI;
     AR = sr;
     AI = si;
 }
@@ -116,7 +125,7 @@ template <int MB, int L, int n> __device__ __forceinline__ void bf_at(v2f (&R)[1
         constexpr int Em = block_exp<L>(pm / S);
         if constexpr (MB < PB) {
             static_assert(Em == E, "mates in one block");
-            bf_joint<(E >= 8)>(R[pr<MB>(pa)], I[pr<MB>(pa)], R[pr<MB>(pb)], I[pr<MB>(pb)], tw[E & 7]);
+            bf_joint<(E >= 8), RO_PLANAR_DROP(L, n)>(R[pr<MB>(pa)], I[pr<MB>(pa)], R[pr<MB>(pb)], I[pr<MB>(pb)], tw[E & 7]);
         } else {
             static_assert(Em == E + 8 && E < 8, "mates in neighbouring blocks: a factor -i");
             bf_mixed(R[pr<MB>(pa)], I[pr<MB>(pa)], R[pr<MB>(pb)], I[pr<MB>(pb)], tw[E]);
