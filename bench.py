@@ -70,6 +70,11 @@ def parse():
     p.add_argument("--comm", choices=["nccl", "gloo-host"], default="nccl",
                    help="gloo-host: rehearsal mode for 1-GPU boxes -- every rank uses cuda:0 and the gather is "
                         "staged through host memory over gloo (exercises the N>1 control flow, not xGMI)")
+    p.add_argument("--pattern", choices=["nccl", "direct"], default="nccl",
+                   help="how --gather all moves the rows: one ncclAllGather (whatever algorithm RCCL picks) or the DIRECT "
+                        "exchange SURVEY 8(e) prescribes for xGMI's point-to-point links -- every rank sends its block to each "
+                        "peer and receives each peer's block at its stitched place, one group of sends / receives "
+                        "(ro_allgather_rows_direct with --exchange capi); a run with N > 1 reports both legs")
     p.add_argument("--gather", choices=["all", "root", "none"], default="all",
                    help="N > 1: what ends a step inside the timed region of `value`.  all (default) = the RCCL all-gather "
                         "of band tile + scan records north_star and BASELINE's config 5 name (every rank stitches); root = "
@@ -283,14 +288,30 @@ def large_leg(torch, ro, dev, local_rank, parity, bins, overlap, rows, cite, ker
                               "achieved": alg * rows / (step_ms * 1e-3) / 1e9,
                               "frac": alg * rows / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "kernel": kernels, "algorithmic_bytes_per_row": alg, "traffic": traffic}}
+        if isinstance(traffic, str) and traffic.endswith(".json"):
+            # bytes per launch by FETCH_SIZE / WRITE_SIZE from a committed rocprofv3 --pmc record of this shape, scaled to
+            # this launch's rows (counters cannot be read from inside the run)
+            try:
+                with open(os.path.join(ROOT, "profiles", traffic)) as fh:
+                    rec = json.load(fh)
+                per_row = rec["traffic_bytes_per_launch"] / (rec["algorithmic_bytes_per_launch"] / alg)
+                entry["roofline"]["traffic"] = per_row * rows
+                entry["roofline"]["traffic_over_algorithmic"] = per_row / alg
+                entry["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; L2 hit rate %s)" % (
+                    traffic, "%.3f" % rec["tcc_hit_rate"] if rec.get("tcc_hit_rate") is not None else "n/a")
+            except Exception as e:
+                entry["roofline"]["traffic"] = None
+                entry["roofline"]["traffic_source"] = "profiles/%s unreadable: %s" % (traffic, str(e)[:80])
         if parity:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import ro_oracle as O
-            seg = iq[(rows - 1) * hop:(rows - 1) * hop + bins].cpu().numpy()
-            want = O.stft(seg, bins, overlap, w=st.window)[0]
-            got = out_rows[rows - 1].cpu().numpy()
-            entry["parity"] = {"rows_checked": [rows - 1], "tolerance": 1e-5,
-                               "max_err_rel_to_row_max": float(np.abs(got.astype(np.float64) - want).max() / want.max())}
+            worst, picks = 0.0, [0, rows // 2, rows - 1]
+            for r in picks:
+                seg = iq[r * hop:r * hop + bins].cpu().numpy()
+                want = O.stft(seg, bins, overlap, w=st.window)[0]
+                got = out_rows[r].cpu().numpy()
+                worst = max(worst, float(np.abs(got.astype(np.float64) - want).max() / want.max()))
+            entry["parity"] = {"rows_checked": picks, "tolerance": 1e-5, "max_err_rel_to_row_max": worst}
     del iq, out_rows, recs
     torch.cuda.empty_cache()
     return entry
@@ -570,7 +591,9 @@ def main():
             rccl = RcclComm(dist, world, rank)
             stage = [torch.empty((R_max, max(tcols, 3)), dtype=torch.float32, device=dev) for _ in range(2)]
 
-    mode = {"now": a.gather if exchanging else "none", "note": None}
+    # how a step ends: "all" = ncclAllGather, "direct" = the all-gather as grouped point-to-point transfers, "root" = gather
+    # to rank 0, "none" = compute only
+    mode = {"now": ("direct" if a.gather == "all" and a.pattern == "direct" else a.gather) if exchanging else "none", "note": None}
 
     def exchange(out, inp, cols, b, which):
         """one buffer (band tile or records) of this step: all-gather, or gather to rank 0.  `out` = world x R_max rows
@@ -581,11 +604,21 @@ def main():
                 rc = L.ro_allgather_rows(rccl.comm, ctypes.c_void_p(inp.data_ptr()), R, R_total, world, rank, cols * 4,
                                          ctypes.c_void_p(stage[which].data_ptr()), ctypes.c_void_p(out.data_ptr()),
                                          ctypes.c_void_p(cptr))
+            elif mode["now"] == "direct":
+                rc = L.ro_allgather_rows_direct(rccl.comm, ctypes.c_void_p(inp.data_ptr()), R, R_total, world, rank, cols * 4,
+                                                ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(cptr))
             else:
                 rc = L.ro_gather_rows(rccl.comm, ctypes.c_void_p(inp.data_ptr()), R, R_total, world, rank, 0, cols * 4,
                                       ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(cptr))
             if rc != 0:
                 raise RuntimeError("C-ABI exchange failed: %s" % L.ro_last_error())
+            return
+        if mode["now"] == "direct":
+            # the same schedule as ro_allgather_rows_direct, through torch.distributed's point-to-point operations
+            if a.comm == "nccl":
+                sh.gather_rows_direct(inp[:R], R_total, out=out[:R_total])
+            else:                                               # rehearsal: through host memory
+                out[:R_total].copy_(sh.gather_rows_direct(inp[:R].cpu(), R_total))
             return
         send = sh.pad_block(inp, R_total, world) if c5 else inp
         if a.comm == "nccl":
@@ -656,7 +689,7 @@ def main():
         return ok > 0.5
 
     # the way a step ends is chosen ONCE, before anything is timed, and by all ranks together
-    if exchanging and mode["now"] == "root" and not usable("root"):
+    if exchanging and mode["now"] in ("root", "direct") and not usable(mode["now"]):
         mode["now"] = "all"
         mode["note"] = (mode["note"] or "") + ": all-gather instead"
     sampler = ClockPowerSampler(torch, local_rank) if rank == 0 else None
@@ -709,8 +742,8 @@ def main():
         import hashlib
         last = (a.steps - 1) & 1
         if exchanging and mode["now"] != "none":
-            if a.exchange == "capi" and mode["now"] == "root":
-                t_all, r_all = g_tiles[last][:R_total], g_recs[last][:R_total]
+            if (a.exchange == "capi" and mode["now"] == "root") or mode["now"] == "direct":
+                t_all, r_all = g_tiles[last][:R_total], g_recs[last][:R_total]          # rows already in place
             else:
                 t_all, r_all = sh.stitch(g_tiles[last], R_total, world), sh.stitch(g_recs[last], R_total, world)
         else:
@@ -727,7 +760,7 @@ def main():
     if world > 1 and a.gather != "none" and not a.no_legs:
         main_mode = mode["now"]
         legs = {main_mode: R_total * a.steps / dt}
-        for m in ("all", "root", "none"):
+        for m in ("all", "direct", "root", "none"):
             if m in legs:
                 continue
             if m != "none" and not usable(m):
@@ -781,8 +814,9 @@ def main():
                        "input": "float32 I/Q resident in HBM", "output": "float32 rows in HBM",
                        "parallelism": "time-chunk per GPU" + (("; %s of band tile [%d,+%d) + scan records per step (%s), "
                                                                "overlapped with the next step"
-                                                               % (({"all": "all-gather", "root": "gather to rank 0"}[mode["now"]],)
-                                                                  + tile + ("C ABI: ro_allgather_rows / ro_gather_rows"
+                                                               % (({"all": "all-gather (ncclAllGather)", "direct": "all-gather as direct point-to-point transfers",
+                                                                    "root": "gather to rank 0"}[mode["now"]],)
+                                                                  + tile + ("C ABI: ro_allgather_rows / ro_allgather_rows_direct / ro_gather_rows"
                                                                             if a.exchange == "capi" else
                                                                             "torch.distributed",)))
                                                               if exchanging and mode["now"] != "none" else
@@ -814,6 +848,13 @@ def main():
             "gpu_ms_per_step_events": gpu_ms_per_step, "step_ms_back_to_back": float(np.mean(ms_all)),
             "step_ms_median": float(np.median(ms_all)), "step_ms_min": float(np.min(ms_all)),
         }
+
+        # the steady state under the package's power cap: the same launches for --soak-seconds behind the timed region (the
+        # driver's 20-step region ends before the package has reached its cap; this is what a long job runs at)
+        if clock_power and isinstance(clock_power.get("soak"), dict):
+            soak_ms = clock_power["soak"]["ms_per_step"]
+            out["roofline"]["frac_at_power_cap"] = ALG_BYTES_PER_ROW * R / (soak_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["roofline"]["ms_per_step_at_power_cap"] = soak_ms
 
         # ---- device copy bandwidth for context (float32 copy of the row buffer)
         c = torch.empty_like(rows)
@@ -859,21 +900,22 @@ def main():
 
         # ---- the strict-precision mode next to the headline (never the headline): same input, fewer rows
         if world == 1 and not a.no_strict:
-            r64 = min(R, 2048)
+            r64 = R                                           # the headline's rows per step
             with ro.Stft(bins=BINS, overlap=OVERLAP, sample_rate=FS, device=local_rank, bands=bands,
                          window=ro.RO_WINDOW_HANN if a.window == "hann" else ro.RO_WINDOW_NUTTALL,
                          precision=ro.RO_PRECISION_F64) as st64:
-                ms64, k64, s64 = st64.time_resident(iq, ro.RO_IQ_F32, samples, 0, r64, rows, 5, d_records=recs[1],
+                n64 = max(a.steps, 20) + 2
+                ms64, k64, s64 = st64.time_resident(iq, ro.RO_IQ_F32, samples, 0, r64, rows, n64, d_records=recs[1],
                                                     stream=sptr)
                 torch.cuda.synchronize(dev)
-                ms_strict = float(np.mean(ms64[1:]))
+                ms_strict = float(np.mean(ms64[2:]))          # (the first two launches allocate and warm the scratch)
                 # traffic model of the two-trip form at bins = 32768: trip 1 reads the row's samples
                 # (8 B per point, overlap re-reads from L2) and writes complex doubles (16 B); trip 2 reads them
                 # (16 B) and writes the float row (4 B): 44 B per point against 6 B algorithmic
                 model = 44.0 * BINS
                 entry = {"mode": "RO_PRECISION_F64 (double window multiply, double transform in two trips through HBM "
                                  "scratch, double sqrt, one narrowing: the reference's arithmetic type)",
-                         "value": r64 / (ms_strict * 1e-3), "unit": "rows/s", "rows_per_step": r64,
+                         "value": r64 / (ms_strict * 1e-3), "unit": "rows/s", "rows_per_step": r64, "steps": n64 - 2,
                          "ms_per_step": ms_strict, "dtype": "f64",
                          "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                                       "achieved": ALG_BYTES_PER_ROW * r64 / (ms_strict * 1e-3) / 1e9,
@@ -882,7 +924,10 @@ def main():
                                       "traffic_model_bytes_per_row": model,
                                       "traffic_model_GBs": model * r64 / (ms_strict * 1e-3) / 1e9,
                                       "traffic_model_frac_of_peak": model * r64 / (ms_strict * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                      "traffic": None}}
+                                      # FETCH_SIZE x 1.994 + WRITE_SIZE of this mode's kernels, per point x points of a step
+                                      # (profiles/r05_f64_one_launch.txt section 2: 38.7 B per point)
+                                      "traffic": 38.70 * BINS * r64 if BINS == 32768 else None,
+                                      "traffic_source": "profiles/r05_f64_one_launch.txt (rocprofv3 --pmc passes, two-launch form)"}}
                 if not a.no_parity:
                     sys.path.insert(0, os.path.join(ROOT, "oracle"))
                     import ro_oracle as O
@@ -903,7 +948,8 @@ def main():
                                        "four_cols_kernel + four_rows_kernel + scan_kernel (csrc/ro_fourstep.hip)",
                                        "13.5 MiB per row by FETCH_SIZE / WRITE_SIZE (profiles/r04_fourstep.txt)")
             out["bolidozor"] = large_leg(torch, ro, dev, local_rank, not a.no_parity, 65536, 49152, 8192, "Bolidozor.json:45-46",
-                                         "stft_kernel<Plan32768, ., 3> (two workgroups per stream row) + scan_kernel", None)
+                                         "stft_kernel<Plan32768, ., 3> (two workgroups per stream row) + scan_kernel",
+                                         "r05_traffic_65536.json")
 
         # ---- the drop-in path at full speed (never the headline): Frontend::process -> HipWaterfallBackend::process
         # with 4096-sample vector<Complex> calls (src/RawStream.cpp:44-66) -> kernels -> full rows back to the host row

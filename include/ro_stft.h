@@ -157,6 +157,14 @@ int     ro_stitch_rows(const void *gathered, int64_t total_rows, int world, size
  * Asynchronous on `stream` (copy into the staging block, then ncclAllGather as bytes). */
 int     ro_allgather_rows(void *nccl_comm, const void *d_local, int64_t local_rows, int64_t total_rows, int world,
                           int rank, size_t row_bytes, void *d_staging, void *d_gathered, void *stream);
+/* The all-gather as the DIRECT exchange SURVEY 5 / 8(e) asks for ("prefer a direct all-to-all-write pattern ... over a
+ * single ring": xGMI is point to point, seven links per GPU): inside one ncclGroupStart / ncclGroupEnd every rank
+ * ncclSend's its local_rows x row_bytes to each peer and ncclRecv's each peer's rows AT THEIR STITCHED PLACE in d_out
+ * (total_rows x row_bytes, device, on every rank) -- no zero-padded staging block, no stitch afterwards; the band the
+ * consumer writes (src/WaterfallBackend.cpp:174-205) is complete on every rank when the stream reaches this point.
+ * Asynchronous on `stream`. */
+int     ro_allgather_rows_direct(void *nccl_comm, const void *d_local, int64_t local_rows, int64_t total_rows, int world,
+                                 int rank, size_t row_bytes, void *d_out, void *stream);
 /* The same exchange when only ONE rank consumes the rows -- the reference's FITS writer and detector are one process
  * (src/WaterfallBackend.cpp:141-211, src/BolidRecorder.cpp:171-273): every rank sends its local_rows x row_bytes
  * straight to `root` (ncclSend / ncclRecv in one group: world - 1 transfers over world - 1 different links), where

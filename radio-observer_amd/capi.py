@@ -80,6 +80,8 @@ _EXPORTS = {
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "ro_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_size_t,
                                  C.c_void_p, C.c_void_p]),
+    "ro_allgather_rows_direct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_size_t,
+                                           C.c_void_p, C.c_void_p]),
     "ro_stitch_rows_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ro_stft_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
     "ro_stft_destroy": (C.c_int, [C.c_void_p]),

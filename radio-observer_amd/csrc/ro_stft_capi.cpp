@@ -1159,6 +1159,41 @@ extern "C" int ro_gather_rows(void *nccl_comm, const void *d_local, int64_t loca
     return RO_OK;
 }
 
+// the all-gather as a DIRECT exchange: inside one group every rank sends its block to each peer and receives each peer's
+// block at its stitched place -- world - 1 point-to-point transfers per rank over world - 1 different xGMI links, no
+// ring through one link, no padding, no stitch (what ro_gather_rows does for one root, for all)
+extern "C" int ro_allgather_rows_direct(void *nccl_comm, const void *d_local, int64_t local_rows, int64_t total_rows, int world,
+                                        int rank, size_t row_bytes, void *d_out, void *stream)
+{
+    if (!nccl_comm || world < 1 || rank < 0 || rank >= world || total_rows < 0 || row_bytes == 0 ||
+        (local_rows > 0 && !d_local) || (total_rows > 0 && !d_out))
+        return fail(RO_ERR_INVALID, "ro_allgather_rows_direct: bad arguments");
+    int64_t first = 0, mine = 0;
+    ro_shard_rows(total_rows, world, rank, &first, &mine);
+    if (local_rows != mine)
+        return fail(RO_ERR_INVALID, "ro_allgather_rows_direct: rank %d of %d owns %lld of %lld rows, not %lld", rank, world,
+                    (long long)mine, (long long)total_rows, (long long)local_rows);
+    const Rccl &rccl = rccl_api();
+    if (!rccl.group_start || !rccl.group_end || !rccl.send || !rccl.recv)
+        return fail(RO_ERR_UNSUPPORTED, "librccl (ncclSend / ncclRecv) not found on this host");
+    hipStream_t s = (hipStream_t)stream;
+    char *out = static_cast<char *>(d_out);
+    if (mine > 0)                            // this rank's own rows: a copy to their place
+        HIP_TRY(hipMemcpyAsync(out + (size_t)first * row_bytes, d_local, (size_t)mine * row_bytes, hipMemcpyDeviceToDevice, s));
+    int rc = rccl.group_start();
+    // peers in the order rank + 1, rank + 2, ...: at every step of the schedule each link pair is used once
+    for (int k = 1; k < world && rc == 0; ++k) {
+        const int to = (rank + k) % world, from = (rank - k + world) % world;
+        int64_t f = 0, n = 0;
+        ro_shard_rows(total_rows, world, from, &f, &n);
+        if (mine > 0) rc = rccl.send(d_local, (size_t)mine * row_bytes, /*ncclInt8*/ 0, to, nccl_comm, s);
+        if (rc == 0 && n > 0) rc = rccl.recv(out + (size_t)f * row_bytes, (size_t)n * row_bytes, 0, from, nccl_comm, s);
+    }
+    const int rc_end = rccl.group_end();
+    if (rc != 0 || rc_end != 0) return fail(RO_ERR_HIP, "ncclSend / ncclRecv failed with code %d", rc ? rc : rc_end);
+    return RO_OK;
+}
+
 extern "C" int ro_stitch_rows_device(const void *d_gathered, int64_t total_rows, int world, size_t row_bytes, void *d_out,
                                      void *stream)
 {
@@ -1271,6 +1306,23 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
         delete h;
         return fail(RO_ERR_UNSUPPORTED, "device %d offers %zu bytes of LDS per CU and %d CUs; the kernels need 135168 for one workgroup and 8",
                     cfg->device, lds, cus);
+    }
+
+    // ... and the persistent kernels hand rows out in eight runs, one per XCD (blockIdx % 8 under round-robin dispatch;
+    // ro_stft32k.hip, ro_kernels.hip, ro_fourstep.hip).  The device says how many XCDs it has: a partition mode with
+    // another number would still compute the same rows but lose the placement silently, so it is refused instead.  (A
+    // runtime that does not know the attribute is taken at its word that this is a whole MI355X.)
+    {
+        int xccs = 0;
+        if (hipDeviceGetAttribute(&xccs, hipDeviceAttributeNumberOfXccs, cfg->device) == hipSuccess) {
+            if (xccs != 8) {
+                delete h;
+                return fail(RO_ERR_UNSUPPORTED, "device %d reports %d XCDs; the kernels' row placement is laid out for 8 "
+                                                "(an MI355X in SPX mode)", cfg->device, xccs);
+            }
+        } else {
+            (void)hipGetLastError();
+        }
     }
 
     h->window.resize(h->bins);

@@ -87,3 +87,31 @@ def gather_rows(local, total_rows, group=None, async_op=False, root=None):
     if async_op:
         return finish, work
     return finish(), None
+
+
+def gather_rows_direct(local, total_rows, group=None, out=None):
+    """The all-gather as a DIRECT exchange (xGMI is point to point): every rank sends its rows to each peer
+    and receives each peer's rows at their stitched place -- the torch.distributed form of ro_allgather_rows_direct
+    (same schedule: to rank + k, from rank - k, k = 1 .. world - 1, one batch of point-to-point operations).  No
+    padding, no stitch.  Returns [total_rows, C] in row order (written into `out` when given)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    shards = all_shards(total_rows, world)
+    first, mine = shards[rank]
+    assert local.shape[0] == mine, (local.shape, shards[rank])
+    if out is None:
+        out = torch.empty((total_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    src = local.contiguous()
+    out[first:first + mine].copy_(src)
+    ops = []
+    for k in range(1, world):
+        to, frm = (rank + k) % world, (rank - k) % world
+        f, n = shards[frm]
+        if mine > 0:
+            ops.append(dist.P2POp(dist.isend, src, to, group))
+        if n > 0:
+            ops.append(dist.P2POp(dist.irecv, out[f:f + n], frm, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return out

@@ -66,11 +66,11 @@ def test_bench_line_has_the_contract_fields(ro, torch_cuda):
     assert "cpu_baseline_O0" in d and "error" not in d["cpu_baseline_O0"]
 
 
-@pytest.mark.parametrize("exchange", ["torch", "capi"])
-def test_bench_c5_hash_is_the_hash_of_the_stream(ro, torch_cuda, exchange):
+@pytest.mark.parametrize("exchange,pattern", [("torch", "nccl"), ("capi", "nccl"), ("capi", "direct")])
+def test_bench_c5_hash_is_the_hash_of_the_stream(ro, torch_cuda, exchange, pattern):
     torch = torch_cuda
     seconds = 900.0
-    d = run_bench(["--workload", "c5", "--c5-seconds", str(seconds), "--exchange", exchange, "--steps", "2", "--warmup", "1",
+    d = run_bench(["--workload", "c5", "--c5-seconds", str(seconds), "--exchange", exchange, "--pattern", pattern, "--steps", "2", "--warmup", "1",
                    "--prewarm", "1", "--no-cpu-baseline", "--no-strict", "--no-parity", "--no-streaming"])
     assert d["scaling"] == "strong"
     got = d["config"]["c5_hash_of_stitched_band_and_records"]

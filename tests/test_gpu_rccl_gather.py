@@ -49,6 +49,15 @@ def test_allgather_rows_on_a_single_rank_communicator(ro, torch_cuda):
         assert rc == 0, L.ro_last_error()
         torch.cuda.synchronize()
         assert torch.equal(out2, local)
+        # the all-gather as direct point-to-point transfers (one group of sends / receives): rows land stitched on every rank
+        out3 = torch.zeros((rows, cols), device="cuda", dtype=torch.float32)
+        rc = L.ro_allgather_rows_direct(comm, C.c_void_p(local.data_ptr()), rows, rows, 1, 0, cols * 4,
+                                        C.c_void_p(out3.data_ptr()), C.c_void_p(s))
+        assert rc == 0, L.ro_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(out3, local)
+        assert L.ro_allgather_rows_direct(comm, C.c_void_p(local.data_ptr()), rows - 1, rows, 1, 0, cols * 4,
+                                          C.c_void_p(out3.data_ptr()), C.c_void_p(s)) == -1
         assert L.ro_gather_rows(comm, C.c_void_p(local.data_ptr()), rows, rows, 1, 0, 1, cols * 4,
                                 C.c_void_p(out2.data_ptr()), C.c_void_p(s)) == -1          # root outside the world
         # a row count that is not this rank's share is refused before anything is queued

@@ -63,6 +63,9 @@ def _worker(rank, world, port, total_rows, out_dir):
         recs[:, 2] = a
         tile = torch.from_numpy(np.ascontiguousarray(local[:, TILE[0]:TILE[0] + TILE[1]]))
         g_tile, _ = sh.gather_rows(tile, total_rows)
+        # the direct exchange (point-to-point transfers, rows landing stitched) must leave exactly the same band
+        assert torch.equal(sh.gather_rows_direct(tile, total_rows), g_tile)
+        assert torch.equal(sh.gather_rows_direct(torch.from_numpy(recs), total_rows), sh.gather_rows(torch.from_numpy(recs), total_rows)[0])
         stitch, work = sh.gather_rows(torch.from_numpy(recs), total_rows, async_op=True)
         work.wait()
         g_recs = stitch()
