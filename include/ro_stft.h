@@ -32,7 +32,7 @@ extern "C" {
 #define RO_ERR_NOMEM       (-4)
 #define RO_ERR_STATE       (-5)   /* call not valid in the handle's current state */
 
-#define RO_ABI_VERSION 3
+#define RO_ABI_VERSION 4
 
 /* window function; the reference hard-codes the 4-term Nuttall
  * (src/FFTBackend.cpp:165-184) and keeps Hann as dead code (:157-163). */
@@ -293,6 +293,13 @@ int ro_stft_flush(ro_stft_t *h, int64_t *rows_ready);
 int ro_stft_fetch(ro_stft_t *h, int64_t max_rows, int first_col, int cols,
                   float *rows_out, ro_scan_record_t *records_out,
                   int64_t *first_row_index, int64_t *rows_got);
+/* Rows at the head of the output queue whose batches have finished on the device, download included: ro_stft_fetch
+ * hands these over without waiting (it WAITS for anything beyond them).  A host that fetches only what is complete
+ * keeps the next batch in flight under the previous one's download and under its own per-row work -- the recorders
+ * then see a batch's rows one Backend::process call later than a blocking fetch would show them, never later than the
+ * next call or ro_stft_flush + fetch (src/WaterfallBackend.cpp:534-536 runs Recorder::update() inside processFFT;
+ * here it runs a batch behind by construction). */
+int ro_stft_rows_complete(ro_stft_t *h, int64_t *rows);
 /* Row sink: the streaming path's rows go STRAIGHT into the caller's row ring instead of the handle's pinned batches --
  * WaterfallBackend::processFFT writes each finished row into buffer_->push() (src/WaterfallBackend.cpp:488-505); with a
  * sink the device-to-host copy of a batch is that write, and the ring's only copy.  Row r of the stream (counted from

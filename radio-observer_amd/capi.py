@@ -112,6 +112,7 @@ _EXPORTS = {
     "ro_stft_fetch": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_float),
                                 C.POINTER(ScanRecord), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ro_stft_reset": (C.c_int, [C.c_void_p]),
+    "ro_stft_rows_complete": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ro_stft_set_row_sink": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]),
     "ro_pinned_alloc": (C.c_void_p, [C.c_int, C.c_size_t]),
     "ro_pinned_free": (None, [C.c_void_p]),
@@ -489,6 +490,12 @@ class Stft:
         t = Timing()
         _check(library().ro_stft_timing(self._h, C.byref(t), 1 if reset else 0))
         return {k: getattr(t, k) for k, _ in Timing._fields_}
+
+    def rows_complete(self):
+        """rows ro_stft_fetch would hand over without waiting (their batches have finished on the device)"""
+        n = C.c_int64()
+        _check(library().ro_stft_rows_complete(self._h, C.byref(n)))
+        return n.value
 
     def stats(self):
         s, r, l = C.c_int64(), C.c_int64(), C.c_int64()

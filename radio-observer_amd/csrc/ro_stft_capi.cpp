@@ -1942,6 +1942,25 @@ extern "C" int ro_stft_fetch(ro_stft_t *h, int64_t max_rows, int first_col, int 
     return RO_OK;
 }
 
+// rows at the head of the output queue whose batches have FINISHED (download included): what ro_stft_fetch hands over
+// without waiting.  A caller that fetches only these keeps the next batch's upload and kernels in flight under the
+// previous batch's download and under its own per-row work, instead of waiting out every batch it has just launched.
+extern "C" int ro_stft_rows_complete(ro_stft_t *h, int64_t *rows)
+{
+    if (!h || !rows) return fail(RO_ERR_INVALID, "null argument");
+    int64_t n = 0;
+    for (Batch *b : h->ready) {
+        if (b->pending) {
+            const hipError_t e = hipEventQuery(b->done);
+            if (e == hipErrorNotReady) break;
+            if (e != hipSuccess) return fail(RO_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
+        }
+        n += b->rows - b->consumed;
+    }
+    *rows = n;
+    return RO_OK;
+}
+
 extern "C" int ro_stft_fetch_ln(ro_stft_t *h, int64_t max_rows, float *tile_out, float *ln_out, float *minmax_out,
                                 ro_scan_record_t *records_out, int64_t *first_row_index, int64_t *rows_got)
 {

@@ -42,6 +42,7 @@ bool WaterfallBase::beginStream(const StreamInfo &info, ro_bands_t *bands)
     info_ = info;
     fftSampleRate_ = ro_fft_sample_rate(info.sampleRate, bins_, overlap_);     // FFTBackend.cpp:150-151
     rowsDelivered_ = 0;
+    rowsFetched_ = 0;
     rowLog_.clear();
     // src/WaterfallBackend.cpp:577-588
     int bufferSize = 1;
@@ -235,7 +236,14 @@ void HipWaterfallBackend::process(const std::vector<Complex> &data, DataInfo inf
             // over.  (Rows that complete without filling a batch are marked a batch early: conservative.)
             const int64_t upTo = samplesIn_ - (int64_t)data.size() + (int64_t)(at + n);
             const int64_t complete = upTo >= bins_ ? (upTo - bins_) / hop_ + 1 : 0;
-            const int64_t ahead = complete - rowsDelivered_;
+            int64_t ahead = complete - rowsDelivered_;
+            if (ahead > buffer_.getCapacity() / 2) {
+                // rows that are complete on the device but not handed over yet occupy the ring's free slots: before
+                // they and this piece could fill it (a push that would lap them is refused whole), everything in
+                // flight is waited for and handed over
+                drain(false, true);
+                ahead = complete - rowsDelivered_;
+            }
             if (ahead > 0) {
                 std::lock_guard<std::mutex> g(bufferMutex_);
                 buffer_.markAhead((int)std::min<int64_t>(ahead, buffer_.getCapacity()));
@@ -255,6 +263,8 @@ void HipWaterfallBackend::process(const std::vector<Complex> &data, DataInfo inf
             std::fprintf(stderr, "HipWaterfallBackend: %s\n", lastError_.c_str());
             return;
         }
+        // (rows that are complete but not yet handed over count against the sink's free slots: if this piece could be
+        // refused for it, everything in flight is handed over first -- see the check in front of the push)
         drain(false);
     }
 }
@@ -268,7 +278,7 @@ void HipWaterfallBackend::endStream()
 
 // Hand finished rows to the recorders in stream order.  `flush` runs the kernels on every
 // complete row still staged (end of stream, or a caller that wants minimum latency).
-void HipWaterfallBackend::drain(bool flush)
+void HipWaterfallBackend::drain(bool flush, bool wait)
 {
     int64_t ready = 0;
     if (flush && ro_stft_flush(stft_, &ready) != RO_OK) {
@@ -278,14 +288,37 @@ void HipWaterfallBackend::drain(bool flush)
     const int64_t CH = 64;
     if (!rowSink_) fetchRows_.resize((size_t)CH * bins_);
     fetchRecs_.resize((size_t)CH);
+    // Between two process() calls only what has FINISHED on the device is handed over: the batch this call has just
+    // launched stays in flight under the recorders' work and under the next call's staging (two batches overlap: one
+    // downloading, one uploading / transforming), and its rows reach the recorders with the next call.  At the end of
+    // the stream (flush) everything is waited for.
+    int64_t budget = -1;
+    if (!flush && !wait) {
+        if (ro_stft_rows_complete(stft_, &budget) != RO_OK) {
+            lastError_ = ro_last_error();
+            return;
+        }
+    }
     for (;;) {
         int64_t first = 0, got = 0;
-        if (ro_stft_fetch(stft_, CH, 0, bins_, rowSink_ ? nullptr : fetchRows_.data(), scanEnabled_ ? fetchRecs_.data() : nullptr,
+        if (budget == 0) {
+            // ... but never more than ONE batch stays launched-and-not-handed-over: the recorders look back `advance` rows
+            // into rings that are sized for a batch of lag plus a batch being staged (startStream), so a second
+            // outstanding batch is waited for.  (In real time the batch of a second ago finished long before this call.)
+            int64_t launched = 0;
+            if (ro_stft_stats(stft_, nullptr, &launched, nullptr, nullptr) != RO_OK) break;
+            if (launched - rowsFetched_ <= batchRows_) break;
+            budget = launched - rowsFetched_ - batchRows_;
+        }
+        const int64_t want = budget < 0 ? CH : std::min<int64_t>(CH, budget);
+        if (ro_stft_fetch(stft_, want, 0, bins_, rowSink_ ? nullptr : fetchRows_.data(), scanEnabled_ ? fetchRecs_.data() : nullptr,
                           &first, &got) != RO_OK) {
             lastError_ = ro_last_error();
             return;
         }
         if (got == 0) break;
+        if (budget > 0) budget -= got;
+        rowsFetched_ += got;
         for (int64_t i = 0; i < got; ++i) {
             const int64_t r = first + i;
             DataInfo di;

@@ -168,6 +168,7 @@ protected:
     std::vector<Recorder *>    recorders_;
     int     rawCapacity_ = 1;
     int64_t rowsDelivered_ = 0;
+    int64_t rowsFetched_ = 0;        // rows taken out of the handle's queue (== rowsDelivered_ between calls)
     ro_scan_record_t currentScan_{};
     std::vector<RowInfo> rowLog_;
     bool keepLog_ = false;
@@ -205,7 +206,7 @@ public:
     bool timing(ro_stft_timing_t *out, bool reset) const { return stft_ && ro_stft_timing(stft_, out, reset ? 1 : 0) == RO_OK; }
 
 private:
-    void drain(bool flush);
+    void drain(bool flush, bool wait = false);
     void stampRowStarts(int64_t takeBegin, int64_t takeEnd, const WFTime &t);
 
     ro_stft_t *stft_ = nullptr;

@@ -27,7 +27,7 @@ def test_header_symbols_are_exported(ro):
         assert hasattr(lib, n), "libro_stft.so does not export %s" % n
     # and the binding covers exactly the header
     assert sorted(ro.capi.exported_symbols()) == names
-    assert lib.ro_abi_version() == 3
+    assert lib.ro_abi_version() == 4
 
 
 def test_struct_layouts(ro):

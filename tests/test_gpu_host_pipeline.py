@@ -73,7 +73,10 @@ def test_default_batch_is_bounded_by_latency(oracle):
         fed = min(i + 4096, T)
         complete = (fed - bins) // hop + 1 if fed >= bins else 0
         worst = max(worst, complete - p.rows)
-    assert worst <= p.batch_rows(), (worst, p.batch_rows())      # never more than one batch behind
+    # never two batches behind: at most ONE batch is launched and not yet handed over (between two calls only rows that
+    # have finished on the device are fetched -- the launch overlaps the next calls -- and a second outstanding batch is
+    # waited for), plus what is being staged for the next launch
+    assert worst < 2 * p.batch_rows(), (worst, p.batch_rows())
     p.end()
     assert p.rows == (T - bins) // hop + 1 and p.error == ""
     p.close()
