@@ -33,7 +33,7 @@ with ro.Stft(bins=bins, overlap=overlap, precision=ro.RO_PRECISION_F64) as st:
     torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / steps
 h = hashlib.sha256(rows.cpu().numpy().tobytes()).hexdigest()[:16]
-knobs = " ".join("%s=%s" % (k, os.environ[k]) for k in ("RO_F64_FUSED", "RO_F64_RING_ROWS", "RO_F64_WGS", "RO_F64_SCRATCH_MB")
+knobs = " ".join("%s=%s" % (k, os.environ[k]) for k in ("RO_F64_FUSED", "RO_F64_STREAM", "RO_F64_RING_ROWS", "RO_F64_WGS", "RO_F64_SCRATCH_MB")
                  if k in os.environ)
 print("%-48s bins %d rows/step %d  %.4f ms/step  %.4g rows/s  frac %.4f  rows_hash %s"
       % (knobs or "defaults", bins, R, ms, R / (ms * 1e-3), (8 * (bins - overlap) + 4 * bins) * R / (ms * 1e-3) / 8e12, h), flush=True)
