@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-parity --no-streaming"      # the default run: 25 pre-warm + 30 warm-up + 50 timed steps
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.log
 echo "trace done"
-SHORT="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-streaming --no-strict"
+SHORT="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-streaming --no-strict --no-large"
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$N -- $SHORT > /dev/null 2> $OUT/pmc_$N.log || echo "pmc $C failed"
