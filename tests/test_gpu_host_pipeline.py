@@ -82,6 +82,35 @@ def test_default_batch_is_bounded_by_latency(oracle):
     p.close()
 
 
+def test_one_long_process_call_on_a_wrapped_ring(oracle):
+    """A file replayed in ONE Backend::process call (the whole stream at once) on a ring that wraps many times: the backend
+    hands the call over in pieces that stay inside the ring, rows land in the ring's slots by DMA ahead of the push() that
+    publishes them, and what is in flight is bounded -- every row arrives, in order, with the stamps of the chunked run,
+    and the ring ends holding the newest rows (the oracle's), not rows from a lap earlier or later."""
+    bins, overlap, hop = 4096, 3072, 1024
+    rng = np.random.default_rng(11)
+    R = 1500
+    T = bins + (R - 1) * hop + 17
+    iq = noise_iq(rng, T)
+    z = iq[:, 0].astype(np.float64) + 1j * iq[:, 1].astype(np.float64)
+    start = (1700000000, 0)
+    p = HostPipeline(bins, overlap, start=start, max_batch_rows=0, snapshot_length=1)
+    cap = p.ring_capacity()
+    assert R > 3 * cap, (R, cap)                                  # the ring wraps more than three times
+    o = oracle.Stream(bins, overlap, start=start, raw_capacity_rows=p.raw_capacity())
+    want_rows, want_info = o.process(z)                           # one call there too: the same time stamps
+    p.process(z)
+    p.end()
+    assert p.error == "" and p.rows == R == want_rows.shape[0]
+    assert p.ring_mark() == R % cap
+    keep = min(cap - 1, 64)
+    got = np.stack([p.ring_row(p.ring_mark() - keep + i) for i in range(keep)])
+    assert rel_to_row_max(got, want_rows[R - keep:]) <= 1e-5
+    for i in (0, 1, cap - 1, cap, 2 * cap + 3, R - 1):
+        assert p.row_info(i) == want_info[i], (i, p.row_info(i), want_info[i])
+    p.close()
+
+
 def test_bolid_detection_through_the_pipeline(oracle):
     """C4: chirps in noise through Frontend -> HipWaterfallBackend -> BolidRecorder; the events
     must equal the oracle's FSM driven by the oracle's FP64 rows."""
