@@ -319,7 +319,8 @@ int ro_stft_set_row_sink(ro_stft_t *h, float *base, int64_t row_stride, int64_t 
 /* page-locked host memory for such a ring (hipHostMalloc on `device`'s context); NULL when there is none to be had */
 void *ro_pinned_alloc(int device, size_t bytes);
 void  ro_pinned_free(void *p);
-/* 1 when [p, p + bytes) is host memory page-locked by this process's HIP runtime (what ro_stft_set_row_sink accepts:
+/* 1 when the first and the last byte of [p, p + bytes) are host memory page-locked by this process's HIP runtime and
+ * lie the same distance apart in its view (what ro_stft_set_row_sink accepts:
  * the target of the DMA that stands in for processFFT's write into buffer_->push(), src/WaterfallBackend.cpp:488-505),
  * 0 for anything else -- heap or stack memory, device memory, or no HIP device in the process. */
 int   ro_pinned_check(const void *p, size_t bytes);

@@ -166,6 +166,10 @@ void HipWaterfallBackend::startStream(StreamInfo info)
                              "raw captures of events will hold newer samples than their rows\n",
                      batchRows_, (long long)batchRows_ * hop_ + bins_, rawCapacity_);
     c.max_batch_rows = batchRows_;
+    // batches that may be in flight and not yet handed to the recorders (drain): two, if three batches of lag (two in
+    // flight, one being staged) are still a small part of both rings
+    maxOutstanding_ = (3 * (int64_t)batchRows_ <= buffer_.getCapacity() / 4 &&
+                       (!cfg_.keep_raw || 3 * (int64_t)batchRows_ * hop_ + bins_ <= rawCapacity_ / 2)) ? 2 : 1;
     c.enable_scan = scanEnabled_ ? 1 : 0;
     if (ro_stft_create(&c, &stft_) != RO_OK) {
         // the reference logs and carries on (LOG_ERROR + return); so does this: no rows will come
@@ -302,13 +306,15 @@ void HipWaterfallBackend::drain(bool flush, bool wait)
     for (;;) {
         int64_t first = 0, got = 0;
         if (budget == 0) {
-            // ... but never more than ONE batch stays launched-and-not-handed-over: the recorders look back `advance` rows
-            // into rings that are sized for a batch of lag plus a batch being staged (startStream), so a second
-            // outstanding batch is waited for.  (In real time the batch of a second ago finished long before this call.)
+            // ... but never more than maxOutstanding_ batches stay launched-and-not-handed-over (two where the rings are
+            // long against a batch -- every shipped config: a second of rows against eight snapshots -- one where they are
+            // not): the recorders look back `advance` rows into the row ring and the raw ring, which have to hold that lag
+            // plus the batch being staged (startStream).  What is beyond is waited for.  (In real time the batch of a
+            // second ago finished long before this call.)
             int64_t launched = 0;
             if (ro_stft_stats(stft_, nullptr, &launched, nullptr, nullptr) != RO_OK) break;
-            if (launched - rowsFetched_ <= batchRows_) break;
-            budget = launched - rowsFetched_ - batchRows_;
+            if (launched - rowsFetched_ <= (int64_t)maxOutstanding_ * batchRows_) break;
+            budget = launched - rowsFetched_ - (int64_t)maxOutstanding_ * batchRows_;
         }
         const int64_t want = budget < 0 ? CH : std::min<int64_t>(CH, budget);
         if (ro_stft_fetch(stft_, want, 0, bins_, rowSink_ ? nullptr : fetchRows_.data(), scanEnabled_ ? fetchRecs_.data() : nullptr,

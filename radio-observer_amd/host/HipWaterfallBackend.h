@@ -167,6 +167,7 @@ protected:
     std::vector<RawDataHandle> rawHandles_;
     std::vector<Recorder *>    recorders_;
     int     rawCapacity_ = 1;
+    int     maxOutstanding_ = 1;      // batches launched and not yet handed to the recorders (drain)
     int64_t rowsDelivered_ = 0;
     int64_t rowsFetched_ = 0;        // rows taken out of the handle's queue (== rowsDelivered_ between calls)
     ro_scan_record_t currentScan_{};
