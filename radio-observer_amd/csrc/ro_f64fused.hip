@@ -29,6 +29,12 @@
 //     reports through ctl->error.
 //
 // Same butterflies, same table entries, same order as f64_pair_kernel twice: bit-identical rows.
+//
+// MEASURED (round 5, profiles/r05_f64_one_launch.txt): correct under every placement tried, and SLOWER than the two
+// launches -- 2.30 against 2.97 x 10^6 rows/s at the C3 shape.  The hand-off does stay in the L2 while an XCD has at most
+// two rows in flight (16.3 B per point across the fabric instead of 38.7), but its 32 CUs hold four, and at that ring
+// only the read side is saved (28.4); this first version also spends ~18k cycles per tile where arithmetic is ~3.5k.
+// Selectable as RO_PRECISION_F64_ONE_LAUNCH; RO_PRECISION_F64 runs f64_pair_kernel.
 #include "ro_kernels.h"
 #include "ro_f64_device.h"
 

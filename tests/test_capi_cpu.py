@@ -122,6 +122,12 @@ def test_row_sink_entry_points_without_a_device(ro):
             ro.PinnedArray(4, 4)
 
 
+def test_rows_complete_wants_a_handle(ro):
+    import ctypes as C2
+    n = C2.c_int64(7)
+    assert ro.library().ro_stft_rows_complete(None, C2.byref(n)) == -1 and n.value == 7
+
+
 def test_pinned_check_refuses_heap_memory(ro):
     """ro_pinned_check is what ro_stft_set_row_sink asks before it lets a DMA near the caller's ring: heap memory, NULL
     and empty ranges are not page-locked memory of this process's HIP runtime (with no device nothing is)."""

@@ -241,3 +241,32 @@ def test_one_hip_runtime_in_the_test_process(ro, torch_cuda):
     hostlib.host_library()                              # libro_host.so + the harness: linked against the same SONAME
     assert len(ro.hip_runtimes()) == 1, ro.hip_runtimes()
     ro.require_one_hip_runtime()
+
+
+def test_rows_complete_counts_only_finished_batches(ro, oracle):
+    """ro_stft_rows_complete: the rows ro_stft_fetch hands over without waiting.  Nothing before a batch is launched;
+    after a flush and a wait, everything; and what it reports can be fetched at once and matches the oracle."""
+    bins, overlap, batch = 4096, 2048, 5
+    hop = bins - overlap
+    rng = np.random.default_rng(21)
+    R = 3 * batch + 2
+    iq = noise_iq(rng, bins + (R - 1) * hop)
+    want = oracle.stft(iq, bins, overlap)
+    with ro.Stft(bins=bins, overlap=overlap, max_batch_rows=batch) as st:
+        assert st.rows_complete() == 0
+        st.push(iq[:bins + (batch - 2) * hop])               # not a whole batch yet: nothing launched
+        assert st.rows_complete() == 0
+        st.push(iq[bins + (batch - 2) * hop:])
+        st.flush()
+        import time
+        for _ in range(2000):                                # the launches finish by themselves: poll, never fetch
+            if st.rows_complete() == R:
+                break
+            time.sleep(0.001)
+        assert st.rows_complete() == R
+        first, rows, _ = st.fetch(4)                         # a partial fetch leaves the rest reported
+        assert first == 0 and rows.shape[0] == 4 and st.rows_complete() == R - 4
+        first, rest, _ = st.fetch(1000)
+        assert first == 4 and rest.shape[0] == R - 4 and st.rows_complete() == 0
+        got = np.concatenate([rows, rest])
+    assert (np.abs(got.astype(np.float64) - want).max(axis=1) / want.max(axis=1)).max() <= 1e-5
