@@ -946,7 +946,7 @@ def main():
         if world == 1 and not a.no_large and not c5 and BINS == 32768:
             out["ionozor"] = large_leg(torch, ro, dev, local_rank, not a.no_parity, 524288, 262144, 1024, "Ionozor.json:27-28",
                                        "four_cols_kernel + four_rows_kernel + scan_kernel (csrc/ro_fourstep.hip)",
-                                       "13.5 MiB per row by FETCH_SIZE / WRITE_SIZE (profiles/r04_fourstep.txt)")
+                                       "r05_traffic_524288.json")
             out["bolidozor"] = large_leg(torch, ro, dev, local_rank, not a.no_parity, 65536, 49152, 8192, "Bolidozor.json:45-46",
                                          "stft_kernel<Plan32768, ., 3> (two workgroups per stream row) + scan_kernel",
                                          "r05_traffic_65536.json")
