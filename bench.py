@@ -737,6 +737,13 @@ def main():
         dt = max_over_ranks(dt)
 
     # ---- c5: what the job produced, stitched in row order on rank 0, hashed (N ranks == 1 rank, bit for bit)
+    # rank 0's own scan records of the last step: its input (seed 0xC3, or the first time chunk of the C5 stream) and
+    # therefore its records are the same whatever the number of ranks -- an N-rank run's line can be checked against the
+    # one-rank run's, bit for bit, without the C5 workload
+    rank0_hash = None
+    if rank == 0:
+        import hashlib
+        rank0_hash = hashlib.sha256(recs[(a.steps - 1) & 1].cpu().numpy().tobytes()).hexdigest()[:32]
     c5_hash = None
     if c5:
         import hashlib
@@ -823,6 +830,7 @@ def main():
                                                               ("; compute only (--gather none)" if exchanging else "")),
                        **({"gather_note": mode["note"]} if mode["note"] else {}),
                        **({"c5_hash_of_stitched_band_and_records": c5_hash} if c5_hash else {}),
+                       **({"rank0_scan_records_hash": rank0_hash} if rank0_hash and not c5 else {}),
                        **({"exchange_legs_rows_per_s": legs} if legs else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

@@ -61,6 +61,7 @@ def test_bench_line_has_the_contract_fields(ro, torch_cuda):
         assert "error" not in st, st
         assert st["rows"] > 0 and st["samples_per_call"] == 4096 and st["real_time_factor"] > 10
         assert st["value"] == pytest.approx(st["rows"] / st["seconds"])
+    assert len(d["config"]["rank0_scan_records_hash"]) == 32          # what an N-rank run's line is compared with
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
     assert "cpu_baseline_O0" in d and "error" not in d["cpu_baseline_O0"]
