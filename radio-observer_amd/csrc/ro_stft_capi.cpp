@@ -1963,6 +1963,8 @@ extern "C" int ro_stft_rows_complete(ro_stft_t *h, int64_t *rows)
             const hipError_t e = hipEventQuery(b->done);
             if (e == hipErrorNotReady) break;
             if (e != hipSuccess) return fail(RO_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
+            const int rc = await_batch(h, b);        // finished: book its kernel time once, never query it again
+            if (rc != RO_OK) return rc;
         }
         n += b->rows - b->consumed;
     }

@@ -1,3 +1,6 @@
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include "HipWaterfallBackend.h"
 
 #include <sys/time.h>
@@ -90,7 +93,16 @@ int WaterfallBase::pushRaw(const Complex *data, size_t n, RawSpan spans[2])
     int ns = 0;
     rawBuffer_.pushRun((int)n, [&](float *rows, int count, int done) {
         const double *src = &data[done].real;                // struct Complex = {double real, imag}
-        for (int i = 0; i < 2 * count; ++i) rows[i] = (float)src[i];
+        int i = 0;
+#if defined(__SSE2__)
+        // the one narrowing of struct Complex to the float pairs of the raw ring (and of the GPU path's RO_IQ_F32): four
+        // values per step -- at -O2 g++ leaves the plain loop scalar, and it was most of the host's time per row
+        for (; i + 4 <= 2 * count; i += 4) {
+            const __m128 lo = _mm_cvtpd_ps(_mm_loadu_pd(src + i)), hi = _mm_cvtpd_ps(_mm_loadu_pd(src + i + 2));
+            _mm_storeu_ps(rows + i, _mm_movelh_ps(lo, hi));
+        }
+#endif
+        for (; i < 2 * count; ++i) rows[i] = (float)src[i];
         if (spans && ns < 2) spans[ns++] = RawSpan{rows, count};
     });
     return ns;
