@@ -298,8 +298,13 @@ void HipWaterfallBackend::drain(bool flush, bool wait)
 {
     int64_t ready = 0;
     if (flush && ro_stft_flush(stft_, &ready) != RO_OK) {
-        lastError_ = ro_last_error();
-        return;
+        // (a flush whose last batch would lap rows still waiting in the sink is refused with its samples kept: hand over
+        // everything that is in flight, then flush again -- once is enough, the ring is empty then)
+        drain(false, true);
+        if (ro_stft_flush(stft_, &ready) != RO_OK) {
+            lastError_ = ro_last_error();
+            return;
+        }
     }
     const int64_t CH = 64;
     if (!rowSink_) fetchRows_.resize((size_t)CH * bins_);

@@ -270,3 +270,68 @@ def test_rows_complete_counts_only_finished_batches(ro, oracle):
         assert first == 4 and rest.shape[0] == R - 4 and st.rows_complete() == 0
         got = np.concatenate([rows, rest])
     assert (np.abs(got.astype(np.float64) - want).max(axis=1) / want.max(axis=1)).max() <= 1e-5
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_row_sink_soak_random_calls_and_fetches(ro, oracle, seed):
+    """The streaming path with a row sink under calls of random size and fetches at random moments (seeded): pushes that
+    would lap unfetched rows are refused whole and repeated after a fetch, only finished rows are fetched in between,
+    and every row of the stream arrives once, in order, in its slot, equal to the oracle's."""
+    rng = np.random.default_rng(1000 + seed)
+    bins, overlap = 2048, 1536
+    hop = bins - overlap
+    batch = int(rng.integers(2, 7))
+    slots = int(rng.integers(2 * batch, 4 * batch + 3))
+    R = 40 * slots + int(rng.integers(0, slots))
+    T = bins + (R - 1) * hop + int(rng.integers(0, hop))
+    iq = noise_iq(rng, T)
+    want = oracle.stft(iq, bins, overlap)
+    pinned = ro.PinnedArray(slots, bins)
+    ring = pinned.array
+    ring[:] = np.nan
+    seen = refused = 0
+
+    def take(st, limit):
+        nonlocal seen
+        while limit > 0:
+            first, got, _ = st.fetch_records(min(limit, 1 + int(rng.integers(0, 2 * batch))))
+            if got == 0:
+                break
+            assert first == seen
+            for r in range(first, first + got):
+                assert np.abs(ring[r % slots] - want[r]).max() <= 1e-5 * want[r].max(), r
+            seen += got
+            limit -= got
+
+    with ro.Stft(bins=bins, overlap=overlap, max_batch_rows=batch) as st:
+        st.set_row_sink(ring, 0)
+        at = 0
+        while at < T:
+            n = int(rng.integers(1, (slots + batch) * hop))
+            piece = iq[at:at + n]
+            try:
+                st.push(piece)
+                at += len(piece)
+            except ro.StftError as e:
+                assert e.code == -5 and "nothing was consumed" in str(e)
+                refused += 1
+                take(st, 10 ** 9)                              # everything in flight (this one waits), then the same piece again
+                if st.stats()["rows_out"] - seen == 0 and len(piece) > (slots - batch) * hop:
+                    piece = piece[:(slots - batch) * hop]      # a piece no empty ring could take: cut it
+                st.push(piece)
+                at += len(piece)
+            if rng.random() < 0.6:
+                take(st, st.rows_complete())                   # only what has finished: never waits
+        for _ in range(100):                                   # a flush whose batch would lap unfetched rows is refused too:
+            try:                                               # its samples stay staged, fetch and flush again
+                st.flush()
+                break
+            except ro.StftError as e:
+                assert e.code == -5 and "row sink full" in str(e)
+                refused += 1
+                take(st, 10 ** 9)
+        take(st, 10 ** 9)
+        assert seen == R == st.stats()["rows_out"]
+    assert refused > 0                                         # the soak did meet the refusal
+    del ring
+    pinned.close()
