@@ -308,7 +308,8 @@ int ro_stft_rows_complete(ro_stft_t *h, int64_t *rows);
  * ro_pinned_alloc (the copies are asynchronous; hipPointerGetAttributes is asked about its first and last byte and
  * anything that is not a host allocation of this process's HIP runtime -- heap memory, a numpy array -- is refused with
  * RO_ERR_INVALID) and has to stay allocated until the sink is removed (base = NULL) or
- * the handle destroyed.  With a sink ro_stft_push is ALL OR NOTHING: a call whose samples would complete more rows than
+ * the handle destroyed.  (ro_stft_flush launches batch by batch: one that would lap unfetched rows returns RO_ERR_STATE
+ * with its samples still staged -- fetch, then flush again.)  With a sink ro_stft_push is ALL OR NOTHING: a call whose samples would complete more rows than
  * the ring has free slots (capacity_rows - rows waiting to be fetched) returns RO_ERR_STATE having consumed nothing;
  * fetch, then push the same buffer again.  A row is in place once ro_stft_fetch has reported it
  * (rows_out = NULL from then on: RO_ERR_STATE otherwise; the scan records still come through records_out), and the
