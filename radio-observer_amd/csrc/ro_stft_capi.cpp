@@ -225,7 +225,6 @@ struct ro_stft {
     } slot[2];
     bool slots_ready = false;
     hipStream_t s_in = nullptr, s_out = nullptr;
-    bool one_stream = false;           // small batches: upload, kernels and download in order on `stream` (see ensure_stream_slots)
     int out_first = 0, out_cols = 0;           // columns of every row that travel to the host (the tile, or all)
     int64_t batch_seq = 0;
     std::vector<Batch *> batch_pool;           // recycled pinned batches
@@ -772,8 +771,8 @@ void free_stream_slots(ro_stft *h)
         if (sl.drained) (void)hipEventDestroy(sl.drained);
         sl = ro_stft::Slot();
     }
-    if (h->s_in && !h->one_stream) (void)hipStreamDestroy(h->s_in);
-    if (h->s_out && !h->one_stream) (void)hipStreamDestroy(h->s_out);
+    if (h->s_in) (void)hipStreamDestroy(h->s_in);
+    if (h->s_out) (void)hipStreamDestroy(h->s_out);
     h->s_in = h->s_out = nullptr;
     h->slots_ready = false;
 }
@@ -790,9 +789,7 @@ int ensure_stream_slots(ro_stft *h)
     // batch n - 1.  (Round 5 measured everything in order on ONE stream for latency-bound batches -- eight runtime calls
     // fewer per batch: push 3.9 -> 2.7 us per call, and the same 6.7e4 rows/s, because a batch then occupies the stream
     // for its whole upload -> kernel -> download chain, ~90 us; with three streams a second batch in flight overlaps it.)
-    h->one_stream = false;
-    if (h->one_stream) h->s_in = h->s_out = h->stream;
-    else ok(hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking)) && ok(hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
+    ok(hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking)) && ok(hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
     for (auto &sl : h->slot) {
         ok(hipMalloc(&sl.d_iq, in_samples * 2 * sizeof(float))) &&
             ok(hipMalloc(&sl.d_rows, (size_t)h->batch_rows * h->bins * sizeof(float))) &&
@@ -868,14 +865,13 @@ int run_stream_batch(ro_stft *h, int64_t rows)
         if (rc == RO_OK && e != hipSuccess) rc = fail(RO_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
         return rc == RO_OK;
     };
-    const bool chained = !h->one_stream;                                // (one stream: program order is the chain)
     // upload (s_in): after the kernels that last read this slot's d_iq
-    (!chained || step(hipStreamWaitEvent(h->s_in, sl.computed, 0), "hipStreamWaitEvent")) &&
+    step(hipStreamWaitEvent(h->s_in, sl.computed, 0), "hipStreamWaitEvent") &&
         step(hipMemcpyAsync(sl.d_iq, sl.h_in, (size_t)need * sb, hipMemcpyHostToDevice, h->s_in), "upload") &&
         step(hipEventRecord(sl.uploaded, h->s_in), "hipEventRecord");
     // kernels (stream): after the upload, and after the download that last read this slot's outputs
-    (!chained || (step(hipStreamWaitEvent(h->stream, sl.uploaded, 0), "hipStreamWaitEvent") &&
-                  step(hipStreamWaitEvent(h->stream, sl.drained, 0), "hipStreamWaitEvent"))) &&
+    step(hipStreamWaitEvent(h->stream, sl.uploaded, 0), "hipStreamWaitEvent") &&
+        step(hipStreamWaitEvent(h->stream, sl.drained, 0), "hipStreamWaitEvent") &&
         step(hipEventRecord(b->k0, h->stream), "hipEventRecord");
     if (rc == RO_OK) {
         ro_scan_record_t *recs = h->cfg.enable_scan ? sl.d_records : nullptr;
@@ -883,10 +879,9 @@ int run_stream_batch(ro_stft *h, int64_t rows)
         if (rc == RO_OK)
             rc = launch_tile_and_scan(h, sl.d_rows, h->bins, rows, sl.d_tile, recs, h->stream, sl.d_ln, sl.d_minmax);
     }
-    step(hipEventRecord(b->k1, h->stream), "hipEventRecord") &&
-        (!chained || step(hipEventRecord(sl.computed, h->stream), "hipEventRecord"));
+    step(hipEventRecord(b->k1, h->stream), "hipEventRecord") && step(hipEventRecord(sl.computed, h->stream), "hipEventRecord");
     // download (s_out): only the columns somebody asked for travel -- the tile when one is configured
-    if (chained) step(hipStreamWaitEvent(h->s_out, sl.computed, 0), "hipStreamWaitEvent");
+    step(hipStreamWaitEvent(h->s_out, sl.computed, 0), "hipStreamWaitEvent");
     if (rc == RO_OK) {
         const float *src = h->cfg.tile_cols > 0 ? sl.d_tile : sl.d_rows;
         if (h->sink) {
@@ -914,7 +909,7 @@ int run_stream_batch(ro_stft *h, int64_t rows)
                  "download");
         }
     }
-    (!chained || step(hipEventRecord(sl.drained, h->s_out), "hipEventRecord")) && step(hipEventRecord(b->done, h->s_out), "hipEventRecord");
+    step(hipEventRecord(sl.drained, h->s_out), "hipEventRecord") && step(hipEventRecord(b->done, h->s_out), "hipEventRecord");
     if (rc != RO_OK) {
         // nothing of this batch is handed out; whatever was queued is allowed to finish before the buffers are reused
         (void)hipStreamSynchronize(h->s_in);
