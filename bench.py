@@ -256,7 +256,22 @@ def pcie_copy_rates(torch, dev, mib=256):
                 h_out.copy_(d_out, non_blocking=True)
             ev[3].record(s2)
         torch.cuda.synchronize(dev)
-    return 4 * n / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9, 4 * n / (ev[2].elapsed_time(ev[3]) * 1e-3) / 1e9
+    both = (4 * n / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9, 4 * n / (ev[2].elapsed_time(ev[3]) * 1e-3) / 1e9)
+    # ... and each direction on its own: what the link gives a direction at best.  The path's uploads are half the size of
+    # its downloads and neither runs all the time, so the one-direction rates are the bound that can never be beaten
+    # (the both-at-once rates were: a box's simultaneous 256 MiB copies can be slower than the path's own traffic)
+    alone = []
+    for src, dst, st in ((h_in, d_in, s1), (d_out, h_out, s2)):
+        for timed in (False, True):
+            torch.cuda.synchronize(dev)
+            with torch.cuda.stream(st):
+                ev[0].record(st)
+                for _ in range(4):
+                    dst.copy_(src, non_blocking=True)
+                ev[1].record(st)
+            torch.cuda.synchronize(dev)
+        alone.append(4 * n / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9)
+    return both[0], both[1], alone[0], alone[1]
 
 
 def large_leg(torch, ro, dev, local_rank, parity, bins, overlap, rows, cite, kernels, traffic):
@@ -354,13 +369,16 @@ def streaming_leg(seconds, max_batch_rows, pcie=None):
                    "RingBuffer2D::push bookkeeping -> BolidRecorder::update per row; startStream (handle creation) and the "
                    "warm-up calls are outside the timed region, endStream inside"}
     if pcie:
-        h2d, d2h = pcie
-        # the bus's own bound for this path: per row hop samples of 8 bytes up, bins floats down, both directions at once
+        h2d_both, d2h_both, h2d, d2h = pcie
+        # the bus's own bound for this path: per row hop samples of 8 bytes up, bins floats down, each direction at the
+        # best rate the link gives it
         bound = 1.0 / max(HOP * 8 / (h2d * 1e9), BINS * 4 / (d2h * 1e9))
-        out.update({"pcie_h2d_GBs": h2d, "pcie_d2h_GBs": d2h, "pcie_bound_rows_per_s": bound,
+        out.update({"pcie_h2d_GBs": h2d, "pcie_d2h_GBs": d2h, "pcie_h2d_GBs_both_ways_at_once": h2d_both,
+                    "pcie_d2h_GBs_both_ways_at_once": d2h_both, "pcie_bound_rows_per_s": bound,
                     "frac_of_pcie": out["value"] / bound,
-                    "pcie_note": "pinned 256 MiB copies in both directions at once, measured in this run; the bound is the "
-                                 "slower direction's time per row (hop x 8 bytes up, bins x 4 bytes down)"})
+                    "pcie_note": "pinned 256 MiB copies measured in this run, each direction alone (the bound) and both at "
+                                 "once (for the record); the bound is the slower direction's time per row (hop x 8 bytes "
+                                 "up, bins x 4 bytes down) at its one-direction rate"})
     return out
 
 
