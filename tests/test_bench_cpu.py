@@ -12,7 +12,7 @@ def test_bench_flags():
                        timeout=120)
     assert r.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup", "--prewarm", "--gather", "--exchange", "--workload", "--c5-seconds",
-                 "--rows", "--bins", "--overlap", "--no-streaming", "--stream-seconds"):
+                 "--rows", "--bins", "--overlap", "--no-streaming", "--stream-seconds", "--pattern", "--no-large", "--no-strict"):
         assert flag in r.stdout, flag
     # the all-gather north_star names is what ends a step inside the timed region unless asked otherwise
     assert "all (default)" in " ".join(r.stdout.split())
