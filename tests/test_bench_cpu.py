@@ -47,7 +47,7 @@ def test_bench_gpus_n_from_a_plain_shell_starts_n_ranks():
     """`python3 bench.py --gpus 2` with no WORLD_SIZE in the env starts the two ranks itself (as a child
     torch.distributed.run job, before this process has imported torch) and exits with the child's code.  Without a
     device every rank refuses to run, so what can be checked here is the launcher: two ranks came up with
-    WORLD_SIZE = 2, both said why they stop, and the launcher handed the failure on."""
+    WORLD_SIZE = 2, a rank said why it stops, and the launcher handed the failure on."""
     import torch
     if torch.cuda.is_available():
         return                                     # (tests/test_gpu_bench.py runs the 2-rank rehearsal for real)
@@ -56,7 +56,8 @@ def test_bench_gpus_n_from_a_plain_shell_starts_n_ranks():
                         "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True,
                        timeout=600, env=env)
     assert r.returncode != 0
-    assert (r.stderr + r.stdout).count("no CPU fallback") >= 2, r.stderr[-2000:]
+    # (torch.distributed.run ends the other rank as soon as the first one has failed: one refusal is certain, two are usual)
+    assert (r.stderr + r.stdout).count("no CPU fallback") >= 1, r.stderr[-2000:]
     assert "must be started by" not in r.stderr
     assert not r.stdout.strip().startswith("{")
 
