@@ -1319,7 +1319,7 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
     {
         int xccs = 0;
         if (hipDeviceGetAttribute(&xccs, hipDeviceAttributeNumberOfXccs, cfg->device) == hipSuccess) {
-            if (xccs != 8) {
+            if (xccs > 0 && xccs != 8) {                     // (0: a runtime that answers without knowing)
                 delete h;
                 return fail(RO_ERR_UNSUPPORTED, "device %d reports %d XCDs; the kernels' row placement is laid out for 8 "
                                                 "(an MI355X in SPX mode)", cfg->device, xccs);
