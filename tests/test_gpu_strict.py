@@ -162,3 +162,17 @@ def test_one_launch_form_beside_another_kernel(ro, oracle, torch_cuda):
                 torch.cuda.synchronize()
             want = oracle.stft(iq, bins, overlap)
             assert per_bin(out.cpu().numpy(), want).max() <= 2e-7, bins
+
+
+def test_one_launch_form_int16_gain_and_custom_window(ro, oracle, torch_cuda):
+    """the one-launch form's first half takes the WAV format too (int16 frames, un-normalised), the I/Q gain and a caller's
+    window: every bin against the oracle, and the two-launch form's bits"""
+    bins, overlap = 8192, 6144
+    rng = np.random.default_rng(5)
+    i16 = rng.integers(-20000, 20000, size=(bins + 40 * 2048, 2), dtype=np.int16)
+    w = rng.random(bins).astype(np.float32)
+    got = strict_rows(ro, torch_cuda, i16, bins, overlap, fmt=ro.RO_IQ_I16, precision=ro.RO_PRECISION_F64_ONE_LAUNCH,
+                      window_table=w, iq_gain=-77.25)
+    want = oracle.stft(i16.astype(np.float64), bins, overlap, w=w, gain=-77.25)
+    assert per_bin(got, want).max() <= 2e-7
+    assert np.array_equal(got, strict_rows(ro, torch_cuda, i16, bins, overlap, fmt=ro.RO_IQ_I16, window_table=w, iq_gain=-77.25))
