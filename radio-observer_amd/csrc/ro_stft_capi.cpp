@@ -55,6 +55,10 @@
 // RO_PRECISION_F64_ONE_LAUNCH (ro_f64fused.hip): a ring of this many rows of 32768 bins per XCD (scaled so that the
 // ring's bytes stay the same at the other sizes), this many workgroups per CU.  4 rows is the least that keeps an XCD's
 // 32 workgroups busy, and all its L2 serves (profiles/r05_f64_one_launch.txt)
+// streaming path: a full latency-bound batch with a row sink runs as one captured graph per slot (run_stream_batch)
+#ifndef RO_STREAM_GRAPH
+#define RO_STREAM_GRAPH 1
+#endif
 #ifndef RO_F64_RING_ROWS
 #define RO_F64_RING_ROWS 4
 #endif
@@ -222,9 +226,17 @@ struct ro_stft {
         hipEvent_t uploaded = nullptr;         // H2D of this slot done (h_in reusable, kernels may start)
         hipEvent_t computed = nullptr;         // kernels of this slot done (d_iq reusable, D2H may start)
         hipEvent_t drained = nullptr;          // D2H of this slot done (d_rows / d_tile / d_records reusable)
+        // latency-bound batches with a row sink (run_stream_batch): upload + kernels of a FULL batch of this slot as one
+        // graph on the slot's own stream, captured from the very calls the plain path makes
+        hipStream_t    gstream = nullptr;
+        hipGraphExec_t gexec = nullptr;
+        int            graph_fmt = -1;         // stage format the graph was captured for
+        int64_t        uses = 0;               // batches this slot has run (the first one warms every lazy initialisation)
+        bool           on_gstream = false;     // the slot's last batch ran on gstream (else on the three chained streams)
     } slot[2];
     bool slots_ready = false;
     hipStream_t s_in = nullptr, s_out = nullptr;
+    bool graph_refused = false;                // stream capture of a batch failed once on this runtime: plain path only
     int out_first = 0, out_cols = 0;           // columns of every row that travel to the host (the tile, or all)
     int64_t batch_seq = 0;
     std::vector<Batch *> batch_pool;           // recycled pinned batches
@@ -769,6 +781,8 @@ void free_stream_slots(ro_stft *h)
         if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
         if (sl.computed) (void)hipEventDestroy(sl.computed);
         if (sl.drained) (void)hipEventDestroy(sl.drained);
+        if (sl.gexec) (void)hipGraphExecDestroy(sl.gexec);
+        if (sl.gstream) (void)hipStreamDestroy(sl.gstream);
         sl = ro_stft::Slot();
     }
     if (h->s_in) (void)hipStreamDestroy(h->s_in);
@@ -865,6 +879,68 @@ int run_stream_batch(ro_stft *h, int64_t rows)
         if (rc == RO_OK && e != hipSuccess) rc = fail(RO_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
         return rc == RO_OK;
     };
+    // ---- A latency-bound batch (a second of rows: well under a MiB) is all launch overhead -- fourteen runtime calls on
+    // three streams for 23 us of GPU work.  With a row sink, a FULL batch of a slot runs as ONE graph (upload and every
+    // kernel of the size: captured once from the calls below) on the slot's own stream, followed by the downloads into
+    // the sink's slots: seven calls.  The two slots' streams overlap batch n + 1 with batch n; a slot's
+    // own batches are ordered by its stream.  Partial batches (a flush) and the first batch of a slot take the plain path.
+    const bool small = (size_t)h->batch_rows * h->out_cols * sizeof(float) <= ((size_t)4 << 20);
+    bool graphed = RO_STREAM_GRAPH && small && h->sink && !h->cfg.tile_ln && rows == h->batch_rows && sl.uses > 0;
+    ro_scan_record_t *g_recs = h->cfg.enable_scan ? sl.d_records : nullptr;
+    if (graphed && (!sl.gexec || sl.graph_fmt != h->stage_fmt)) {
+        if (sl.gexec) { (void)hipGraphExecDestroy(sl.gexec); sl.gexec = nullptr; }
+        if (!sl.gstream) step(hipStreamCreateWithFlags(&sl.gstream, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+        hipGraph_t g = nullptr;
+        if (rc == RO_OK && step(hipStreamBeginCapture(sl.gstream, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture")) {
+            step(hipMemcpyAsync(sl.d_iq, sl.h_in, (size_t)need * sb, hipMemcpyHostToDevice, sl.gstream), "upload");
+            if (rc == RO_OK) rc = launch_transform(h, sl.d_iq, h->stage_fmt, 0, rows, sl.d_rows, h->bins, sl.gstream, sl.d_tile, g_recs, sl.d_ln);
+            if (rc == RO_OK) rc = launch_tile_and_scan(h, sl.d_rows, h->bins, rows, sl.d_tile, g_recs, sl.gstream, sl.d_ln, sl.d_minmax);
+            const hipError_t ce = hipStreamEndCapture(sl.gstream, &g);          // (always: leaves capture mode)
+            if (rc == RO_OK) step(ce, "hipStreamEndCapture");
+            if (rc == RO_OK) step(hipGraphInstantiate(&sl.gexec, g, nullptr, nullptr, 0), "hipGraphInstantiate");
+            if (g) (void)hipGraphDestroy(g);
+        }
+        if (rc != RO_OK) {                        // no graph on this runtime: the plain path from now on, not an error
+            (void)hipGetLastError();
+            sl.gexec = nullptr;
+            h->graph_refused = true;
+            rc = RO_OK;
+        }
+        sl.graph_fmt = h->stage_fmt;
+    }
+    graphed = graphed && sl.gexec && !h->graph_refused;
+    if (graphed != sl.on_gstream && sl.uses > 0) {
+        // the slot changes streams: what its last batch queued has to be over (a handful of times per stream: first graphed
+        // batch, a flush)
+        if (sl.on_gstream) step(hipStreamSynchronize(sl.gstream), "hipStreamSynchronize");
+        else step(hipStreamSynchronize(h->s_out), "hipStreamSynchronize");
+    }
+    sl.on_gstream = graphed;
+    sl.uses += 1;
+    if (graphed) {
+        hipStream_t gs = sl.gstream;
+        // (`uploaded` is recorded by a stream call BEHIND the graph, not by a node inside it: the host waits on it before it
+        // stages into this slot's pinned buffer again, and an event that only a queued graph will record still reads as
+        // its previous, completed record -- the host then overwrote samples the upload had not read yet: found by the
+        // seeded soak of tests/test_gpu_streaming.py)
+        step(hipEventRecord(b->k0, gs), "hipEventRecord") && step(hipGraphLaunch(sl.gexec, gs), "hipGraphLaunch") &&
+            step(hipEventRecord(b->k1, gs), "hipEventRecord") && step(hipEventRecord(sl.uploaded, gs), "hipEventRecord");
+        if (rc == RO_OK) {
+            const float *src = h->cfg.tile_cols > 0 ? sl.d_tile : sl.d_rows;
+            const size_t w = (size_t)h->out_cols * sizeof(float);
+            const int64_t s0 = (h->sink_first + h->rows_emitted) % h->sink_cap;
+            const int64_t n0 = std::min<int64_t>(rows, h->sink_cap - s0);
+            step(hipMemcpy2DAsync(h->sink + s0 * h->sink_stride, (size_t)h->sink_stride * sizeof(float), src, w, w, (size_t)n0,
+                                  hipMemcpyDeviceToHost, gs), "download");
+            if (n0 < rows)
+                step(hipMemcpy2DAsync(h->sink, (size_t)h->sink_stride * sizeof(float), src + (size_t)n0 * h->out_cols, w, w,
+                                      (size_t)(rows - n0), hipMemcpyDeviceToHost, gs), "download");
+            if (h->cfg.enable_scan)
+                step(hipMemcpyAsync(b->records, sl.d_records, (size_t)rows * sizeof(ro_scan_record_t), hipMemcpyDeviceToHost, gs),
+                     "download");
+        }
+        step(hipEventRecord(b->done, gs), "hipEventRecord");
+    } else {
     // upload (s_in): after the kernels that last read this slot's d_iq
     step(hipStreamWaitEvent(h->s_in, sl.computed, 0), "hipStreamWaitEvent") &&
         step(hipMemcpyAsync(sl.d_iq, sl.h_in, (size_t)need * sb, hipMemcpyHostToDevice, h->s_in), "upload") &&
@@ -910,11 +986,13 @@ int run_stream_batch(ro_stft *h, int64_t rows)
         }
     }
     step(hipEventRecord(sl.drained, h->s_out), "hipEventRecord") && step(hipEventRecord(b->done, h->s_out), "hipEventRecord");
+    }
     if (rc != RO_OK) {
         // nothing of this batch is handed out; whatever was queued is allowed to finish before the buffers are reused
         (void)hipStreamSynchronize(h->s_in);
         (void)hipStreamSynchronize(h->stream);
         (void)hipStreamSynchronize(h->s_out);
+        if (sl.gstream) (void)hipStreamSynchronize(sl.gstream);
         release_batch(h, b);
         return rc;
     }
@@ -2077,6 +2155,8 @@ extern "C" int ro_stft_reset(ro_stft_t *h)
     if (h->s_in) (void)hipStreamSynchronize(h->s_in);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->s_out) (void)hipStreamSynchronize(h->s_out);
+    for (auto &sl : h->slot)
+        if (sl.gstream) (void)hipStreamSynchronize(sl.gstream);
     h->staged_have = 0;
     h->stage_fmt_set = false;
     while (!h->ready.empty()) {
