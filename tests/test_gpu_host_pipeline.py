@@ -113,6 +113,45 @@ def test_one_long_process_call_on_a_wrapped_ring(oracle):
     p.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_pipeline_soak_random_call_sizes(oracle, seed):
+    """Backend::process with calls of random size (one sample ... several batches' worth, seeded) at the latency-bound
+    default batch -- graph-launched batches, rows fetched only when finished, up to two batches in flight, the ring
+    wrapping: every row's DataInfo and raw mark equal the oracle's for the same chunking, and the ring ends holding the
+    newest rows."""
+    rng = np.random.default_rng(500 + seed)
+    bins, overlap, hop = 2048, 1536, 512
+    R = 1200 + int(rng.integers(0, 300))
+    T = bins + (R - 1) * hop + int(rng.integers(0, hop))
+    iq = noise_iq(rng, T)
+    z = iq[:, 0].astype(np.float64) + 1j * iq[:, 1].astype(np.float64)
+    start = (1700000000 + seed, 123456)
+    p = HostPipeline(bins, overlap, start=start, max_batch_rows=0, snapshot_length=2)
+    o = oracle.Stream(bins, overlap, start=start, raw_capacity_rows=p.raw_capacity())
+    want_rows, want_info = [], []
+    at = 0
+    while at < T:
+        n = int(rng.choice([1, 7, 100, 512, 1024, 4096, 20000, 90000]))
+        n = max(1, int(rng.integers(1, n + 1)))
+        chunk = z[at:at + n]
+        p.process(chunk)
+        r, inf = o.process(chunk)
+        want_rows.append(r)
+        want_info += inf
+        at += len(chunk)
+    p.end()
+    assert p.error == ""
+    want_rows = np.concatenate(want_rows)
+    assert p.rows == R == want_rows.shape[0]
+    cap = p.ring_capacity()
+    keep = min(cap - 1, 200)
+    got = np.stack([p.ring_row(p.ring_mark() - keep + i) for i in range(keep)])
+    assert rel_to_row_max(got, want_rows[R - keep:]) <= 1e-5
+    for i in range(R):
+        assert p.row_info(i) == want_info[i], (i, p.row_info(i), want_info[i])
+    p.close()
+
+
 def test_bolid_detection_through_the_pipeline(oracle):
     """C4: chirps in noise through Frontend -> HipWaterfallBackend -> BolidRecorder; the events
     must equal the oracle's FSM driven by the oracle's FP64 rows."""
