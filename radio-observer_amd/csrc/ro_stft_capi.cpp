@@ -885,7 +885,9 @@ int run_stream_batch(ro_stft *h, int64_t rows)
     // the sink's slots: seven calls.  The two slots' streams overlap batch n + 1 with batch n; a slot's
     // own batches are ordered by its stream.  Partial batches (a flush) and the first batch of a slot take the plain path.
     const bool small = (size_t)h->batch_rows * h->out_cols * sizeof(float) <= ((size_t)4 << 20);
-    bool graphed = RO_STREAM_GRAPH && small && h->sink && !h->cfg.tile_ln && rows == h->batch_rows && sl.uses > 0;
+    // (float32 power-of-two handles only: the FP64 and chirp-z paths keep per-launch host state -- a give-up word, an inner
+    // handle -- that a replayed graph would not see)
+    bool graphed = RO_STREAM_GRAPH && small && h->sink && !h->cfg.tile_ln && !h->f64 && !h->czt && rows == h->batch_rows && sl.uses > 0;
     ro_scan_record_t *g_recs = h->cfg.enable_scan ? sl.d_records : nullptr;
     if (graphed && (!sl.gexec || sl.graph_fmt != h->stage_fmt)) {
         if (sl.gexec) { (void)hipGraphExecDestroy(sl.gexec); sl.gexec = nullptr; }
