@@ -178,10 +178,15 @@ void HipWaterfallBackend::startStream(StreamInfo info)
                              "raw captures of events will hold newer samples than their rows\n",
                      batchRows_, (long long)batchRows_ * hop_ + bins_, rawCapacity_);
     c.max_batch_rows = batchRows_;
-    // batches that may be in flight and not yet handed to the recorders (drain): two, if three batches of lag (two in
-    // flight, one being staged) are still a small part of both rings
-    maxOutstanding_ = (3 * (int64_t)batchRows_ <= buffer_.getCapacity() / 4 &&
-                       (!cfg_.keep_raw || 3 * (int64_t)batchRows_ * hop_ + bins_ <= rawCapacity_ / 2)) ? 2 : 1;
+    // batches that may be in flight and not yet handed to the recorders (drain): two, if that lag -- those in flight plus
+    // the one being staged -- stays a small part of both rings
+    auto lagFits = [&](int64_t batches) {       // `batches` of lag (in flight + the one being staged) stay a small part of both rings
+        return batches * (int64_t)batchRows_ <= buffer_.getCapacity() / 4 &&
+               (!cfg_.keep_raw || batches * (int64_t)batchRows_ * hop_ + bins_ <= rawCapacity_ / 2);
+    };
+    // (two at the most: the streaming path has two slots of device and staging buffers, a third batch in flight only moves
+    // the wait from the fetch into the next push -- measured)
+    maxOutstanding_ = lagFits(3) ? 2 : 1;
     c.enable_scan = scanEnabled_ ? 1 : 0;
     if (ro_stft_create(&c, &stft_) != RO_OK) {
         // the reference logs and carries on (LOG_ERROR + return); so does this: no rows will come
