@@ -55,6 +55,10 @@
 // RO_PRECISION_F64_ONE_LAUNCH (ro_f64fused.hip): a ring of this many rows of 32768 bins per XCD (scaled so that the
 // ring's bytes stay the same at the other sizes), this many workgroups per CU.  4 rows is the least that keeps an XCD's
 // 32 workgroups busy, and all its L2 serves (profiles/r05_f64_one_launch.txt)
+// streaming path: sets of device + pinned staging buffers a handle rotates through (batches that can be in flight at once)
+#ifndef RO_STREAM_SLOTS
+#define RO_STREAM_SLOTS 3
+#endif
 // streaming path: a full latency-bound batch with a row sink runs as one captured graph per slot (run_stream_batch)
 #ifndef RO_STREAM_GRAPH
 #define RO_STREAM_GRAPH 1
@@ -202,15 +206,15 @@ struct ro_stft {
     float4 *d_twiddles_k = nullptr;    // packed copy for the radix-16/32 stages
     hipStream_t stream = nullptr;
 
-    // streaming state.  Three HIP streams and two slots of device buffers: while the kernels of batch n run on
+    // streaming state.  Three HIP streams and RO_STREAM_SLOTS slots of device buffers: while the kernels of batch n run on
     // `stream`, batch n+1 is uploaded on `s_in` and batch n-1 goes home on `s_out`.
     int batch_rows = 0;
     // Samples are staged where the upload reads them: in the pinned buffer (h_in) of the slot the next batch will use
-    // (slot = batch_seq & 1), from its first byte.  A batch uploads the front of it and the samples later rows still
+    // (slot = batch_seq % RO_STREAM_SLOTS), from its first byte.  A batch uploads the front of it and the samples later rows still
     // need -- the overlap and whatever came in behind the batch's last row -- are carried over to the other slot.
     int stage_fmt = RO_IQ_F32;                 // what is staged: RO_IQ_F32 (8 B per sample) or RO_IQ_I16 (4 B)
     bool stage_fmt_set = false;
-    size_t  staged_have = 0;                   // live samples at the front of slot[batch_seq & 1].h_in
+    size_t  staged_have = 0;                   // live samples at the front of slot[batch_seq % RO_STREAM_SLOTS].h_in
     int64_t stream_sample0 = 0;                // stream index of the first of them
     // row sink (ro_stft_set_row_sink): finished rows go straight into the caller's ring (ro_pinned_alloc memory)
     float  *sink = nullptr;
@@ -233,7 +237,7 @@ struct ro_stft {
         int            graph_fmt = -1;         // stage format the graph was captured for
         int64_t        uses = 0;               // batches this slot has run (the first one warms every lazy initialisation)
         bool           on_gstream = false;     // the slot's last batch ran on gstream (else on the three chained streams)
-    } slot[2];
+    } slot[RO_STREAM_SLOTS];
     bool slots_ready = false;
     hipStream_t s_in = nullptr, s_out = nullptr;
     bool graph_refused = false;                // stream capture of a batch failed once on this runtime: plain path only
@@ -863,7 +867,7 @@ int run_stream_batch(ro_stft *h, int64_t rows)
     if (h->sink && h->rows_ready + rows > h->sink_cap)
         return fail(RO_ERR_STATE, "row sink full: %lld rows wait to be fetched in a ring of %lld slots", (long long)h->rows_ready,
                     (long long)h->sink_cap);
-    ro_stft::Slot &sl = h->slot[h->batch_seq & 1];                      // (its samples are already in sl.h_in)
+    ro_stft::Slot &sl = h->slot[h->batch_seq % RO_STREAM_SLOTS];                      // (its samples are already in sl.h_in)
     // Back-pressure: one large ro_stft_push must not queue a pinned batch per launch without bound (64 MiB each with
     // full rows).  Batches older than the newest MAX_IN_FLIGHT are waited for here -- they stay in `ready` for the
     // next fetch, their buffers are simply known to be complete.
@@ -882,7 +886,7 @@ int run_stream_batch(ro_stft *h, int64_t rows)
     // ---- A latency-bound batch (a second of rows: well under a MiB) is all launch overhead -- fourteen runtime calls on
     // three streams for 23 us of GPU work.  With a row sink, a FULL batch of a slot runs as ONE graph (upload and every
     // kernel of the size: captured once from the calls below) on the slot's own stream, followed by the downloads into
-    // the sink's slots: seven calls.  The two slots' streams overlap batch n + 1 with batch n; a slot's
+    // the sink's slots: seven calls.  The slots' streams overlap a batch with the one or two before it; a slot's
     // own batches are ordered by its stream.  Partial batches (a flush) and the first batch of a slot take the plain path.
     const bool small = (size_t)h->batch_rows * h->out_cols * sizeof(float) <= ((size_t)4 << 20);
     // (float32 power-of-two handles only: the FP64 and chirp-z paths keep per-launch host state -- a give-up word, an inner
@@ -1013,7 +1017,7 @@ int run_stream_batch(ro_stft *h, int64_t rows)
     h->rows_emitted += rows;
     h->rows_ready += rows;
     h->ready.push_back(b);
-    ro_stft::Slot &nx = h->slot[h->batch_seq & 1];                      // (batch_seq has moved on)
+    ro_stft::Slot &nx = h->slot[h->batch_seq % RO_STREAM_SLOTS];                      // (batch_seq has moved on)
     const hipError_t we = hipEventSynchronize(nx.uploaded);
     const size_t left = h->staged_have - (size_t)consumed;
     std::memcpy(nx.h_in, static_cast<const char *>(sl.h_in) + (size_t)consumed * sb, left * sb);
@@ -1907,7 +1911,7 @@ extern "C" int ro_stft_push(ro_stft_t *h, const void *iq, int format, int64_t sa
         h->stage_fmt_set = true;
     } else if (h->stage_fmt == RO_IQ_I16 && !in_i16) {
         // widen what is staged, in place and from the back (the buffer is sized for 8 bytes per sample)
-        char *base = static_cast<char *>(h->slot[h->batch_seq & 1].h_in);
+        char *base = static_cast<char *>(h->slot[h->batch_seq % RO_STREAM_SLOTS].h_in);
         const int16_t *src = reinterpret_cast<const int16_t *>(base);
         float *dst = reinterpret_cast<float *>(base);
         for (size_t i = h->staged_have * 2; i-- > 0;) dst[i] = (float)src[i];
@@ -1938,7 +1942,7 @@ extern "C" int ro_stft_push(ro_stft_t *h, const void *iq, int format, int64_t sa
     h->stat_samples += samples;
     for (int64_t left = samples; left > 0;) {
         // into the pinned buffer the next upload reads, converting on the way (no second copy)
-        char *dstb = static_cast<char *>(h->slot[h->batch_seq & 1].h_in) + h->staged_have * sb;
+        char *dstb = static_cast<char *>(h->slot[h->batch_seq % RO_STREAM_SLOTS].h_in) + h->staged_have * sb;
         const int64_t take = std::min<int64_t>(left, (int64_t)(cap - h->staged_have));
         if (h->stage_fmt == RO_IQ_I16) {
             std::memcpy(dstb, in, (size_t)take * 4);

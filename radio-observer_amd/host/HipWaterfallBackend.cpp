@@ -85,6 +85,42 @@ WFTime WaterfallBase::now() const
     return WFTime((int64_t)tv.tv_sec, (int64_t)tv.tv_usec);
 }
 
+// The one narrowing of struct Complex (two doubles) to the float pairs of the raw ring -- which are the GPU path's RO_IQ_F32
+// as well.  At -O2 g++ leaves the plain loop scalar, and it was most of the host's time per row: eight values per step
+// where the CPU has AVX (checked once at run time: the library is built on one machine and runs on another), four with
+// SSE2, one otherwise.  cvtpd2ps rounds like the cast.
+#if defined(__x86_64__) && defined(__GNUC__)
+#include <immintrin.h>
+__attribute__((target("avx"))) static void narrowAvx(const double *src, float *dst, int count)
+{
+    int i = 0;
+    for (; i + 8 <= count; i += 8) {
+        const __m128 lo = _mm256_cvtpd_ps(_mm256_loadu_pd(src + i)), hi = _mm256_cvtpd_ps(_mm256_loadu_pd(src + i + 4));
+        _mm256_storeu_ps(dst + i, _mm256_set_m128(hi, lo));
+    }
+    for (; i < count; ++i) dst[i] = (float)src[i];
+}
+#define RO_HAVE_NARROW_AVX 1
+#endif
+static void narrowToFloat(const double *src, float *dst, int count)
+{
+#ifdef RO_HAVE_NARROW_AVX
+    static const bool avx = __builtin_cpu_supports("avx");
+    if (avx) {
+        narrowAvx(src, dst, count);
+        return;
+    }
+#endif
+    int i = 0;
+#if defined(__SSE2__)
+    for (; i + 4 <= count; i += 4) {
+        const __m128 lo = _mm_cvtpd_ps(_mm_loadu_pd(src + i)), hi = _mm_cvtpd_ps(_mm_loadu_pd(src + i + 2));
+        _mm_storeu_ps(dst + i, _mm_movelh_ps(lo, hi));
+    }
+#endif
+    for (; i < count; ++i) dst[i] = (float)src[i];
+}
+
 int WaterfallBase::pushRaw(const Complex *data, size_t n, RawSpan spans[2])
 {
     if (!cfg_.keep_raw || rawBuffer_.getCapacity() == 0) return 0;
@@ -92,17 +128,7 @@ int WaterfallBase::pushRaw(const Complex *data, size_t n, RawSpan spans[2])
     // push() per sample cost more than everything else Backend::process does on the host
     int ns = 0;
     rawBuffer_.pushRun((int)n, [&](float *rows, int count, int done) {
-        const double *src = &data[done].real;                // struct Complex = {double real, imag}
-        int i = 0;
-#if defined(__SSE2__)
-        // the one narrowing of struct Complex to the float pairs of the raw ring (and of the GPU path's RO_IQ_F32): four
-        // values per step -- at -O2 g++ leaves the plain loop scalar, and it was most of the host's time per row
-        for (; i + 4 <= 2 * count; i += 4) {
-            const __m128 lo = _mm_cvtpd_ps(_mm_loadu_pd(src + i)), hi = _mm_cvtpd_ps(_mm_loadu_pd(src + i + 2));
-            _mm_storeu_ps(rows + i, _mm_movelh_ps(lo, hi));
-        }
-#endif
-        for (; i < 2 * count; ++i) rows[i] = (float)src[i];
+        narrowToFloat(&data[done].real, rows, 2 * count);    // struct Complex = {double real, imag}
         if (spans && ns < 2) spans[ns++] = RawSpan{rows, count};
     });
     return ns;
@@ -178,15 +204,14 @@ void HipWaterfallBackend::startStream(StreamInfo info)
                              "raw captures of events will hold newer samples than their rows\n",
                      batchRows_, (long long)batchRows_ * hop_ + bins_, rawCapacity_);
     c.max_batch_rows = batchRows_;
-    // batches that may be in flight and not yet handed to the recorders (drain): two, if that lag -- those in flight plus
-    // the one being staged -- stays a small part of both rings
+    // batches that may be in flight and not yet handed to the recorders (drain): as many (up to three) as keep the lag --
+    // those in flight plus the one being staged -- a small part of both rings
     auto lagFits = [&](int64_t batches) {       // `batches` of lag (in flight + the one being staged) stay a small part of both rings
         return batches * (int64_t)batchRows_ <= buffer_.getCapacity() / 4 &&
                (!cfg_.keep_raw || batches * (int64_t)batchRows_ * hop_ + bins_ <= rawCapacity_ / 2);
     };
-    // (two at the most: the streaming path has two slots of device and staging buffers, a third batch in flight only moves
-    // the wait from the fetch into the next push -- measured)
-    maxOutstanding_ = lagFits(3) ? 2 : 1;
+    // (three at the most: the streaming path rotates through three slots of device and staging buffers)
+    maxOutstanding_ = lagFits(4) ? 3 : lagFits(3) ? 2 : 1;
     c.enable_scan = scanEnabled_ ? 1 : 0;
     if (ro_stft_create(&c, &stft_) != RO_OK) {
         // the reference logs and carries on (LOG_ERROR + return); so does this: no rows will come
@@ -328,9 +353,9 @@ void HipWaterfallBackend::drain(bool flush, bool wait)
     for (;;) {
         int64_t first = 0, got = 0;
         if (budget == 0) {
-            // ... but never more than maxOutstanding_ batches stay launched-and-not-handed-over (two where the rings are
-            // long against a batch -- every shipped config: a second of rows against eight snapshots -- one where they are
-            // not): the recorders look back `advance` rows into the row ring and the raw ring, which have to hold that lag
+            // ... but never more than maxOutstanding_ batches stay launched-and-not-handed-over (three where the rings are
+            // long against a batch -- every shipped config: a second of rows against eight snapshots -- two or one where
+            // they are not): the recorders look back `advance` rows into the row ring and the raw ring, which have to hold that lag
             // plus the batch being staged (startStream).  What is beyond is waited for.  (In real time the batch of a
             // second ago finished long before this call.)
             int64_t launched = 0;

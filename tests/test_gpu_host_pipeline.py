@@ -73,12 +73,12 @@ def test_default_batch_is_bounded_by_latency(oracle):
         fed = min(i + 4096, T)
         complete = (fed - bins) // hop + 1 if fed >= bins else 0
         worst = max(worst, complete - p.rows)
-    # never three batches behind: at most two batches are launched and not yet handed over (between two calls only rows
+    # never four batches behind: at most three batches are launched and not yet handed over (between two calls only rows
     # that have finished on the device are fetched -- the launches overlap the next calls -- and anything beyond is
     # waited for), plus what is being staged for the next launch
-    # (a second outstanding batch is allowed where three batches of lag are a small part of both rings -- every shipped
-    # config; this test's one-second snapshots make the rings short, so it is one here or two: the bound covers both)
-    assert worst < 3 * p.batch_rows(), (worst, p.batch_rows())
+    # (more than one outstanding batch is allowed where that lag is a small part of both rings -- three in every shipped
+    # config; this test's one-second snapshots make the rings short: the bound covers every case)
+    assert worst < 4 * p.batch_rows(), (worst, p.batch_rows())
     p.end()
     assert p.rows == (T - bins) // hop + 1 and p.error == ""
     p.close()
