@@ -313,7 +313,8 @@ int ro_stft_rows_complete(ro_stft_t *h, int64_t *rows);
  * the ring has free slots (capacity_rows - rows waiting to be fetched) returns RO_ERR_STATE having consumed nothing;
  * fetch, then push the same buffer again.  A row is in place once ro_stft_fetch has reported it
  * (rows_out = NULL from then on: RO_ERR_STATE otherwise; the scan records still come through records_out), and the
- * handle writes up to a batch of slots AHEAD of what has been fetched: capacity_rows >= 2 x max_batch_rows, and
+ * handle writes the slots of every launched batch AHEAD of what has been fetched (as many batches as the caller lets
+ * stay in flight, never lapping rows that wait to be fetched): capacity_rows >= 2 x max_batch_rows, and
  * whoever reads old rows of the ring (snapshot writers) has to stay that far behind the head, as it has to for push().
  * Only on an idle stream (RO_ERR_STATE otherwise); not for tile_ln handles (RO_ERR_UNSUPPORTED). */
 int ro_stft_set_row_sink(ro_stft_t *h, float *base, int64_t row_stride, int64_t capacity_rows, int64_t first_slot);
