@@ -1,0 +1,244 @@
+"""Randomised parity of the resident entry points against the oracle (test infrastructure).
+
+The parametrised tests pin one feature at a time; this draws whole configurations -- size (every power of two and
+chirp-z lengths), overlap (0, 1, N-1, odd), row range, sample format, I/Q gain, window, precision mode, scan bands,
+band tile, row stride and base offset, CUs left free -- and checks every output the call makes:
+
+  * rows against the oracle's (norm-wise bar of tests/test_gpu_stft.py; the FP64 modes against float rounding),
+  * the cells of the row buffer the call must not touch (stride padding, rows outside the range, guard words),
+  * the tile against the rows it copies, bit for bit,
+  * the scan records against the oracle's scan of those rows, bit for bit,
+  * complex spectra (power-of-two sizes, F32) against the oracle's spectrum.
+
+`python tests/fuzz_parity.py --seconds 300 --seed 1` on a GPU box; `--case K` replays one case of a seed.
+tests/test_gpu_fuzz.py runs a short fixed-seed slice of it in the GPU suite.
+"""
+import argparse
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+TOL_F32 = 1e-5          # BASELINE.md's norm-wise bar (tests/test_gpu_stft.py)
+TOL_F64 = 1e-9          # FP64 arithmetic, float32 rows: the oracle's bits but for a last place of a small bin
+                        # (3657 cases on the device: 1.8e-11 at worst, profiles/r05_fuzz.txt)
+TOL_SPEC = 1e-5         # complex spectra, against the largest bin of the row
+
+POW2_SMALL = [256, 512, 1024, 2048, 4096]
+POW2_MID = [8192, 16384, 32768]
+POW2_LARGE = [65536, 131072, 262144, 524288, 1048576]
+
+
+def draw_case(rng):
+    """one configuration as a plain dict (printable, replayable)"""
+    cls = rng.choice(["small", "mid", "large", "czt_small", "czt_mid", "czt_large"],
+                     p=[0.30, 0.25, 0.12, 0.15, 0.12, 0.06])
+    if cls == "small":
+        bins = int(rng.choice(POW2_SMALL))
+    elif cls == "mid":
+        bins = int(rng.choice(POW2_MID))
+    elif cls == "large":
+        bins = int(rng.choice(POW2_LARGE, p=[0.35, 0.25, 0.2, 0.12, 0.08]))
+    elif cls == "czt_small":
+        bins = 2 * int(rng.integers(129, 4096))
+    elif cls == "czt_mid":
+        bins = 2 * int(rng.integers(4096, 20000))
+    else:
+        bins = 2 * int(rng.integers(20000, 262143))
+    pow2 = bins & (bins - 1) == 0
+    ov_kind = rng.choice(["zero", "one", "half", "three_quarters", "max", "any", "beyond"],
+                         p=[0.12, 0.05, 0.2, 0.2, 0.1, 0.28, 0.05])
+    overlap = {"zero": 0, "one": 1, "half": bins // 2, "three_quarters": bins * 3 // 4, "max": bins - 1,
+               "any": int(rng.integers(0, bins)), "beyond": bins + int(rng.integers(0, 100))}[ov_kind]
+    eff = min(max(overlap, 0), bins - 1)                     # src/FFTBackend.cpp:108-109
+    hop = bins - eff
+    budget = 1 << 22 if bins <= 32768 else 3 << 20          # points the oracle transforms per case
+    max_rows = max(1, min(40, budget // bins))
+    if hop <= 8:                                             # many rows are cheap in samples, not in transforms
+        max_rows = min(max_rows, 24)
+    total = int(rng.integers(1, max_rows + 1))
+    first = int(rng.integers(0, total))
+    rows = int(rng.integers(1, total - first + 1))
+    tail = int(rng.integers(0, min(hop, 9)))                 # leftover samples that make no row
+    fmt = str(rng.choice(["f32", "i16"], p=[0.7, 0.3]))
+    gain = float(rng.choice([0.0, 0.0, 0.5, -3.25, 37.5]))
+    window = str(rng.choice(["nuttall", "hann", "custom"], p=[0.6, 0.15, 0.25]))
+    precision = int(rng.choice([0, 1, 2], p=[0.7, 0.2, 0.1]))
+    if not pow2:                                             # RO_PRECISION_F64 is for power-of-two bins only
+        precision = 0
+    if bins > 131072 and precision:                          # keep the FP64 oracle + device time bounded
+        precision = int(rng.choice([0, 1], p=[0.7, 0.3]))
+    bands = None
+    if rng.random() < 0.6:
+        avg = int(rng.integers(1, min(101, bins // 8)))
+        dw = int(rng.integers(1, max(2, min(bins // 4, 9000))))
+        lo = avg // 2
+        hi = bins - dw - avg
+        if hi > lo:
+            ld = int(rng.integers(lo, hi))
+            nw = int(rng.integers(1, max(2, min(bins // 4, 9000))))
+            ln = int(rng.integers(0, bins - nw + 1))
+            bands = (ln, nw, ld, dw, avg)
+    tile = None
+    if rng.random() < 0.5:
+        cols = int(rng.integers(1, min(bins, 4096) + 1))
+        tile = (int(rng.integers(0, bins - cols + 1)), cols)
+    stride_extra = int(rng.choice([0, 0, 1, 3, 64, 1000]))
+    base_off = int(rng.choice([0, 0, 1, 5, 32]))
+    spare = int(rng.choice([0, 0, 0, 1, 3]))
+    spectra = bool(pow2 and precision == 0 and rng.random() < 0.25)
+    return dict(bins=bins, overlap=overlap, total=total, first=first, rows=rows, tail=tail, fmt=fmt, gain=gain,
+                window=window, precision=precision, bands=bands, tile=tile, stride_extra=stride_extra,
+                base_off=base_off, spare=spare, spectra=spectra, data_seed=int(rng.integers(0, 2 ** 31)))
+
+
+def make_input(c):
+    rng = np.random.default_rng(c["data_seed"])
+    bins = c["bins"]
+    hop = bins - min(max(c["overlap"], 0), bins - 1)
+    samples = bins + (c["total"] - 1) * hop + c["tail"]
+    if c["fmt"] == "i16":
+        iq = rng.integers(-20000, 20000, size=(samples, 2), dtype=np.int16)
+    else:
+        iq = rng.standard_normal((samples, 2)).astype(np.float32)
+        t = np.arange(samples, dtype=np.float64)
+        f = float(rng.uniform(-0.45, 0.45))
+        amp = float(rng.choice([0.0, 5.0, 200.0]))
+        iq[:, 0] += (amp * np.cos(2 * np.pi * f * t)).astype(np.float32)
+        iq[:, 1] += (amp * np.sin(2 * np.pi * f * t)).astype(np.float32)
+    w = None
+    if c["window"] == "custom":
+        w = (0.25 + rng.random(bins)).astype(np.float32)
+    return iq, w
+
+
+def run_case(ro, oracle, torch, c):
+    """raises AssertionError with the case in the message; returns the rows' error for the record"""
+    bins, first, rows = c["bins"], c["first"], c["rows"]
+    eff = ro.clamp_overlap(bins, c["overlap"])
+    iq, w = make_input(c)
+    samples = iq.shape[0]
+    assert ro.row_count(samples, bins, eff) == c["total"], c
+    kw = dict(bins=bins, overlap=c["overlap"], iq_gain=c["gain"], precision=c["precision"],
+              spare_cus_per_xcd=c["spare"])
+    if c["window"] == "hann":
+        kw["window"] = ro.RO_WINDOW_HANN
+    elif c["window"] == "custom":
+        kw["window_table"] = w
+    if c["bands"]:
+        ln, nw, ld, dw, avg = c["bands"]
+        kw["bands"] = ro.Bands(low_noise=ln, noise_width=nw, low_detect=ld, detect_width=dw, avg_bins=avg)
+    if c["tile"]:
+        kw["tile"] = c["tile"]
+    fmt = ro.RO_IQ_I16 if c["fmt"] == "i16" else ro.RO_IQ_F32
+    stride = bins + c["stride_extra"]
+    guard = 64
+    d_iq = torch.from_numpy(iq).cuda()
+    buf = torch.full((c["base_off"] + rows * stride + guard,), float("nan"), dtype=torch.float32, device="cuda")
+    d_rows = buf[c["base_off"]:]
+    d_tile = d_recs = None
+    if c["tile"]:
+        d_tile = torch.full((rows * c["tile"][1] + guard,), float("nan"), dtype=torch.float32, device="cuda")
+    if c["bands"]:
+        d_recs = torch.full((rows * 3 + guard,), float("nan"), dtype=torch.float32, device="cuda")
+    spec = None
+    with ro.Stft(**kw) as st:
+        assert st.hop == bins - eff, c
+        st.run_resident(d_iq, fmt, samples, first, rows, d_rows, row_stride=stride, d_tile=d_tile,
+                        d_records=d_recs, stream=torch.cuda.current_stream().cuda_stream)
+        if c["spectra"]:
+            spec = torch.full((rows, bins, 2), float("nan"), dtype=torch.float32, device="cuda")
+            st.spectra_resident(d_iq, fmt, samples, first, rows, spec,
+                                stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    host = buf.cpu().numpy()
+    assert np.isnan(host[:c["base_off"]]).all(), ("wrote in front of the row buffer", c)
+    body = host[c["base_off"]:c["base_off"] + rows * stride].reshape(rows, stride)
+    got = body[:, :bins]
+    assert np.isfinite(got).all(), ("non-finite row values", c)
+    assert np.isnan(body[:, bins:]).all(), ("wrote into the stride padding", c)
+    assert np.isnan(host[c["base_off"] + rows * stride:]).all(), ("wrote behind the row buffer", c)
+    ow = w if w is not None else oracle.window(bins, "hann" if c["window"] == "hann" else "nuttall")
+    src = iq.astype(np.float32) if c["fmt"] == "i16" else iq
+    want = oracle.stft(src, bins, eff, w=ow, gain=c["gain"], first_row=first, max_rows=rows)
+    assert want.shape == got.shape, (want.shape, got.shape, c)
+    err = np.abs(got.astype(np.float64) - want).max(axis=1) / np.maximum(np.abs(want).max(axis=1), 1e-300)
+    tol = TOL_F64 if c["precision"] else TOL_F32
+    assert err.max() <= tol, ("rows differ from the oracle: %.3g > %.3g" % (err.max(), tol), c)
+    if c["tile"]:
+        t = d_tile.cpu().numpy()
+        f, n = c["tile"]
+        assert np.array_equal(t[:rows * n].reshape(rows, n), got[:, f:f + n]), ("tile differs from its rows", c)
+        assert np.isnan(t[rows * n:]).all(), ("wrote behind the tile", c)
+    if c["bands"]:
+        r = d_recs.cpu().numpy()
+        recs = r[:rows * 3].copy().view(ro.capi.SCAN_DTYPE).reshape(-1)
+        ln, nw, ld, dw, avg = c["bands"]
+        n_, p_, a_ = oracle.scan_rows(np.ascontiguousarray(got), ln, nw, ld, dw, avg)
+        assert np.array_equal(recs["peak"], p_), ("scan peak", c)
+        assert np.array_equal(recs["noise"].view(np.uint32), n_.view(np.uint32)), ("scan noise", c)
+        assert np.array_equal(recs["average"].view(np.uint32), a_.view(np.uint32)), ("scan average", c)
+        assert np.isnan(r[rows * 3:]).all(), ("wrote behind the records", c)
+    if spec is not None:
+        s = spec.cpu().numpy().astype(np.float64)
+        s = s[..., 0] + 1j * s[..., 1]
+        hop = bins - eff
+        flat = src.astype(np.float64)
+        for i in (0, rows - 1):
+            seg = flat[(first + i) * hop:(first + i) * hop + bins]
+            _, ws = oracle.row_with_spectrum(seg[:, 0] + 1j * seg[:, 1], ow, gain=c["gain"])
+            e = np.abs(s[i] - ws).max() / max(np.abs(ws).max(), 1e-300)
+            assert e <= TOL_SPEC, ("spectra differ from the oracle: %.3g" % e, c)
+    return float(err.max())
+
+
+def fuzz(ro, oracle, torch, seed, seconds=None, cases=None, only=None, log=None):
+    """run cases of `seed` until `seconds` are over or `cases` are done; returns (cases run, worst error by mode)"""
+    rng = np.random.default_rng(seed)
+    t0, k, worst = time.time(), 0, {0: 0.0, 1: 0.0, 2: 0.0}
+    while True:
+        if cases is not None and k >= cases:
+            break
+        if seconds is not None and time.time() - t0 > seconds:
+            break
+        c = draw_case(rng)
+        if only is None or only == k:
+            t1 = time.time()
+            e = run_case(ro, oracle, torch, c)
+            worst[c["precision"]] = max(worst[c["precision"]], e)
+            if log:
+                log("seed %d case %d: %.1f s, err %.3g  %s" % (seed, k, time.time() - t1, e, c))
+        k += 1
+        if only is not None and k > only:
+            break
+    return k, worst
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--cases", type=int, default=None)
+    ap.add_argument("--case", type=int, default=None, help="replay this case of the seed only")
+    ap.add_argument("--quiet", action="store_true")
+    a = ap.parse_args()
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    ro = importlib.import_module("radio-observer_amd")
+    import ro_oracle
+    ro_oracle.lib()
+    log = None if a.quiet else (lambda s: print(s, flush=True))
+    n, worst = fuzz(ro, ro_oracle, torch, a.seed, seconds=None if a.case is not None else a.seconds,
+                    cases=a.cases, only=a.case, log=log)
+    print("fuzz_parity: seed %d, %d cases, all outputs within their bars; worst row error f32 %.3g, f64 %.3g, "
+          "f64 one launch %.3g" % (a.seed, n, worst[0], worst[1], worst[2]), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,44 @@
+"""A short fixed-seed slice of tests/fuzz_parity.py in the GPU suite: whole random configurations of the resident entry
+points (size, overlap, row range, format, gain, window, precision, bands, tile, stride, base offset) against the oracle.
+RO_FUZZ_SECONDS / RO_FUZZ_SEEDS (comma-separated) widen it; profiles/r05_fuzz.txt holds a long run."""
+import os
+
+import pytest
+
+import fuzz_parity
+
+SEEDS = [int(s) for s in os.environ.get("RO_FUZZ_SEEDS", "1,2").split(",") if s.strip()]
+SECONDS = float(os.environ.get("RO_FUZZ_SECONDS", "6"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_configurations_match_oracle(ro, oracle, torch_cuda, seed):
+    n, worst = fuzz_parity.fuzz(ro, oracle, torch_cuda, seed, seconds=SECONDS)
+    print("seed %d: %d cases, worst row error f32 %.3g / f64 %.3g / one launch %.3g" %
+          (seed, n, worst[0], worst[1], worst[2]))
+    assert n >= 1
+
+
+def test_case_generator_covers_the_edges():
+    """the draws themselves (no device): every size class, the overlap edges, both formats, all three precisions,
+    bands that keep average()'s window inside the row"""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    cases = [fuzz_parity.draw_case(rng) for _ in range(3000)]
+    bins = {c["bins"] for c in cases}
+    assert {256, 32768, 65536, 524288, 1048576} <= bins
+    assert any(b & (b - 1) for b in bins) and all(b % 2 == 0 for b in bins)
+    assert any(c["overlap"] == 0 for c in cases) and any(c["overlap"] == c["bins"] - 1 for c in cases)
+    assert any(c["overlap"] >= c["bins"] for c in cases)
+    assert {c["fmt"] for c in cases} == {"f32", "i16"} and {c["precision"] for c in cases} == {0, 1, 2}
+    for c in cases:
+        assert 0 <= c["first"] < c["total"] and 1 <= c["rows"] <= c["total"] - c["first"]
+        if c["precision"]:
+            assert c["bins"] & (c["bins"] - 1) == 0
+        if c["bands"]:
+            ln, nw, ld, dw, avg = c["bands"]
+            assert ld - avg // 2 >= 0 and ld + dw - 1 - avg // 2 + avg <= c["bins"]
+            assert 0 <= ln and ln + nw <= c["bins"]
+        if c["tile"]:
+            assert c["tile"][0] + c["tile"][1] <= c["bins"]
