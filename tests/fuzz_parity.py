@@ -10,7 +10,11 @@ band tile, row stride and base offset, CUs left free -- and checks every output 
   * the scan records against the oracle's scan of those rows, bit for bit,
   * complex spectra (power-of-two sizes, F32) against the oracle's spectrum.
 
-`python tests/fuzz_parity.py --seconds 300 --seed 1` on a GPU box; `--case K` replays one case of a seed.
+`--kind stream` feeds the same draws call by call (ro_stft_push / flush / fetch, with and without a row sink, pieces and
+fetches of random size, float / double / complex / int16 deliveries) and holds every streamed row, tile and record
+against the resident call's, bit for bit.
+
+`python tests/fuzz_parity.py --seconds 300 --seed 1 [--kind stream]` on a GPU box; `--case K` replays one case of a seed.
 tests/test_gpu_fuzz.py runs a short fixed-seed slice of it in the GPU suite.
 """
 import argparse
@@ -197,8 +201,165 @@ def run_case(ro, oracle, torch, c):
     return float(err.max())
 
 
-def fuzz(ro, oracle, torch, seed, seconds=None, cases=None, only=None, log=None):
-    """run cases of `seed` until `seconds` are over or `cases` are done; returns (cases run, worst error by mode)"""
+
+# ---- the call-by-call form: ro_stft_push / flush / fetch (and the row sink) -------------------------------------
+
+def draw_stream_case(rng):
+    """a resident configuration plus how the same stream arrives call by call"""
+    c = draw_case(rng)
+    bins = c["bins"]
+    hop = bins - min(max(c["overlap"], 0), bins - 1)
+    budget = 1 << 22 if bins <= 32768 else 3 << 20
+    c["total"] = int(rng.integers(1, max(2, min(70, budget // bins) + 1)))
+    c["first"], c["rows"], c["stride_extra"], c["base_off"], c["spectra"] = 0, c["total"], 0, 0, False
+    if c["precision"] == 2:
+        c["precision"] = 1
+    c["batch"] = int(rng.choice([0, 1, 2, 3, 5, 8], p=[0.08, 0.12, 0.2, 0.2, 0.2, 0.2]))    # 0: the ABI's default (64 MiB of rows)
+    c["push_fmt"] = c["fmt"] if c["fmt"] == "i16" else str(rng.choice(["f32", "f64", "c64", "c128"]))
+    c["sink"] = bool(c["batch"] > 0 and rng.random() < 0.5)
+    if c["sink"]:
+        c["slots"] = 2 * c["batch"] + int(rng.integers(0, 2 * c["batch"] + 3))
+        c["first_slot"] = int(rng.integers(0, c["slots"]))
+        c["ring_pad"] = int(rng.choice([0, 3]))
+    span = max(c["batch"], 1) * hop
+    c["piece"] = int(rng.choice([max(1, hop // 3), hop, hop + 1, 3 * hop + 7, 4096, span + 7, 4 * span + bins]))
+    c["piece"] = max(c["piece"], (bins + c["total"] * hop) // 1500)        # at most a few thousand calls per case
+    c["fetch_p"] = float(rng.choice([0.0, 0.3, 1.0]))
+    return c
+
+
+def run_stream_case(ro, oracle, torch, c):
+    """the streamed outputs equal the resident call's bit for bit (which run_case holds against the oracle), every row
+    once and in order; with a sink, in its slot; refusals leave nothing consumed"""
+    bins = c["bins"]
+    eff = ro.clamp_overlap(bins, c["overlap"])
+    hop = bins - eff
+    iq, w = make_input(c)
+    samples, total = iq.shape[0], c["total"]
+    kw = dict(bins=bins, overlap=c["overlap"], iq_gain=c["gain"], precision=c["precision"],
+              spare_cus_per_xcd=c["spare"])
+    if c["window"] == "hann":
+        kw["window"] = ro.RO_WINDOW_HANN
+    elif c["window"] == "custom":
+        kw["window_table"] = w
+    if c["bands"]:
+        ln, nw, ld, dw, avg = c["bands"]
+        kw["bands"] = ro.Bands(low_noise=ln, noise_width=nw, low_detect=ld, detect_width=dw, avg_bins=avg)
+    if c["tile"]:
+        kw["tile"] = c["tile"]
+    # the resident call on the same samples: what the stream has to reproduce
+    d_iq = torch.from_numpy(iq).cuda()
+    d_rows = torch.empty((total, bins), dtype=torch.float32, device="cuda")
+    d_recs = torch.zeros((total, 3), dtype=torch.float32, device="cuda") if c["bands"] else None
+    with ro.Stft(**kw) as st:
+        st.run_resident(d_iq, ro.RO_IQ_I16 if c["fmt"] == "i16" else ro.RO_IQ_F32, samples, 0, total, d_rows,
+                        d_records=d_recs, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    ref_rows = d_rows.cpu().numpy()
+    ref = ref_rows[:, c["tile"][0]:c["tile"][0] + c["tile"][1]] if c["tile"] else ref_rows
+    ref_recs = d_recs.cpu().numpy().view(ro.capi.SCAN_DTYPE).reshape(-1) if c["bands"] else None
+    del d_iq, d_rows, d_recs
+    # one spot check of the reference itself against the oracle (run_case does this exhaustively)
+    ow = w if w is not None else oracle.window(bins, "hann" if c["window"] == "hann" else "nuttall")
+    r = total - 1
+    src = iq[r * hop:r * hop + bins].astype(np.float32)
+    want = oracle.stft(src, bins, 0, w=ow, gain=c["gain"])[0]
+    err = float(np.abs(ref_rows[r].astype(np.float64) - want).max() / max(np.abs(want).max(), 1e-300))
+    assert err <= (TOL_F64 if c["precision"] else TOL_F32), ("resident row differs from the oracle: %.3g" % err, c)
+    del ref_rows
+
+    if c["push_fmt"] == "f64":
+        feed = iq.astype(np.float64)
+    elif c["push_fmt"] == "c64":
+        feed = (iq[:, 0] + 1j * iq[:, 1]).astype(np.complex64)
+    elif c["push_fmt"] == "c128":
+        feed = iq[:, 0].astype(np.float64) + 1j * iq[:, 1]
+    else:
+        feed = iq
+    cols = ref.shape[1]
+    pinned = ring = None
+    seen = 0
+    prng = np.random.default_rng(c["data_seed"] ^ 0x5EED)
+
+    def check_rows(first, rows, recs):
+        assert first == seen, ("rows out of order: first %d, expected %d" % (first, seen), c)
+        n = rows.shape[0] if rows is not None else len(recs)
+        if rows is not None:
+            assert np.array_equal(rows.view(np.uint32), ref[first:first + n].view(np.uint32)), ("streamed rows differ from the resident call", first, c)
+        if ref_recs is not None:
+            for k in ("noise", "peak", "average"):
+                assert np.array_equal(recs[k].view(np.uint32), ref_recs[k][first:first + n].view(np.uint32)), ("streamed record " + k, first, c)
+
+    with ro.Stft(max_batch_rows=c["batch"], **kw) as st:
+        if c["sink"]:
+            pinned = ro.PinnedArray(c["slots"], cols + c["ring_pad"])
+            ring = pinned.array
+            ring[:] = np.nan
+            st.set_row_sink(ring, c["first_slot"])
+
+        def take(limit):
+            nonlocal seen
+            while limit > 0:
+                ask = min(limit, 1 + int(prng.integers(0, 2 * max(c["batch"], 1) + 40)))
+                if c["sink"]:
+                    first, got, recs = st.fetch_records(ask)
+                    if got == 0:
+                        return
+                    check_rows(first, None, recs if recs is not None else [0] * got)
+                    for r_ in range(first, first + got):
+                        slot = ring[(c["first_slot"] + r_) % c["slots"]]
+                        assert np.array_equal(slot[:cols].view(np.uint32), ref[r_].view(np.uint32)), ("sink slot of row %d" % r_, c)
+                        assert np.isnan(slot[cols:]).all(), ("sink padding written", c)
+                else:
+                    first, rows, recs = st.fetch(ask)
+                    got = rows.shape[0]
+                    if got == 0:
+                        return
+                    check_rows(first, rows, recs)
+                seen += got
+                limit -= got
+
+        at = 0
+        while at < samples:
+            n = int(prng.integers(1, c["piece"] + 1))
+            piece = feed[at:at + n]
+            try:
+                st.push(piece)
+            except ro.StftError as e:
+                assert c["sink"] and e.code == -5 and "nothing was consumed" in str(e), (str(e), c)
+                take(10 ** 9)
+                room = (c["slots"] - c["batch"]) * hop
+                if len(piece) > room:
+                    piece = piece[:room]
+                st.push(piece)
+            at += len(piece)
+            if prng.random() < c["fetch_p"]:
+                take(st.rows_complete() if prng.random() < 0.5 else int(prng.integers(1, 50)))
+        for _ in range(200):
+            try:
+                st.flush()
+                break
+            except ro.StftError as e:
+                assert c["sink"] and e.code == -5 and "row sink full" in str(e), (str(e), c)
+                take(10 ** 9)
+        else:
+            raise AssertionError(("flush never accepted", c))
+        take(10 ** 9)
+        stats = st.stats()
+        assert seen == total == stats["rows_out"] and stats["samples_in"] == samples, (seen, total, stats, c)
+        if c["sink"]:
+            st.reset()
+            st.set_row_sink(None)
+    if pinned is not None:
+        del ring
+        pinned.close()
+    return err
+
+
+def fuzz(ro, oracle, torch, seed, seconds=None, cases=None, only=None, log=None, kind="resident"):
+    """run cases of `seed` (kind: "resident" or "stream") until `seconds` are over or `cases` are done; returns
+    (cases run, worst row error by precision mode)"""
+    draw, run = (draw_stream_case, run_stream_case) if kind == "stream" else (draw_case, run_case)
     rng = np.random.default_rng(seed)
     t0, k, worst = time.time(), 0, {0: 0.0, 1: 0.0, 2: 0.0}
     while True:
@@ -206,13 +367,13 @@ def fuzz(ro, oracle, torch, seed, seconds=None, cases=None, only=None, log=None)
             break
         if seconds is not None and time.time() - t0 > seconds:
             break
-        c = draw_case(rng)
+        c = draw(rng)
         if only is None or only == k:
             t1 = time.time()
-            e = run_case(ro, oracle, torch, c)
+            e = run(ro, oracle, torch, c)
             worst[c["precision"]] = max(worst[c["precision"]], e)
             if log:
-                log("seed %d case %d: %.1f s, err %.3g  %s" % (seed, k, time.time() - t1, e, c))
+                log("%s seed %d case %d: %.1f s, err %.3g  %s" % (kind, seed, k, time.time() - t1, e, c))
         k += 1
         if only is not None and k > only:
             break
@@ -226,6 +387,7 @@ def main():
     ap.add_argument("--cases", type=int, default=None)
     ap.add_argument("--case", type=int, default=None, help="replay this case of the seed only")
     ap.add_argument("--quiet", action="store_true")
+    ap.add_argument("--kind", choices=["resident", "stream"], default="resident")
     a = ap.parse_args()
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -235,9 +397,9 @@ def main():
     ro_oracle.lib()
     log = None if a.quiet else (lambda s: print(s, flush=True))
     n, worst = fuzz(ro, ro_oracle, torch, a.seed, seconds=None if a.case is not None else a.seconds,
-                    cases=a.cases, only=a.case, log=log)
-    print("fuzz_parity: seed %d, %d cases, all outputs within their bars; worst row error f32 %.3g, f64 %.3g, "
-          "f64 one launch %.3g" % (a.seed, n, worst[0], worst[1], worst[2]), flush=True)
+                    cases=a.cases, only=a.case, log=log, kind=a.kind)
+    print("fuzz_parity (%s): seed %d, %d cases, all outputs within their bars; worst row error f32 %.3g, f64 %.3g, "
+          "f64 one launch %.3g" % (a.kind, a.seed, n, worst[0], worst[1], worst[2]), flush=True)
 
 
 if __name__ == "__main__":

@@ -20,6 +20,16 @@ def test_random_configurations_match_oracle(ro, oracle, torch_cuda, seed):
     assert n >= 1
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_streams_equal_the_resident_call(ro, oracle, torch_cuda, seed):
+    """the same draws delivered call by call (push / flush / fetch, with and without a row sink): bit for bit the
+    resident call's rows, tiles and records, every row once and in order"""
+    n, _ = fuzz_parity.fuzz(ro, oracle, torch_cuda, 100 + seed, seconds=SECONDS, kind="stream")
+    print("seed %d: %d streams" % (100 + seed, n))
+    assert n >= 1
+
+
 def test_case_generator_covers_the_edges():
     """the draws themselves (no device): every size class, the overlap edges, both formats, all three precisions,
     bands that keep average()'s window inside the row"""
@@ -42,3 +52,10 @@ def test_case_generator_covers_the_edges():
             assert 0 <= ln and ln + nw <= c["bins"]
         if c["tile"]:
             assert c["tile"][0] + c["tile"][1] <= c["bins"]
+    streams = [fuzz_parity.draw_stream_case(rng) for _ in range(2000)]
+    assert {c["push_fmt"] for c in streams} == {"f32", "f64", "c64", "c128", "i16"}
+    assert {c["batch"] for c in streams} == {0, 1, 2, 3, 5, 8} and any(c["sink"] for c in streams)
+    for c in streams:
+        assert c["first"] == 0 and c["rows"] == c["total"] and c["precision"] in (0, 1)
+        if c["sink"]:
+            assert c["batch"] > 0 and c["slots"] >= 2 * c["batch"] and 0 <= c["first_slot"] < c["slots"]
