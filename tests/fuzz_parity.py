@@ -96,7 +96,8 @@ def draw_case(rng):
     base_off = int(rng.choice([0, 0, 1, 5, 32]))
     spare = int(rng.choice([0, 0, 0, 1, 3]))
     spectra = bool(pow2 and precision == 0 and rng.random() < 0.25)
-    return dict(bins=bins, overlap=overlap, total=total, first=first, rows=rows, tail=tail, fmt=fmt, gain=gain,
+    ln = bool(tile is not None and rng.random() < 0.35)      # tile_ln: the tile's natural log and its min / max per row
+    return dict(ln=ln, bins=bins, overlap=overlap, total=total, first=first, rows=rows, tail=tail, fmt=fmt, gain=gain,
                 window=window, precision=precision, bands=bands, tile=tile, stride_extra=stride_extra,
                 base_off=base_off, spare=spare, spectra=spectra, data_seed=int(rng.integers(0, 2 ** 31)))
 
@@ -150,11 +151,19 @@ def run_case(ro, oracle, torch, c):
         d_tile = torch.full((rows * c["tile"][1] + guard,), float("nan"), dtype=torch.float32, device="cuda")
     if c["bands"]:
         d_recs = torch.full((rows * 3 + guard,), float("nan"), dtype=torch.float32, device="cuda")
-    spec = None
+    spec = d_ln = d_mm = None
+    if c.get("ln"):
+        kw["tile_ln"] = True
+        d_ln = torch.full((rows * c["tile"][1] + guard,), float("nan"), dtype=torch.float32, device="cuda")
+        d_mm = torch.full((rows * 2 + guard,), float("nan"), dtype=torch.float32, device="cuda")
     with ro.Stft(**kw) as st:
         assert st.hop == bins - eff, c
-        st.run_resident(d_iq, fmt, samples, first, rows, d_rows, row_stride=stride, d_tile=d_tile,
-                        d_records=d_recs, stream=torch.cuda.current_stream().cuda_stream)
+        if c.get("ln"):
+            st.run_resident_ln(d_iq, fmt, samples, first, rows, d_rows, d_tile, d_ln=d_ln, d_minmax=d_mm,
+                               row_stride=stride, d_records=d_recs, stream=torch.cuda.current_stream().cuda_stream)
+        else:
+            st.run_resident(d_iq, fmt, samples, first, rows, d_rows, row_stride=stride, d_tile=d_tile,
+                            d_records=d_recs, stream=torch.cuda.current_stream().cuda_stream)
         if c["spectra"]:
             spec = torch.full((rows, bins, 2), float("nan"), dtype=torch.float32, device="cuda")
             st.spectra_resident(d_iq, fmt, samples, first, rows, spec,
@@ -179,6 +188,19 @@ def run_case(ro, oracle, torch, c):
         f, n = c["tile"]
         assert np.array_equal(t[:rows * n].reshape(rows, n), got[:, f:f + n]), ("tile differs from its rows", c)
         assert np.isnan(t[rows * n:]).all(), ("wrote behind the tile", c)
+        if c.get("ln"):
+            # tests/test_gpu_ln_tile.py's bars: logf within 2 ulp of libm's, the rows' min / max of it exact
+            image = np.ascontiguousarray(got[:, f:f + n])
+            lnv = d_ln.cpu().numpy()
+            mm = d_mm.cpu().numpy()
+            assert np.isnan(lnv[rows * n:]).all() and np.isnan(mm[rows * 2:]).all(), ("wrote behind the ln tile", c)
+            lnv, mm = lnv[:rows * n].reshape(rows, n), mm[:rows * 2].reshape(rows, 2)
+            want_ln = oracle.ln_levels(image)[0]
+            nz = image != 0
+            tol = 2 * np.spacing(np.maximum(np.abs(want_ln[nz]), np.float32(1.0)).astype(np.float32))
+            assert np.all(np.abs(lnv[nz] - want_ln[nz]) <= tol), ("ln tile beyond 2 ulp", c)
+            if nz.all():
+                assert np.array_equal(mm[:, 0], lnv.min(axis=1)) and np.array_equal(mm[:, 1], lnv.max(axis=1)), ("ln min / max", c)
     if c["bands"]:
         r = d_recs.cpu().numpy()
         recs = r[:rows * 3].copy().view(ro.capi.SCAN_DTYPE).reshape(-1)
