@@ -336,7 +336,10 @@ int ro_stft_reset(ro_stft_t *h);
  * clearProcessingTime (src/FFTBackend.h:86-92, :208-235: average and maximum per process() call, per FFT, per
  * analysis).  push = wall time of one ro_stft_push (the host side of Backend::process); batch = GPU time of the kernels
  * of one batch (HIP events; window + FFT + magnitude, and the band scan where the plan fuses it), known once the batch
- * has been fetched; row = the same per row; fetch = wall time of one ro_stft_fetch (includes waiting for the GPU). */
+ * has been fetched; row = the same per row; fetch = wall time of one ro_stft_fetch (includes waiting for the GPU).
+ * `batches` / `batch_rows` count every batch; of the latency-bound batches that run as one captured graph (full batches of
+ * at most 4 MiB into a row sink) one in eight carries the timing events -- an event record costs the host as much as a
+ * kernel launch -- and batch_gpu_ms_avg / _max and row_gpu_us_avg are over the timed ones. */
 typedef struct ro_stft_timing {
     int64_t push_calls;  double push_ms_avg, push_ms_max;
     int64_t batches;     double batch_gpu_ms_avg, batch_gpu_ms_max;

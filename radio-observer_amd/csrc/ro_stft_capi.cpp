@@ -23,6 +23,7 @@
 
 #include "../../include/ro_stft.h"
 #include "ro_kernels.h"
+#include "ro_narrow.h"
 
 // a -DRO_DIAG=1 build (tools/ab_build.sh) reads its run-time knobs (RO_BIG_FORM, RO_F64_SCRATCH_MB) from the environment
 #if defined(RO_DIAG) && !defined(RO_DIAG_KNOBS)
@@ -56,6 +57,9 @@
 // ring's bytes stay the same at the other sizes), this many workgroups per CU.  4 rows is the least that keeps an XCD's
 // 32 workgroups busy, and all its L2 serves (profiles/r05_f64_one_launch.txt)
 // streaming path: sets of device + pinned staging buffers a handle rotates through (batches that can be in flight at once)
+#ifndef RO_GRAPH_TIME_EVERY
+#define RO_GRAPH_TIME_EVERY 8
+#endif
 #ifndef RO_STREAM_SLOTS
 #define RO_STREAM_SLOTS 3
 #endif
@@ -189,6 +193,7 @@ struct Batch {
     hipEvent_t done = nullptr;
     hipEvent_t k0 = nullptr, k1 = nullptr;     // around the kernels of this batch (timing counters)
     bool pending = false;                      // `done` not yet waited for
+    bool timed = true;                         // k0 / k1 were recorded around this batch's kernels
 };
 
 }  // namespace
@@ -228,6 +233,8 @@ struct ro_stft {
         ro_scan_record_t *d_records = nullptr;
         void  *h_in = nullptr;                 // pinned upload staging
         hipEvent_t uploaded = nullptr;         // H2D of this slot done (h_in reusable, kernels may start)
+        hipEvent_t staging_free = nullptr;     // what the host waits for before it writes h_in again: `uploaded`, or the `done`
+                                               // event of the graphed batch that last used the slot (not owned)
         hipEvent_t computed = nullptr;         // kernels of this slot done (d_iq reusable, D2H may start)
         hipEvent_t drained = nullptr;          // D2H of this slot done (d_rows / d_tile / d_records reusable)
         // latency-bound batches with a row sink (run_stream_batch): upload + kernels of a FULL batch of this slot as one
@@ -252,6 +259,10 @@ struct ro_stft {
     // per-call counters in the spirit of FFTBackend's RunningAverage2 trio (src/FFTBackend.h:86-92, :208-235)
     ro_stft_timing_t timing{};
     double push_ms_sum = 0.0, batch_ms_sum = 0.0, fetch_ms_sum = 0.0;
+    int64_t timed_batches = 0, timed_rows = 0; // the batches behind batch_ms_sum (graphed batches are timed one in RO_GRAPH_TIME_EVERY)
+    double  last_batch_ms = 0.0;               // ... and the last one's time, the estimate for the ones in between
+    int64_t graph_batches = 0;
+    int     diag_time_every = 0, diag_done_only = 0, diag_direct = 0;   // (-DRO_DIAG: tools/r5/host_calls_ab.py)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     unsigned long long *d_stamps = nullptr;    // diagnostic builds (RO_STAMPS) only
 
@@ -840,12 +851,17 @@ int await_batch(ro_stft *h, Batch *b)
     HIP_TRY(hipEventSynchronize(b->done));
     b->pending = false;
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, b->k0, b->k1) == hipSuccess) {
+    h->timing.batches += 1;
+    h->timing.batch_rows += b->rows;
+    if (b->timed && hipEventElapsedTime(&ms, b->k0, b->k1) == hipSuccess) {
         h->stat_kernel_ms += ms;
-        h->timing.batches += 1;
-        h->timing.batch_rows += b->rows;
+        h->timed_batches += 1;
+        h->timed_rows += b->rows;
         h->batch_ms_sum += ms;
+        h->last_batch_ms = ms;
         h->timing.batch_gpu_ms_max = std::max(h->timing.batch_gpu_ms_max, (double)ms);
+    } else if (!b->timed) {
+        h->stat_kernel_ms += h->last_batch_ms;      // (an untimed graphed batch: the same graph as the last timed one)
     }
     return RO_OK;
 }
@@ -929,8 +945,30 @@ int run_stream_batch(ro_stft *h, int64_t rows)
         // stages into this slot's pinned buffer again, and an event that only a queued graph will record still reads as
         // its previous, completed record -- the host then overwrote samples the upload had not read yet: found by the
         // seeded soak of tests/test_gpu_streaming.py)
-        step(hipEventRecord(b->k0, gs), "hipEventRecord") && step(hipGraphLaunch(sl.gexec, gs), "hipGraphLaunch") &&
-            step(hipEventRecord(b->k1, gs), "hipEventRecord") && step(hipEventRecord(sl.uploaded, gs), "hipEventRecord");
+        // A runtime call costs the host 1 - 4 us here (tools/r5/event_cost.hip: an event record 2.4, the graph 10, a 2-D copy
+        // 4) and a batch of a second of rows is 40 us of host time in all, so the timing events around the kernels go round
+        // one batch in RO_GRAPH_TIME_EVERY only (the graph is the same every time; ro_stft_timing averages over the timed
+        // ones): +8 % rows/s at the Backend's default batch, settings alternated inside one process
+        // (profiles/r05_host_calls_ab.txt).  The same A/B says the `uploaded` event has to stay: with the batch's own `done`
+        // event as the host's "staging buffer is free again" the host waits for a whole batch two launches back instead of
+        // its upload, and the rate halves.
+        const int every = h->diag_time_every > 0 ? h->diag_time_every : RO_GRAPH_TIME_EVERY;
+        b->timed = h->graph_batches++ % every == 0;
+        if (b->timed) step(hipEventRecord(b->k0, gs), "hipEventRecord");
+        if (h->diag_direct) {                       // the graph's calls made one by one on the slot's stream
+            step(hipMemcpyAsync(sl.d_iq, sl.h_in, (size_t)need * sb, hipMemcpyHostToDevice, gs), "upload");
+            if (rc == RO_OK) rc = launch_transform(h, sl.d_iq, h->stage_fmt, 0, rows, sl.d_rows, h->bins, gs, sl.d_tile, g_recs, sl.d_ln);
+            if (rc == RO_OK) rc = launch_tile_and_scan(h, sl.d_rows, h->bins, rows, sl.d_tile, g_recs, gs, sl.d_ln, sl.d_minmax);
+        } else {
+            step(hipGraphLaunch(sl.gexec, gs), "hipGraphLaunch");
+        }
+        if (b->timed) step(hipEventRecord(b->k1, gs), "hipEventRecord");
+        if (!h->diag_done_only) {
+            step(hipEventRecord(sl.uploaded, gs), "hipEventRecord");
+            sl.staging_free = sl.uploaded;
+        } else {
+            sl.staging_free = b->done;
+        }
         if (rc == RO_OK) {
             const float *src = h->cfg.tile_cols > 0 ? sl.d_tile : sl.d_rows;
             const size_t w = (size_t)h->out_cols * sizeof(float);
@@ -951,6 +989,8 @@ int run_stream_batch(ro_stft *h, int64_t rows)
     step(hipStreamWaitEvent(h->s_in, sl.computed, 0), "hipStreamWaitEvent") &&
         step(hipMemcpyAsync(sl.d_iq, sl.h_in, (size_t)need * sb, hipMemcpyHostToDevice, h->s_in), "upload") &&
         step(hipEventRecord(sl.uploaded, h->s_in), "hipEventRecord");
+    sl.staging_free = sl.uploaded;
+    b->timed = true;
     // kernels (stream): after the upload, and after the download that last read this slot's outputs
     step(hipStreamWaitEvent(h->stream, sl.uploaded, 0), "hipStreamWaitEvent") &&
         step(hipStreamWaitEvent(h->stream, sl.drained, 0), "hipStreamWaitEvent") &&
@@ -1018,7 +1058,7 @@ int run_stream_batch(ro_stft *h, int64_t rows)
     h->rows_ready += rows;
     h->ready.push_back(b);
     ro_stft::Slot &nx = h->slot[h->batch_seq % RO_STREAM_SLOTS];                      // (batch_seq has moved on)
-    const hipError_t we = hipEventSynchronize(nx.uploaded);
+    const hipError_t we = hipEventSynchronize(nx.staging_free ? nx.staging_free : nx.uploaded);
     const size_t left = h->staged_have - (size_t)consumed;
     std::memcpy(nx.h_in, static_cast<const char *>(sl.h_in) + (size_t)consumed * sb, left * sb);
     h->staged_have = left;
@@ -1610,6 +1650,11 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
     // streaming buffers are allocated lazily by the first push
     h->batch_rows = cfg->max_batch_rows > 0 ? cfg->max_batch_rows
                                             : std::max(1, (64 << 20) / (h->bins * 4));   // ~64 MiB of rows
+#ifdef RO_DIAG_KNOBS
+    if (const char *e = getenv("RO_GRAPH_TIME_EVERY")) h->diag_time_every = atoi(e);       // tools/r5/host_calls_ab.py
+    if (const char *e = getenv("RO_GRAPH_TWO_EVENTS")) h->diag_done_only = atoi(e) == 0;
+    if (const char *e = getenv("RO_GRAPH_DIRECT")) h->diag_direct = atoi(e);
+#endif
     *out = h;
     return RO_OK;
 }
@@ -1955,7 +2000,20 @@ extern "C" int ro_stft_push(ro_stft_t *h, const void *iq, int format, int64_t sa
                 for (int64_t i = 0; i < take * 2; ++i) dst[i] = (float)src[i];
             } else {
                 const double *src = reinterpret_cast<const double *>(in);         // struct Complex
-                for (int64_t i = 0; i < take * 2; ++i) dst[i] = (float)src[i];
+                // (a slot of a few hundred KiB -- a latency-bound batch -- stays in the caches between the calls that
+                // fill it and the overlap copy that reads it back; one of many MiB does not, and is written past them)
+                // (tools/r5/host_nt.py: at a slot of 590 KiB -- the Backend's default batch -- the two forms cannot be told
+                // apart: 1.15 ... 1.52 x 10^5 rows/s with either, from one process to the next)
+                size_t nt_from = (size_t)8 << 20;
+#ifdef RO_DIAG_KNOBS
+                if (const char *e = getenv("RO_STAGE_NT_BYTES")) nt_from = (size_t)atoll(e);
+#endif
+                const bool past_caches = cap * sb > nt_from;
+                for (int64_t at = 0; at < take * 2; at += (int64_t)1 << 30) {     // (the loops count in int)
+                    const int n = (int)std::min<int64_t>(take * 2 - at, (int64_t)1 << 30);
+                    if (past_caches) ro::narrowToFloatStream(src + at, dst + at, n);
+                    else ro::narrowToFloat(src + at, dst + at, n);
+                }
             }
         }
         h->staged_have += (size_t)take;
@@ -2181,13 +2239,14 @@ extern "C" int ro_stft_timing(ro_stft_t *h, ro_stft_timing_t *out, int reset)
     if (out) {
         *out = h->timing;
         out->push_ms_avg = h->timing.push_calls ? h->push_ms_sum / (double)h->timing.push_calls : 0.0;
-        out->batch_gpu_ms_avg = h->timing.batches ? h->batch_ms_sum / (double)h->timing.batches : 0.0;
-        out->row_gpu_us_avg = h->timing.batch_rows ? h->batch_ms_sum * 1e3 / (double)h->timing.batch_rows : 0.0;
+        out->batch_gpu_ms_avg = h->timed_batches ? h->batch_ms_sum / (double)h->timed_batches : 0.0;
+        out->row_gpu_us_avg = h->timed_rows ? h->batch_ms_sum * 1e3 / (double)h->timed_rows : 0.0;
         out->fetch_ms_avg = h->timing.fetch_calls ? h->fetch_ms_sum / (double)h->timing.fetch_calls : 0.0;
     }
     if (reset) {                                             // FFTBackend::clearProcessingTime, src/FFTBackend.h:231-235
         h->timing = ro_stft_timing_t{};
         h->push_ms_sum = h->batch_ms_sum = h->fetch_ms_sum = 0.0;
+        h->timed_batches = h->timed_rows = 0;
     }
     return RO_OK;
 }

@@ -2,6 +2,7 @@
 #include <emmintrin.h>
 #endif
 #include "HipWaterfallBackend.h"
+#include "../csrc/ro_narrow.h"
 
 #include <sys/time.h>
 
@@ -85,53 +86,15 @@ WFTime WaterfallBase::now() const
     return WFTime((int64_t)tv.tv_sec, (int64_t)tv.tv_usec);
 }
 
-// The one narrowing of struct Complex (two doubles) to the float pairs of the raw ring -- which are the GPU path's RO_IQ_F32
-// as well.  At -O2 g++ leaves the plain loop scalar, and it was most of the host's time per row: eight values per step
-// where the CPU has AVX (checked once at run time: the library is built on one machine and runs on another), four with
-// SSE2, one otherwise.  cvtpd2ps rounds like the cast.
-#if defined(__x86_64__) && defined(__GNUC__)
-#include <immintrin.h>
-__attribute__((target("avx"))) static void narrowAvx(const double *src, float *dst, int count)
+void WaterfallBase::pushRaw(const Complex *data, size_t n)
 {
-    int i = 0;
-    for (; i + 8 <= count; i += 8) {
-        const __m128 lo = _mm256_cvtpd_ps(_mm256_loadu_pd(src + i)), hi = _mm256_cvtpd_ps(_mm256_loadu_pd(src + i + 4));
-        _mm256_storeu_ps(dst + i, _mm256_set_m128(hi, lo));
-    }
-    for (; i < count; ++i) dst[i] = (float)src[i];
-}
-#define RO_HAVE_NARROW_AVX 1
-#endif
-static void narrowToFloat(const double *src, float *dst, int count)
-{
-#ifdef RO_HAVE_NARROW_AVX
-    static const bool avx = __builtin_cpu_supports("avx");
-    if (avx) {
-        narrowAvx(src, dst, count);
-        return;
-    }
-#endif
-    int i = 0;
-#if defined(__SSE2__)
-    for (; i + 4 <= count; i += 4) {
-        const __m128 lo = _mm_cvtpd_ps(_mm_loadu_pd(src + i)), hi = _mm_cvtpd_ps(_mm_loadu_pd(src + i + 2));
-        _mm_storeu_ps(dst + i, _mm_movelh_ps(lo, hi));
-    }
-#endif
-    for (; i < count; ++i) dst[i] = (float)src[i];
-}
-
-int WaterfallBase::pushRaw(const Complex *data, size_t n, RawSpan spans[2])
-{
-    if (!cfg_.keep_raw || rawBuffer_.getCapacity() == 0) return 0;
+    if (!cfg_.keep_raw || rawBuffer_.getCapacity() == 0) return;
     // one ring row per sample (FFTBackend::floatToInt(Complex, float*), FFTBackend.h:258-262), a call's worth at a time:
     // push() per sample cost more than everything else Backend::process does on the host
-    int ns = 0;
     rawBuffer_.pushRun((int)n, [&](float *rows, int count, int done) {
-        narrowToFloat(&data[done].real, rows, 2 * count);    // struct Complex = {double real, imag}
-        if (spans && ns < 2) spans[ns++] = RawSpan{rows, count};
+        // struct Complex = {double real, imag}; written past the caches: the ring is read again only by an event's capture
+        narrowToFloatStream(&data[done].real, rows, 2 * count);
     });
-    return ns;
 }
 
 void WaterfallBase::finishStream()
@@ -264,9 +227,11 @@ void HipWaterfallBackend::process(const std::vector<Complex> &data, DataInfo inf
         }
         samplesIn_ += (int64_t)data.size();
     }
-    // ---- the samples themselves go to the GPU path.  struct Complex is two doubles; the raw ring wants them as float
-    // pairs anyway (one narrowing pass), and those rows ARE the RO_IQ_F32 wire format: the GPU path takes them from there
-    // (at most two runs of the ring).  Without a raw ring: RO_IQ_F64, narrowed on the way into the pinned staging buffer.
+    // ---- the samples themselves go to the GPU path.  struct Complex is two doubles: they are narrowed twice from the
+    // caller's (cache-hot) vector, once into the raw ring with stores that go past the caches and once, by ro_stft_push
+    // (RO_IQ_F64), straight into the pinned staging buffer the upload reads.  (Round 4 narrowed into the raw ring and pushed
+    // its float rows: the second pass was a memcpy out of a ring that every store had first to read from memory -- the PC
+    // samples of tools/r5/host_sample.py had 75 % of the host thread in those two loops at 256 rows per launch.)
     // A call of ordinary size goes over in one piece; a very long one (a file replayed in one block) in pieces that each
     // complete at most a quarter of the row ring, the rows handed to the recorders in between -- the rows of a batch
     // land in the ring's slots before they are fetched, so what is in flight has to stay well inside it.
@@ -295,15 +260,8 @@ void HipWaterfallBackend::process(const std::vector<Complex> &data, DataInfo inf
                 buffer_.markAhead((int)std::min<int64_t>(ahead, buffer_.getCapacity()));
             }
         }
-        RawSpan spans[2];
-        const int ns = (size_t)rawBuffer_.getCapacity() >= n ? pushRaw(src, n, spans) : 0;
-        int rc = RO_OK;
-        if (ns > 0) {
-            for (int i = 0; i < ns && rc == RO_OK; ++i) rc = ro_stft_push(stft_, spans[i].rows, RO_IQ_F32, spans[i].count, &ready);
-        } else {
-            pushRaw(src, n);
-            rc = ro_stft_push(stft_, src, RO_IQ_F64, (int64_t)n, &ready);
-        }
+        pushRaw(src, n);
+        const int rc = ro_stft_push(stft_, src, RO_IQ_F64, (int64_t)n, &ready);
         if (rc != RO_OK) {
             lastError_ = ro_last_error();
             std::fprintf(stderr, "HipWaterfallBackend: %s\n", lastError_.c_str());

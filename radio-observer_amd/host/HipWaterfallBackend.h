@@ -154,8 +154,7 @@ protected:
 
     // raw samples as (float)re, (float)im, one ring row per sample (src/FFTBackend.cpp:217-223); `spans` (optional)
     // receives where they went -- at most two runs of consecutive ring rows -- and the call returns how many
-    struct RawSpan { const float *rows; int count; };
-    int pushRaw(const Complex *data, size_t n, RawSpan spans[2] = nullptr);
+    void pushRaw(const Complex *data, size_t n);
 
     std::unique_ptr<CsvLog>    metadataFile_;
     Noise  lastNoise_;

@@ -12,6 +12,7 @@
 #include "BolidRecorder.h"
 #include "Frontends.h"
 #include "HipWaterfallBackend.h"
+#include "../../radio-observer_amd/csrc/ro_narrow.h"
 #include "RingBuffer.h"
 #include "SnapshotRecorder.h"
 
@@ -387,6 +388,22 @@ int ro_host_manual_stdout(void *m, char *buf, int len)
     return (int)RIG(m)->lines.str().size();
 }
 int ro_host_manual_raw_capacity(void *m) { return RIG(m)->source.rawBuffer().getCapacity(); }
+// sample `mark` of the raw ring (a float pair), as the recorders' raw capture reads it
+void ro_host_manual_raw_at(void *m, int mark, float *out2)
+{
+    const float *p = RIG(m)->source.rawBuffer().at(mark);
+    out2[0] = p[0];
+    out2[1] = p[1];
+}
+int ro_host_manual_raw_mark(void *m) { return RIG(m)->source.rawBuffer().mark(); }
+// the narrowing loops of pushRaw one level at a time (csrc/ro_narrow.h): returns the best level this CPU has
+int ro_host_narrow(int level, const double *src, float *dst, int count)
+{
+    // (levels 10 + l: the non-temporal form of level l)
+    if (level >= 10 && level - 10 <= narrowLevel()) narrowWith(level - 10, true, src, dst, count);
+    else if (level >= 0 && level <= narrowLevel()) narrowWith(level, src, dst, count);
+    return narrowLevel();
+}
 void ro_host_manual_end(void *m) { RIG(m)->source.endStream(); }
 int ro_host_manual_info(void *m, int *out6)
 {
@@ -464,6 +481,86 @@ int64_t ro_host_bolid_replay(int bins, int overlap, int sample_rate, float lo_de
 // behind endStream, when every row has been through BolidRecorder::update.
 // stats: [0] seconds  [1] samples  [2] rows delivered  [3] process() calls  [4] rows per kernel launch
 //        [5] mean ms per process() call  [6] max ms per process() call  [7] events fired
+//
+// RO_HOST_SAMPLE=<file>: a program-counter sampler over the timed region (a 4 kHz timer on the calling thread's CPU
+// time): where the host thread spends its time, by shared object and nearest exported symbol -- there is no perf on the
+// GPU boxes.  Diagnostic only; tools/r5/host_sample.sh runs it.
+}  // extern "C"
+#include <dlfcn.h>
+#include <signal.h>
+#include <sys/syscall.h>
+#include <sys/time.h>
+#include <ucontext.h>
+#include <unistd.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <string>
+namespace {
+constexpr int SAMPLE_MAX = 1 << 16;
+void *g_samples[SAMPLE_MAX];
+volatile int g_nsamples = 0;
+void on_prof(int, siginfo_t *, void *uc)
+{
+    const int i = g_nsamples;
+    if (i < SAMPLE_MAX) {
+        g_samples[i] = (void *)((ucontext_t *)uc)->uc_mcontext.gregs[REG_RIP];
+        g_nsamples = i + 1;
+    }
+}
+timer_t g_timer;
+void sampler_start()
+{
+    g_nsamples = 0;
+    struct sigaction sa;
+    std::memset(&sa, 0, sizeof sa);
+    sa.sa_sigaction = on_prof;
+    sa.sa_flags = SA_SIGINFO | SA_RESTART;
+    sigaction(SIGPROF, &sa, nullptr);
+    sigevent sev;                                     // this thread's CPU time, delivered to this thread
+    std::memset(&sev, 0, sizeof sev);
+    sev.sigev_notify = SIGEV_THREAD_ID;
+    sev.sigev_signo = SIGPROF;
+    sev._sigev_un._tid = (pid_t)syscall(SYS_gettid);
+    timer_create(CLOCK_THREAD_CPUTIME_ID, &sev, &g_timer);
+    itimerspec its;
+    its.it_interval.tv_sec = 0;  its.it_interval.tv_nsec = 250000;
+    its.it_value = its.it_interval;
+    timer_settime(g_timer, 0, &its, nullptr);
+}
+void sampler_stop(const char *path)
+{
+    timer_delete(g_timer);
+    signal(SIGPROF, SIG_IGN);
+    std::map<std::string, int> hist;
+    for (int i = 0; i < g_nsamples; ++i) {
+        Dl_info di;
+        std::string key = "?";
+        if (dladdr(g_samples[i], &di) && di.dli_fname) {
+            const char *base = std::strrchr(di.dli_fname, '/');
+            key = base ? base + 1 : di.dli_fname;
+            key += " : ";
+            key += di.dli_sname ? di.dli_sname : "(static)";
+            if (!di.dli_sname) {
+                char off[32];
+                std::snprintf(off, sizeof off, " +0x%zx", (size_t)((char *)g_samples[i] - (char *)di.dli_fbase) & ~(size_t)0xff);
+                key += off;
+            }
+        }
+        hist[key] += 1;
+    }
+    std::vector<std::pair<int, std::string>> v;
+    for (auto &kv : hist) v.push_back({kv.second, kv.first});
+    std::sort(v.rbegin(), v.rend());
+    if (FILE *f = std::fopen(path, "w")) {
+        std::fprintf(f, "# %d samples (250 us of the calling thread's CPU time each)\n", g_nsamples);
+        for (auto &e : v) std::fprintf(f, "%6d %5.1f%%  %s\n", e.first, 100.0 * e.first / std::max(1, (int)g_nsamples), e.second.c_str());
+        std::fclose(f);
+    }
+}
+}  // namespace
+extern "C" {
 int ro_host_stream_bench(int bins, int overlap, int sample_rate, int block, double seconds, int max_batch_rows,
                          int warm_calls, double *stats)
 {
@@ -482,8 +579,13 @@ int ro_host_stream_bench(int bins, int overlap, int sample_rate, int block, doub
     BolidRecorder bolid(&backend, b);
     backend.addRecorder(&bolid);
     FrontendDriver frontend(&backend);
-    // a few different blocks of sigma = 1 noise (the content does not change the work)
-    const int NBLK = 16;
+    // blocks of sigma = 1 noise (the content does not change the work).  The reference's frontends hand over ONE vector
+    // they have just filled (src/RawStream.cpp:36, :59-66: `outputBuffer`, 4096 samples = 64 KiB, rewritten before every
+    // process() call), so what Backend::process reads is in the calling core's caches: two blocks alternate here.
+    // (Rounds 3-5 rotated sixteen -- 1 MiB, which a core's 1 MiB L2 does not hold next to everything else, so every
+    // call read its samples from L3; RO_STREAM_NBLK=16 brings that back for the record.)
+    const char *nblk_env = std::getenv("RO_STREAM_NBLK");
+    const int NBLK = nblk_env && std::atoi(nblk_env) > 0 ? std::atoi(nblk_env) : 2;
     std::vector<std::vector<Complex>> blocks((size_t)NBLK, std::vector<Complex>((size_t)block));
     uint64_t lcg = 0x9E3779B97F4A7C15ull;
     auto uni = [&]() { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return (double)(lcg >> 11) * (1.0 / 9007199254740992.0); };
@@ -504,6 +606,8 @@ int ro_host_stream_bench(int bins, int overlap, int sample_rate, int block, doub
     ro_stft_timing_t tm;
     backend.timing(&tm, true);                                       // the counters of the timed region only
     auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
+    const char *sample_path = std::getenv("RO_HOST_SAMPLE");
+    if (sample_path) sampler_start();
     const double t0 = now();
     double worst = 0.0;
     int64_t timed = 0;
@@ -519,6 +623,7 @@ int ro_host_stream_bench(int bins, int overlap, int sample_rate, int block, doub
     backend.timing(&tm, false);
     frontend.endStream();
     const double dt = now() - t0;
+    if (sample_path) sampler_stop(sample_path);
     stats[8] = tm.push_ms_avg;  stats[9] = tm.fetch_ms_avg;  stats[10] = tm.batch_gpu_ms_avg;  stats[11] = tm.row_gpu_us_avg;
     stats[12] = (double)tm.push_calls;  stats[13] = (double)tm.fetch_calls;  stats[14] = (double)tm.batches;
     stats[15] = backend.rowsByDma() ? 1.0 : 0.0;

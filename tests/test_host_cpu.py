@@ -412,3 +412,53 @@ def test_bolid_replay_of_a_record_stream_matches_oracle_fsm(oracle):
             want.append((i, ev.snap_start, ev.snap_length, ev.peak_freq))
     got = [(buf[i].row, buf[i].start, buf[i].length, buf[i].peakFreq) for i in range(n_ev)]
     assert len(want) > 5 and got == want
+
+
+def test_raw_ring_narrows_struct_complex_like_a_cast(H, tmp_path):
+    """FFTBackend::floatToInt(Complex, float*) (src/FFTBackend.h:258-262) keeps every sample as (float)real, (float)imag:
+    the vector loops of pushRaw (AVX-512 / AVX / SSE2 by what the CPU has, scalar tails) round like the cast -- calls of
+    every length around the loops' strides, values that round up, down, to even, overflow to inf, denormals, -0."""
+    m, _ = manual(H, tmp_path)
+    cap = H.ro_host_manual_raw_capacity(m)
+    H.ro_host_manual_raw_at.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+    H.ro_host_manual_raw_mark.argtypes = [C.c_void_p]
+    H.ro_host_manual_raw_mark.restype = C.c_int
+    rng = np.random.default_rng(5)
+    special = np.array([0.0, -0.0, 1.0 + 2.0 ** -24, 1.0 + 3 * 2.0 ** -24, 1.0 + 2.0 ** -23 + 2.0 ** -24, 1e-45, -1e-46, 3.5e38,
+                        -3.5e38, 1e300, np.float64(np.float32(1.1)), 2.0 ** -126 * (1 + 2.0 ** -24), -32768.0, 32767.0])
+    sent = []
+    for n in (1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 100, 1000, 4096, 4099):
+        iq = rng.standard_normal((n, 2)) * 10.0 ** rng.uniform(-3, 6, (n, 1))
+        k = rng.integers(0, n, size=min(n, 6))
+        iq[k, rng.integers(0, 2, size=len(k))] = rng.choice(special, size=len(k))
+        first = H.ro_host_manual_raw_mark(m)
+        H.ro_host_manual_push_samples(m, np.ascontiguousarray(iq).ctypes.data_as(C.POINTER(C.c_double)), n)
+        assert H.ro_host_manual_raw_mark(m) == (first + n) % cap
+        sent.append((first, iq))
+    assert sum(len(iq) for _, iq in sent) < cap                 # nothing was lapped
+    out = (C.c_float * 2)()
+    with np.errstate(over="ignore"):
+        for first, iq in sent:
+            want = iq.astype(np.float32)
+            for i in range(len(iq)):
+                H.ro_host_manual_raw_at(m, (first + i) % cap, out)
+                got = np.array([out[0], out[1]], np.float32)
+                assert np.array_equal(got.view(np.uint32), want[i].view(np.uint32)), (len(iq), i, got, want[i])
+    H.ro_host_manual_destroy(m)
+    # ... and every level the CPU offers, one by one (3: AVX-512, 2: AVX, 1: SSE2, 0: scalar), unaligned in and out
+    H.ro_host_narrow.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_int]
+    H.ro_host_narrow.restype = C.c_int
+    best = H.ro_host_narrow(-1, None, None, 0)
+    assert best >= 1                                               # x86-64 always has SSE2
+    src = np.concatenate([iq.reshape(-1) for _, iq in sent] + [special])
+    for level in list(range(best + 1)) + [10 + l for l in range(best + 1)]:     # (10 + l: with non-temporal stores)
+        for off in (0, 1, 3):
+            for n in (0, 1, 7, 8, 9, 15, 16, 17, 31, 32, 33, 40, 47, 63, 64, 65, 200, len(src) - 3):
+                a = src[off:off + n]
+                out_buf = np.full(n + 5, np.float32(77.0), np.float32)
+                dst = out_buf[1:1 + n]
+                H.ro_host_narrow(level, a.ctypes.data_as(C.POINTER(C.c_double)), dst.ctypes.data_as(C.POINTER(C.c_float)), n)
+                with np.errstate(over="ignore"):
+                    want = a.astype(np.float32)
+                assert np.array_equal(dst.view(np.uint32), want.view(np.uint32)), (level, off, n)
+                assert out_buf[0] == 77.0 and (out_buf[1 + n:] == 77.0).all(), (level, off, n)
