@@ -347,7 +347,8 @@ typedef struct ro_stft_timing {
     int64_t fetch_calls; double fetch_ms_avg, fetch_ms_max;
 } ro_stft_timing_t;
 int ro_stft_timing(ro_stft_t *h, ro_stft_timing_t *out, int reset /* != 0: clear the counters afterwards */);
-/* totals in the spirit of FFTBackend::logProcessingTimes (src/FFTBackend.h:208-229) */
+/* totals in the spirit of FFTBackend::logProcessingTimes (src/FFTBackend.h:208-229); kernel_ms_total counts an untimed
+ * graphed batch (see ro_stft_timing) with the time of the last timed one -- the same graph */
 int ro_stft_stats(const ro_stft_t *h, int64_t *samples_in, int64_t *rows_out,
                   int64_t *launches, double *kernel_ms_total);
 
