@@ -1,4 +1,5 @@
-// GPU box: what one HIP runtime call of the streaming path costs the calling thread (hipcc --offload-arch=gfx950).
+// GPU box: what one HIP runtime call of the streaming path costs the calling thread
+// (hipcc --offload-arch=gfx950 -O2 -o tools/r5/event_cost tools/r5/event_cost.hip on the CPU box; the binary travels with gpurun).
 // hipEventQuery on an event that is not ready / ready, hipEventRecord, hipStreamWaitEvent, a 4-byte hipMemcpyAsync,
 // hipStreamWriteValue32 into pinned memory, hipGraphLaunch of an empty-kernel graph.  Diagnostic.
 #include <hip/hip_runtime.h>
