@@ -1,6 +1,6 @@
 """A short fixed-seed slice of tests/fuzz_parity.py in the GPU suite: whole random configurations of the resident entry
 points (size, overlap, row range, format, gain, window, precision, bands, tile, stride, base offset) against the oracle.
-RO_FUZZ_SECONDS / RO_FUZZ_SEEDS (comma-separated) widen it; profiles/r05_fuzz.txt holds a long run."""
+RO_FUZZ_CASES / RO_FUZZ_SECONDS / RO_FUZZ_SEEDS (comma-separated) widen it; profiles/r05_fuzz.txt holds a long run."""
 import os
 
 import pytest
@@ -8,13 +8,16 @@ import pytest
 import fuzz_parity
 
 SEEDS = [int(s) for s in os.environ.get("RO_FUZZ_SEEDS", "1,2").split(",") if s.strip()]
-SECONDS = float(os.environ.get("RO_FUZZ_SECONDS", "6"))
+# a FIXED number of cases per seed by default (the same draws every run: what the suite checks does not depend on the
+# box's speed); RO_FUZZ_SECONDS switches to a time budget
+SECONDS = float(os.environ["RO_FUZZ_SECONDS"]) if "RO_FUZZ_SECONDS" in os.environ else None
+CASES = None if SECONDS is not None else int(os.environ.get("RO_FUZZ_CASES", "60"))
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", SEEDS)
 def test_random_configurations_match_oracle(ro, oracle, torch_cuda, seed):
-    n, worst = fuzz_parity.fuzz(ro, oracle, torch_cuda, seed, seconds=SECONDS)
+    n, worst = fuzz_parity.fuzz(ro, oracle, torch_cuda, seed, seconds=SECONDS, cases=CASES)
     print("seed %d: %d cases, worst row error f32 %.3g / f64 %.3g / one launch %.3g" %
           (seed, n, worst[0], worst[1], worst[2]))
     assert n >= 1
@@ -25,7 +28,7 @@ def test_random_configurations_match_oracle(ro, oracle, torch_cuda, seed):
 def test_random_streams_equal_the_resident_call(ro, oracle, torch_cuda, seed):
     """the same draws delivered call by call (push / flush / fetch, with and without a row sink): bit for bit the
     resident call's rows, tiles and records, every row once and in order"""
-    n, _ = fuzz_parity.fuzz(ro, oracle, torch_cuda, 100 + seed, seconds=SECONDS, kind="stream")
+    n, _ = fuzz_parity.fuzz(ro, oracle, torch_cuda, 100 + seed, seconds=SECONDS, cases=CASES, kind="stream")
     print("seed %d: %d streams" % (100 + seed, n))
     assert n >= 1
 
