@@ -417,7 +417,14 @@ def main():
     ro = importlib.import_module("radio-observer_amd")
     import ro_oracle
     ro_oracle.lib()
-    log = None if a.quiet else (lambda s: print(s, flush=True))
+    last = [time.time()]
+
+    def quiet_log(line):                      # (a heartbeat every half minute: a silent job on a GPU box is taken for hung)
+        if time.time() - last[0] > 30:
+            last[0] = time.time()
+            print(line[:100] + " ...", flush=True)
+
+    log = quiet_log if a.quiet else (lambda s: print(s, flush=True))
     n, worst = fuzz(ro, ro_oracle, torch, a.seed, seconds=None if a.case is not None else a.seconds,
                     cases=a.cases, only=a.case, log=log, kind=a.kind)
     print("fuzz_parity (%s): seed %d, %d cases, all outputs within their bars; worst row error f32 %.3g, f64 %.3g, "
