@@ -29,8 +29,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 TOL_F32 = 1e-5          # BASELINE.md's norm-wise bar (tests/test_gpu_stft.py)
-TOL_F64 = 1e-9          # FP64 arithmetic, float32 rows: the oracle's bits but for a last place of a small bin
-                        # (3657 cases on the device: 1.8e-11 at worst, profiles/r05_fuzz.txt)
+TOL_F64 = 1.5e-7        # FP64 arithmetic, float32 rows: the oracle's bits but for the rounding of the stored row where the two
+                        # double results straddle a float boundary (13 000 cases on the device: 2.8e-10 at worst --
+                        # small bins only --, profiles/r05_fuzz.txt)
 TOL_SPEC = 1e-5         # complex spectra, against the largest bin of the row
 
 POW2_SMALL = [256, 512, 1024, 2048, 4096]
