@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libro_stft.so")
-SOURCES = ["ro_kernels.hip", "ro_stft32k.hip", "ro_fourstep.hip", "ro_f64fused.hip", "ro_stft_capi.cpp"]
+SOURCES = ["ro_kernels.hip", "ro_stft32k.hip", "ro_fourstep.hip", "ro_f64fused.hip", "ro_f64reg.hip", "ro_stft_capi.cpp"]
 HEADERS = ["ro_kernels.h", "ro_fft_device.h", "ro_fft_planar.h", "ro_k32_lds.h", "ro_device_util.h", "ro_f64_device.h", "ro_narrow.h", os.path.join("..", "..", "include", "ro_stft.h")]
 
 # -fno-slp-vectorize: the SLP vectoriser turns the twiddle multiplies into v_pk_* ops whose

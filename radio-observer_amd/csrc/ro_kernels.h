@@ -101,6 +101,25 @@ hipError_t launch_f64_pass(int radix, bool first, bool last, int fmt, const BigA
 // two consecutive passes (radix 16 with a.ns, then radix r2) in one kernel through LDS; n >= 4096
 hipError_t launch_f64_pair(int r2, bool first, bool last, int fmt, const BigArgsD &a, hipStream_t s);
 
+// ---- strict precision with the row in a CU's registers (ro_f64reg.hip): bins = D x M, M in {4096, 8192, 16384}, no
+// complex-double scratch.  Tables come from f64reg_tables (host), the caller uploads them.
+struct F64RegTables {
+    std::vector<float>   window_k;   // bins floats in the kernel's order
+    std::vector<double2> tw0, tw1, tw2, tw3;
+};
+struct F64RegArgs {
+    const void    *iq;          // sample 0 of the stream
+    const float   *window_k;
+    const double2 *tw0, *tw1, *tw2, *tw3;
+    float         *rows_out;    // [rows][row_stride]
+    int64_t        first_row, rows, row_stride;
+    int            hop;
+    double         gain;
+};
+bool       f64reg_supported(int bins);           // 4096 ... 65536
+void       f64reg_tables(int bins, const float *window, F64RegTables &t);
+hipError_t launch_f64reg(int bins, int fmt, const F64RegArgs &a, hipStream_t s);
+
 // all four passes of a row in one persistent launch, the intermediate in one XCD's L2 (ro_f64fused.hip):
 // bins = 16 x 16 x 16 x r2.  ring = 8 x ring_rows x n complex doubles, ctl = f64_fused_ctl_bytes() bytes (zeroed by the
 // launch); a.in / a.out / a.ns are not used.  ctl word [1] != 0 after the launch: a bounded wait gave up.

@@ -304,6 +304,10 @@ struct ro_stft {
     // strict precision (RO_PRECISION_F64): double twiddle table + two complex-double scratch blocks
     bool     f64 = false;
     double2 *d_tw_f64 = nullptr;
+    // ... bins 4096 ... 65536: the row in a CU's registers, no scratch (ro_f64reg.hip); its window order and twiddle tables
+    bool     f64reg = false;
+    float   *d_f64r_window = nullptr;
+    double2 *d_f64r_tw[4] = {nullptr, nullptr, nullptr, nullptr};
     double2 *d_scratch_d[2] = {nullptr, nullptr};
     int64_t  scratch_rows_d = 0;
     // ... or, for bins = 16^3 r2, all four passes in one launch with the intermediate in an XCD's L2 (ro_f64fused.hip):
@@ -611,6 +615,23 @@ int launch_transform_f64(ro_stft *h, const void *d_iq, int format, int64_t first
         if (const char *e = getenv("RO_F64_FUSED")) fused = atoi(e) != 0 && ro::f64_fused_supported(h->bins);
 #endif
         if (fused) return launch_transform_f64_fused(h, d_iq, format, first_row, rows, d_rows, row_stride, s);
+    }
+    if (h->f64reg) {
+        ro::F64RegArgs r{};
+        r.iq = d_iq;
+        r.window_k = h->d_f64r_window;
+        r.tw0 = h->d_f64r_tw[0];
+        r.tw1 = h->d_f64r_tw[1];
+        r.tw2 = h->d_f64r_tw[2];
+        r.tw3 = h->d_f64r_tw[3];
+        r.rows_out = d_rows;
+        r.first_row = first_row;
+        r.rows = rows;
+        r.row_stride = row_stride;
+        r.hop = h->hop;
+        r.gain = h->cfg.iq_gain;
+        HIP_TRY(ro::launch_f64reg(h->bins, format, r, s));
+        return RO_OK;
     }
     if (!h->d_scratch_d[0]) {
         int64_t mib = RO_F64_SCRATCH_MB;
@@ -1534,6 +1555,22 @@ extern "C" int ro_stft_create(const ro_stft_config_t *cfg_in, ro_stft_t **out)
         std::vector<double2> full = build_full_twiddles_f64(h->bins);
         CREATE_TRY(hipMalloc(&h->d_tw_f64, sizeof(double2) * full.size()));
         CREATE_TRY(hipMemcpy(h->d_tw_f64, full.data(), sizeof(double2) * full.size(), hipMemcpyHostToDevice));
+        h->f64reg = ro::f64reg_supported(h->bins) && !h->f64_one_launch;
+#ifdef RO_DIAG
+        if (const char *e = getenv("RO_F64_HBM")) h->f64reg = h->f64reg && atoi(e) == 0;   // the through-HBM passes, for A/B
+#endif
+        if (h->f64reg) {
+            ro::F64RegTables t;
+            ro::f64reg_tables(h->bins, h->window.data(), t);
+            CREATE_TRY(hipMalloc(&h->d_f64r_window, sizeof(float) * t.window_k.size()));
+            CREATE_TRY(hipMemcpy(h->d_f64r_window, t.window_k.data(), sizeof(float) * t.window_k.size(), hipMemcpyHostToDevice));
+            const std::vector<double2> *tabs[4] = {&t.tw0, &t.tw1, &t.tw2, &t.tw3};
+            for (int i = 0; i < 4; ++i) {
+                if (tabs[i]->empty()) continue;
+                CREATE_TRY(hipMalloc(&h->d_f64r_tw[i], sizeof(double2) * tabs[i]->size()));
+                CREATE_TRY(hipMemcpy(h->d_f64r_tw[i], tabs[i]->data(), sizeof(double2) * tabs[i]->size(), hipMemcpyHostToDevice));
+            }
+        }
     }
     if (h->big && h->dec > 1) {
         // the rotations W_bins^(q m), [dec][sub_bins], each rounded once from long double
@@ -1698,6 +1735,9 @@ extern "C" int ro_stft_destroy(ro_stft_t *h)
     if (h->d_dif_tw) (void)hipFree(h->d_dif_tw);
     if (h->d_dif_shift) (void)hipFree(h->d_dif_shift);
     if (h->d_tw_f64) (void)hipFree(h->d_tw_f64);
+    if (h->d_f64r_window) (void)hipFree(h->d_f64r_window);
+    for (int i = 0; i < 4; ++i)
+        if (h->d_f64r_tw[i]) (void)hipFree(h->d_f64r_tw[i]);
     if (h->d_ln_part) (void)hipFree(h->d_ln_part);
     for (int i = 0; i < 2; ++i)
         if (h->d_scratch_d[i]) (void)hipFree(h->d_scratch_d[i]);
