@@ -42,11 +42,20 @@
 
 #include <mutex>
 #include <cmath>
+#include <type_traits>
 
 // 1: (float)sqrt(double) as hipcc expands it (about fifteen FP64 operations); 0: float square root + one residual step in
 // double (exact to ~1e-14 of a float ulp before the final rounding)
 #ifndef RO_F64R_SQRT_EXACT
 #define RO_F64R_SQRT_EXACT 0
+#endif
+
+// The ONE diagnostic switch of this file.  A -DRO_DIAG=1 build (tools/ab_build.sh) may set RO_F64R_STAMPS=1: s_memtime
+// deltas per phase of the sub-row loop, every wave of every workgroup, accumulated into Args::stamps
+// (tools/r6/f64r_stamps.py).  Never timed, never shipped.
+#if !defined(RO_DIAG) || !defined(RO_F64R_STAMPS)
+#undef RO_F64R_STAMPS
+#define RO_F64R_STAMPS 0
 #endif
 
 namespace ro {
@@ -57,7 +66,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 template <int LOGM> struct Geo {
     static constexpr int M = 1 << LOGM, T = M / 16, R3 = M / 4096, Q = T / 16;
     static constexpr int ST = T + 16 * R3;          // doubles per k0 territory
-    static constexpr int S2 = Q + R3, S3 = Q + 1;
+    static constexpr int S2 = Q + (R3 == 1 ? 1 : 2);   // exchange 2: doubles between two k1 slots
     static constexpr int PLANE = 16 * ST;           // doubles
     static constexpr int LDS_BYTES = PLANE * 8;
     static constexpr int L3 = R3 == 1 ? 0 : R3 == 2 ? 1 : 2;
@@ -86,24 +95,46 @@ template <int BITS> __host__ __device__ constexpr int brev(int k)
 }
 
 // one block of one level: L = 16 >> LVL points starting at BETA * L
-template <int LVL, int BETA, typename TW> __device__ __forceinline__ void block16(double *re, double *im, const TW &tw)
+struct TwC;
+// (a, b) <- (a + (-i)^ROT b, a - (-i)^ROT b): four additions
+template <int ROT> __device__ __forceinline__ void bfly_plain(double &ar, double &ai, double &br, double &bi)
+{
+    const double tr = ROT == 0 ? br : bi, ti = ROT == 0 ? bi : -br;
+    br = ar - tr;
+    bi = ai - ti;
+    ar = ar + tr;
+    ai = ai + ti;
+}
+template <int LVL, int BETA, typename TW> __device__ __forceinline__ void block16(double *re, double *im, TW &tw)
 {
     constexpr int L = 16 >> LVL, H = L / 2, E = brev<LVL>(BETA) * H;         // E = exponent of W16
     constexpr int IDX = LVL == 0 ? 0 : LVL == 1 ? 1 : LVL == 2 ? 2 + (E % 4) / 2 : 4 + E % 4;
     constexpr int ROT = E / 4;
 #pragma unroll
-    for (int m = 0; m < H; ++m) bfly<ROT>(re[BETA * L + m], im[BETA * L + m], re[BETA * L + m + H], im[BETA * L + m + H], tw.re(IDX), tw.im(IDX));
+    for (int m = 0; m < H; ++m) {
+        double &ar = re[BETA * L + m], &ai = im[BETA * L + m], &br = re[BETA * L + m + H], &bi = im[BETA * L + m + H];
+        if constexpr (std::is_same<typename std::remove_reference<TW>::type, TwC>::value) {
+            // exp(-2 pi i (E % 4) / 16) = (c, -s)
+            constexpr double C[4] = {1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173};
+            constexpr double S[4] = {0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128675613};
+            if constexpr (E % 4 == 0) bfly_plain<ROT>(ar, ai, br, bi);
+            else bfly<ROT>(ar, ai, br, bi, C[E % 4], -S[E % 4]);
+        } else {
+            bfly<ROT>(ar, ai, br, bi, tw.re(IDX), tw.im(IDX));
+        }
+    }
 }
 template <int LVL, typename TW, int... Bs>
-__device__ __forceinline__ void level16(double *re, double *im, const TW &tw, std::integer_sequence<int, Bs...>)
+__device__ __forceinline__ void level16(double *re, double *im, TW &tw, std::integer_sequence<int, Bs...>)
 {
     (block16<LVL, Bs>(re, im, tw), ...);
 }
 // twisted radix-16 transform in place: result kd at position bitrev4(kd)
-template <typename TW> __device__ __forceinline__ void twisted16(double *re, double *im, const TW &tw)
+template <typename TW> __device__ __forceinline__ void twisted16(double *re, double *im, TW &&tw)
 {
     level16<0>(re, im, tw, std::make_integer_sequence<int, 1>{});
     level16<1>(re, im, tw, std::make_integer_sequence<int, 2>{});
+    tw.second_half();                                   // (per-lane tables: entries 4..7, the last level's, are asked for here)
     level16<2>(re, im, tw, std::make_integer_sequence<int, 4>{});
     level16<3>(re, im, tw, std::make_integer_sequence<int, 8>{});
 }
@@ -113,21 +144,37 @@ struct TwV {
     d2 t[8];
     __device__ __forceinline__ double re(int i) const { return t[i].x; }
     __device__ __forceinline__ double im(int i) const { return t[i].y; }
-    // entry `index` of a table of `entries` (the base is the same for the whole wave, the index is the lane's)
-    __device__ __forceinline__ void load(const double2 *table, int entries, int index)
+    __amdgpu_buffer_rsrc_t rs;
+    int voff;
+    template <int FIRST> __device__ __forceinline__ void load4()
     {
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(table, (unsigned)entries * 128u);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, index * 128, i * 16, 0);
+        for (int i = FIRST; i < FIRST + 4; ++i) {
+            const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, i * 16, 0);
             t[i] = (d2){__hiloint2double((int)u.y, (int)u.x), __hiloint2double((int)u.w, (int)u.z)};
         }
+    }
+    // entry `index` of a table of `entries` (the base is the same for the whole wave, the index is the lane's): the four
+    // twiddles of levels 0..2 now, the last level's four from inside the transform -- all eight at once are 32 VGPRs
+    // beside the 64 of the points, and where two passes in a row take per-lane tables (M = 4096) hipcc spills
+    __device__ __forceinline__ void load(const double2 *table, int entries, int index)
+    {
+        rs = make_rsrc(table, (unsigned)entries * 128u);
+        voff = index * 128;
+        __builtin_amdgcn_sched_barrier(0);
+        load4<0>();
+    }
+    __device__ __forceinline__ void second_half()
+    {
+        __builtin_amdgcn_sched_barrier(0);
+        load4<4>();
     }
 };
 struct TwS {
     d2 t[8];
     __device__ __forceinline__ double re(int i) const { return t[i].x; }
     __device__ __forceinline__ double im(int i) const { return t[i].y; }
+    __device__ __forceinline__ void second_half() {}
     // `entry` must be the same for the whole wave
     __device__ __forceinline__ void load(const double2 *entry)
     {
@@ -146,77 +193,184 @@ struct TwS {
     }
 };
 
-// |X| as a float: src/WaterfallBackend.cpp:497-503 takes sqrt in double and narrows once
-__device__ __forceinline__ float magnitude(double re, double im)
+// the twist-free pass (D = 1, pass 0): the eight entries are {1, 1, 1, W_8, 1, W_16, W_8, W_16^3}
+struct TwC {
+    __device__ __forceinline__ void second_half() {}
+};
+
+// |X| as floats: src/WaterfallBackend.cpp:497-503 takes sqrt in double and narrows once.  Here: s = re^2 + im^2 in double;
+// y = rsq_f32(float(s)), r = float(s) y is the root within a few ulp; with e = s - r^2 (the product is exact in double, one
+// rounding) the root is r + e / (2 r) up to e^2 / (8 r^3) < 2^-46 r, and the float operation r + (e y) / 2 rounds that
+// value once -- the correctly rounded float except where the root lies within ~1e-13 of a rounding boundary.  Outside the
+// range where float(s) is a normal number with headroom: the plain way, decided ONCE for the sixteen values of the whole
+// wave (a per-value branch costs more than the arithmetic; a per-lane one hipcc turns into both ways plus a select).
+__device__ __forceinline__ void magnitudes16(const double *re, const double *im, float *out)
 {
-    const double s = __builtin_fma(im, im, re * re);
-#if RO_F64R_SQRT_EXACT
-    return (float)sqrt(s);
-#else
-    // r = sqrt_f32(float(s)) is within an ulp or two; with e = s - r^2 (exact product, one rounding) the root is
-    // r + e / (2 r) up to e^2 / (8 r^3) < 2^-49 r, and the float sum r + c rounds that value once.  Outside the
-    // range where float(s) is a normal number with headroom: the plain way.
-    if (!(s > 0x1p-100 && s < 0x1p100)) return (float)sqrt(s);
-    const float r = __builtin_amdgcn_sqrtf((float)s);
-    const double rd = (double)r;
-    const float e = (float)__builtin_fma(-rd, rd, s);
-    const float h = 0.5f * __builtin_amdgcn_rcpf(r);
-    return __builtin_fmaf(e, h, r);
-#endif
+    double s[16];
+    bool odd = false;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        s[i] = __builtin_fma(im[i], im[i], re[i] * re[i]);
+        odd = odd || !(s[i] > 0x1p-100 && s[i] < 0x1p100);
+    }
+    if (RO_F64R_SQRT_EXACT || __builtin_amdgcn_ballot_w64(odd) != 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) out[i] = (float)sqrt(s[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float sf = (float)s[i];
+            const float y = __builtin_amdgcn_rsqf(sf);
+            const float r = sf * y;
+            const double rd = (double)r;
+            const float e = (float)__builtin_fma(-rd, rd, s[i]);
+            out[i] = __builtin_fmaf(e * y, 0.5f, r);
+        }
+    }
 }
 
-// The fold of sub-row QQ: slot n0 of thread t = sum_r W_D^(r QQ) w[i + M r] (x[i + M r] + i gain), i = t + T n0
+// The raw material of one sub-row in registers: 16 D samples and their window coefficients per thread, requested a whole
+// barrier wait ahead of the fold (D <= 2; at D = 4 they would not fit and the fold asks for them itself)
+template <int D, int FMT> struct Raw {
+    v2f x[D][16];
+    v4f w[D][4];
+};
+template <int LOGM, int D, int FMT>
+__device__ __forceinline__ void raw_load(Raw<D, FMT> &r, const __amdgpu_buffer_rsrc_t &rs_iq, const __amdgpu_buffer_rsrc_t &rs_w, int t)
+{
+    using G = Geo<LOGM>;
+    using S = Sample<FMT>;
+#pragma unroll
+    for (int rr = 0; rr < D; ++rr) {
+#pragma unroll
+        for (int n0 = 0; n0 < 16; ++n0) r.x[rr][n0] = S::load(rs_iq, t * S::BYTES, (G::T * n0 + G::M * rr) * S::BYTES);
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) {
+            const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs_w, t * 16, (rr * 4 + sg) * G::T * 16, 0);
+            r.w[rr][sg] = (v4f){__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z), __uint_as_float(c.w)};
+        }
+    }
+}
+
+// The fold of sub-row q: slot n0 of thread t = sum_r W_D^(r q) w[i + M r] (x[i + M r] + i gain), i = t + T n0
 // (src/FFTBackend.cpp:78-79: Q += gain; :229-232: the window multiply, double x (double)float).  Products of a float32 or
-// int16 sample and a float32 coefficient are exact in double.
-template <int LOGM, int D, int QQ, int FMT>
-__device__ __forceinline__ void fold(double *re, double *im, const __amdgpu_buffer_rsrc_t &rs_iq,
-                                     const __amdgpu_buffer_rsrc_t &rs_w, int t, bool has_gain, double gain)
+// int16 sample and a float32 coefficient are exact in double.  W_D^(r q) = (-i)^ph, ph = r q (4 / D) mod 4, is a swap and
+// two sign flips of the FLOAT sample (exact), the same for the whole workgroup: no copy of the fold per q (hipcc hoists
+// what such copies have in common -- every conversion -- in front of them, and the doubles of a whole sub-row do not fit).
+template <int D> struct Rot {
+    unsigned swap[D], sign_r[D], sign_i[D];      // per term r: exchange the halves; xor masks of the new real / imaginary half
+    double   gain_r[D], gain_i[D];               // what the reference's Q += gain becomes behind the rotation
+    __device__ __forceinline__ Rot(int q, double gain)
+    {
+#pragma unroll
+        for (int r = 0; r < D; ++r) {
+            const int ph = ((r * q) % D) * (4 / D);
+            swap[r] = ph & 1;
+            sign_r[r] = (ph == 2 || ph == 3) ? 0x80000000u : 0u;
+            sign_i[r] = (ph == 1 || ph == 2) ? 0x80000000u : 0u;
+            // (xr + i (xi + g)) (-i)^ph: ph 0: imag + g; 1: real + g; 2: imag - g; 3: real - g
+            gain_r[r] = ph == 1 ? gain : ph == 3 ? -gain : 0.0;
+            gain_i[r] = ph == 0 ? gain : ph == 2 ? -gain : 0.0;
+        }
+    }
+};
+template <int D, bool GAIN, int R>
+__device__ __forceinline__ void fold_term(double &sr, double &si, v2f x, float w, const Rot<D> &rot)
+{
+    float fr = x.x, fi = x.y;
+    if constexpr (R > 0 && D > 1) {
+        if constexpr (D > 2) {
+            const float a = rot.swap[R] ? fi : fr, b = rot.swap[R] ? fr : fi;
+            fr = a;
+            fi = b;
+        }
+        fr = __uint_as_float(__float_as_uint(fr) ^ rot.sign_r[R]);
+        fi = __uint_as_float(__float_as_uint(fi) ^ rot.sign_i[R]);
+    }
+    double xr = (double)fr, xi = (double)fi;
+    if constexpr (GAIN) {
+        if constexpr (D > 2) xr += rot.gain_r[R];
+        xi += rot.gain_i[R];                      // (D <= 2: the rotation is a sign, the gain stays on the imaginary half)
+    }
+    const double wd = (double)w;
+    if constexpr (R == 0) {
+        sr = xr * wd;
+        si = xi * wd;
+    } else {
+        sr = __builtin_fma(xr, wd, sr);
+        si = __builtin_fma(xi, wd, si);
+    }
+}
+template <int D, bool GAIN, int... Rs>
+__device__ __forceinline__ void fold_slot(double &sr, double &si, const v2f (&x)[D], const float (&w)[D], const Rot<D> &rot,
+                                          std::integer_sequence<int, Rs...>)
+{
+    (fold_term<D, GAIN, Rs>(sr, si, x[Rs], w[Rs], rot), ...);
+}
+
+// From the registers of raw_load ...
+template <int LOGM, int D, bool GAIN, int FMT>
+__device__ __forceinline__ void fold_raw(double *re, double *im, const Raw<D, FMT> &r, const Rot<D> &rot)
+{
+#pragma unroll
+    for (int n0 = 0; n0 < 16; ++n0) {
+        v2f x[D];
+        float w[D];
+#pragma unroll
+        for (int rr = 0; rr < D; ++rr) {
+            x[rr] = r.x[rr][n0];
+            w[rr] = r.w[rr][n0 / 4][n0 % 4];
+        }
+        fold_slot<D, GAIN>(re[n0], im[n0], x, w, rot, std::make_integer_sequence<int, D>{});
+        // (two slots at a time: left to itself the scheduler converts all the samples first and the doubles do not fit)
+        if (n0 & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// ... or straight from memory, four slots at a time (D = 4)
+template <int LOGM, int D, bool GAIN, int FMT>
+__device__ __forceinline__ void fold_mem(double *re, double *im, const __amdgpu_buffer_rsrc_t &rs_iq,
+                                         const __amdgpu_buffer_rsrc_t &rs_w, int t, const Rot<D> &rot)
 {
     using G = Geo<LOGM>;
     using S = Sample<FMT>;
     constexpr int M = G::M, T = G::T;
 #pragma unroll
     for (int sg = 0; sg < 4; ++sg) {
-        v2f x[D][4];
+        v2f x[4][D];
         v4f w[D];
 #pragma unroll
         for (int r = 0; r < D; ++r) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[r][e] = S::load(rs_iq, t * S::BYTES, (T * (4 * sg + e) + M * r) * S::BYTES);
+            for (int e = 0; e < 4; ++e) x[e][r] = S::load(rs_iq, t * S::BYTES, (T * (4 * sg + e) + M * r) * S::BYTES);
             const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs_w, t * 16, (r * 4 + sg) * T * 16, 0);
             w[r] = (v4f){__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z), __uint_as_float(c.w)};
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            double sr = 0.0, si = 0.0;
+            float we[D];
 #pragma unroll
-            for (int r = 0; r < D; ++r) {
-                const double xr = (double)x[r][e].x;
-                double xi = (double)x[r][e].y;
-                if (has_gain) xi += gain;
-                const double wd = (double)w[r][e];
-                const int ph = ((r * QQ) % D) * (4 / D);                  // the factor is (-i)^ph
-                if (r == 0) {
-                    sr = xr * wd;
-                    si = xi * wd;
-                } else if (ph == 0) {
-                    sr = __builtin_fma(xr, wd, sr);
-                    si = __builtin_fma(xi, wd, si);
-                } else if (ph == 1) {                                      // -i (xr + i xi) = xi - i xr
-                    sr = __builtin_fma(xi, wd, sr);
-                    si = __builtin_fma(-xr, wd, si);
-                } else if (ph == 2) {
-                    sr = __builtin_fma(-xr, wd, sr);
-                    si = __builtin_fma(-xi, wd, si);
-                } else {                                                   // i (xr + i xi) = -xi + i xr
-                    sr = __builtin_fma(-xi, wd, sr);
-                    si = __builtin_fma(xr, wd, si);
-                }
-            }
-            re[4 * sg + e] = sr;
-            im[4 * sg + e] = si;
+            for (int r = 0; r < D; ++r) we[r] = w[r][e];
+            fold_slot<D, GAIN>(re[4 * sg + e], im[4 * sg + e], x[e], we, rot, std::make_integer_sequence<int, D>{});
         }
     }
+}
+
+// v_permlane32_swap / v_permlane16_swap of two doubles: a 2 x 2 transposition between lane bit 5 (4) and the pair
+template <int BIT> __device__ __forceinline__ void lane_swap(double &a, double &b)
+{
+    unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+    unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    if constexpr (BIT == 5) {
+        const auto l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        alo = l[0]; blo = l[1]; ahi = h[0]; bhi = h[1];
+    } else {
+        const auto l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        alo = l[0]; blo = l[1]; ahi = h[0]; bhi = h[1];
+    }
+    a = __hiloint2double((int)ahi, (int)alo);
+    b = __hiloint2double((int)bhi, (int)blo);
 }
 
 struct Args {
@@ -230,13 +384,15 @@ struct Args {
     int64_t        first_row, rows, row_stride;
     int            hop;
     double         gain;
+    unsigned long long *stamps;  // diagnostic builds only (RO_F64R_STAMPS), else nullptr
 };
 
-template <int LOGM, int D, int FMT> __global__ __launch_bounds__((1 << LOGM) / 16, 4) void f64r_kernel(Args a)
+template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 << LOGM) / 16, 4) void f64r_kernel(Args a)
 {
     using G = Geo<LOGM>;
     using S = Sample<FMT>;
-    constexpr int M = G::M, T = G::T, R3 = G::R3, Q = G::Q, ST = G::ST, N = M * D;
+    [[maybe_unused]] constexpr int M = G::M, T = G::T, R3 = G::R3, Q = G::Q, ST = G::ST, N = M * D;
+    constexpr bool PRE = D <= 2;                        // the samples of the next sub-row are requested a barrier ahead
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *plane = reinterpret_cast<double *>(smem);
     float *image = reinterpret_cast<float *>(smem);
@@ -255,114 +411,163 @@ template <int LOGM, int D, int FMT> __global__ __launch_bounds__((1 << LOGM) / 1
 
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int lane = t & 63;
     const char *iq = reinterpret_cast<const char *>(a.iq);
 
-    // ---- thread roles (fixed for the kernel)
-    const int k0 = t / Q, u = t % Q, k1 = u / R3, n3 = u % R3;
-    const int K1 = k0 + 16 * k1;
-    // LDS cells (doubles / floats; see the header)
-    const int x1w = t, x1r = k0 * ST + u;
-    const int x2w = k0 * ST + u, x2r = k0 * ST + k1 * G::S2 + n3;
-    const int x3w = k0 * ST + u, x3r = k0 * ST + n3 * G::S3 + k1 * R3;
-    // image: writer (k0, s, u), reader (k0 = lane & 15, s = it, u = (lane >> 4) | (wave << 2))
-    const int rk0 = lane & 15, ru = (lane >> 4) | (wave << 2);
-    int imw, imr, imw_odd = 0, imr_odd = 0;
-    if constexpr (R3 == 1) {
-        // cell = 2 k0 ST + (s ^ (k0 & 1)) 16 + ((u + 2 (k0 >> 1)) & 15): even / odd s from two bases
-        const int bw = 2 * k0 * ST + ((u + 2 * (k0 >> 1)) & 15), br_ = 2 * rk0 * ST + ((ru + 2 * (rk0 >> 1)) & 15);
-        imw = bw + 16 * (k0 & 1);
-        imw_odd = bw - 16 * (k0 & 1);
-        imr = br_ + 16 * (rk0 & 1);
-        imr_odd = br_ - 16 * (rk0 & 1);
-    } else {
-        imw = 2 * k0 * ST + ((u + 2 * k0) & (Q - 1));
-        imr = 2 * rk0 * ST + ((ru + 2 * rk0) & (Q - 1));
-    }
-    // read-out: bin = rk0 + 16 rk1 + 256 (rg + R3 i) + 4096 k3 for slot s = i R3 + p (R3 > 1), rk0 + 16 ru + 256 bitrev4(s) else
-    const int rbin = rk0 + 16 * (ru / R3) + 256 * (ru % R3);
-
+    // Thread roles -- pass 1 (k0, n2 = u), pass 2 (k0, k1, n3) with u = n3 16 + k1 -- and the LDS cells that follow from them
+    // (see the header) are recomputed from the thread number where they are used, behind an empty asm statement: as
+    // loop invariants hipcc keeps some twenty of them in VGPRs for the whole kernel and spills the transform's.
+    auto fresh = [&]() {
+        int x = t;
+        asm volatile("" : "+v"(x));
+        return x;
+    };
     const double2 *tw0 = a.tw0 + q * 8;
     const double2 *tw1 = a.tw1 + q * 16 * 8;
     const double2 *tw2 = a.tw2 + q * 256 * 8;
-    const bool has_gain = a.gain != 0.0;
+    const Rot<D> rot(q, a.gain);
 
-    auto readout = [&](int64_t prow) {
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.rows_out + prow * a.row_stride, N * 4);
-        const int voff = (q + D * rbin) * 4;
-        float m[16];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            if constexpr (R3 == 1) m[s] = image[((s & 1) ? imr_odd : imr) + 16 * s];
-            else m[s] = image[imr + Q * s];
+    [[maybe_unused]] unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
+    auto stamp = [&](int k) {
+        if constexpr (RO_F64R_STAMPS) {
+            unsigned long long now;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (k >= 0) st_acc[k] += now - st_prev;
+            st_prev = now;
         }
+    };
+    stamp(-1);
+
+    // ---- the read-out of a finished image: column (k + N/2) mod N of the row holds |X[k]| (src/WaterfallBackend.cpp:
+    // 492-505).  A slot's share of the bin only has bits above the lane's share, and N/2 flips the top one.
+    // position p of a thread -> its share of the sub-row bin (see the header / tools/r6/emu_f64r.py)
+    auto slot_bin = [](int p) constexpr {
+        if (R3 == 1) return 256 * brev<4>(p);
+        if (R3 == 2) return 512 * brev<3>(p & 7) + 4096 * (p >> 3);
+        return 1024 * (((p >> 1) & 1) + 2 * (p & 1)) + 4096 * (((p >> 3) & 1) + 2 * ((p >> 2) & 1));
+    };
+    // D = 1: 16-byte stores.  lane = c + 4 ul (k0 = 4 c + e, e the dword of the store; ul = u & 15 = k1): a wave's store
+    // is 1 KiB of consecutive columns.  code = wave + waves it = (u >> 4) + R3 s.
+    // D > 1: 4-byte stores (the sub-row owns every D-th column): k0 = lane & 15, u = (lane >> 4) | (wave << 2), s = it.
+    float m[16];
+    auto readout_lds = [&]() {
+        const int lane = fresh() & 63;
+        if constexpr (D == 1) {
+            const int rc = lane & 3, ul = lane >> 2;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            // column (k + N/2) mod N of the row holds |X[k]| (src/WaterfallBackend.cpp:492-505): the slot's share of
-            // the bin only has bits above the lane's share, and N/2 flips the top one
-            const int sbin = R3 == 1 ? 256 * brev<4>(s) : 256 * R3 * (s / R3) + 4096 * brev<G::L3>(s % R3);
-            const int soff = ((D * sbin) ^ (N / 2)) * 4;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[s]), rs, voff, soff, RO_STORE_AUX);
+            for (int it = 0; it < 4; ++it) {
+                const int code = wave + (T / 64) * it, uh = code % R3, s = code / R3, ru = ul + 16 * uh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int rk0 = 4 * rc + e;
+                    int cell;
+                    if constexpr (R3 == 1) cell = 2 * rk0 * ST + (s ^ (rc & 1)) * 16 + ((ru + 8 * (rc >> 1)) & 15);
+                    else cell = 2 * rk0 * ST + s * Q + ((ru + 2 * rk0) & (Q - 1));
+                    m[4 * it + e] = image[cell];
+                }
+            }
+        } else {
+            const int rk0 = lane & 15, ru = (lane >> 4) | (wave << 2);
+            const int imr = 2 * rk0 * ST + ((ru + 2 * rk0) & (Q - 1));
+#pragma unroll
+            for (int s = 0; s < 16; ++s) m[s] = image[imr + Q * s];
+        }
+    };
+    auto readout_store = [&](int64_t prow) {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.rows_out + prow * a.row_stride, N * 4);
+        const int lane = fresh() & 63;
+        if constexpr (D == 1) {
+            const int rc = lane & 3, ul = lane >> 2;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int code = wave + (T / 64) * it, uh = code % R3, s = code / R3;
+                // bin of dword 0: 4 rc + 16 ul + 256 g'(uh) + slot_bin(s); g' of writer n3 = uh
+                const int g = R3 == 4 ? (uh >> 1) + 2 * (uh & 1) : uh;
+                int sb = 0;                               // slot_bin(s) for a run-time s: a 16-way select the compiler folds per it
+#pragma unroll
+                for (int p = 0; p < 16; ++p) sb = s == p ? slot_bin(p) : sb;
+                const int col = ((4 * rc + 16 * ul + 256 * g + sb) + N / 2) & (N - 1);
+                buf_store_f4(m[4 * it], m[4 * it + 1], m[4 * it + 2], m[4 * it + 3], rs, col * 4, 0);
+            }
+        } else {
+            const int rk0 = lane & 15, ru = (lane >> 4) | (wave << 2);
+            const int rn3 = ru >> 4, rg = R3 == 4 ? (rn3 >> 1) + 2 * (rn3 & 1) : rn3;
+            const int voff = (q + D * (rk0 + 16 * (ru & 15) + 256 * rg)) * 4;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[s]), rs, voff, ((D * slot_bin(s)) ^ (N / 2)) * 4, RO_STORE_AUX);
         }
     };
 
-    bool have_prev = false;
-    int64_t prev_row = 0;
-    for (;;) {
-        double re[16], im[16];
-        // ---- samples and window of this sub-row; the fold (q is the same for the whole workgroup: one copy per q, the
-        // factors W_D^(r q) = (-i)^(r q (4 / D)) are then signs and swaps inside the FMAs)
-        {
-            const __amdgpu_buffer_rsrc_t rs_iq =
-                make_rsrc(iq + (a.first_row + row) * (int64_t)a.hop * S::BYTES, (unsigned)N * S::BYTES);
-            const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(a.window_k, (unsigned)N * 4);
-            if constexpr (D == 1) {
-                fold<LOGM, D, 0, FMT>(re, im, rs_iq, rs_w, t, has_gain, a.gain);
-            } else if constexpr (D == 2) {
-                if (q == 0) fold<LOGM, D, 0, FMT>(re, im, rs_iq, rs_w, t, has_gain, a.gain);
-                else fold<LOGM, D, 1, FMT>(re, im, rs_iq, rs_w, t, has_gain, a.gain);
-            } else {
-                if (q == 0) fold<LOGM, D, 0, FMT>(re, im, rs_iq, rs_w, t, has_gain, a.gain);
-                else if (q == 1) fold<LOGM, D, 1, FMT>(re, im, rs_iq, rs_w, t, has_gain, a.gain);
-                else if (q == 2) fold<LOGM, D, 2, FMT>(re, im, rs_iq, rs_w, t, has_gain, a.gain);
-                else fold<LOGM, D, 3, FMT>(re, im, rs_iq, rs_w, t, has_gain, a.gain);
-            }
-        }
-        // ---- the image of the sub-row before this one leaves while the samples arrive
-        if (have_prev) readout(prev_row);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(a.window_k, (unsigned)N * 4);
+    auto iq_rsrc = [&](int64_t r, bool valid) {
+        return make_rsrc(iq + (a.first_row + r) * (int64_t)a.hop * S::BYTES, valid ? (unsigned)N * S::BYTES : 0u);
+    };
+    Raw<PRE ? D : 1, FMT> raw;
+    if constexpr (PRE) raw_load<LOGM, D, FMT>(raw, iq_rsrc(row, true), rs_w, t);
 
-        // ---- pass 0
-        {
+    unsigned touch[D] = {};
+    for (;;) {
+        const int64_t next = row + row_step;
+        const bool has_next = next < xcd_end;
+#pragma unroll
+        for (int i = 0; i < D; ++i) asm volatile("" ::"v"(touch[i]));   // the "use" of the touches below (long complete)
+        // (nothing of the fold in front of this point: hoisted above the barrier and the read-out, its conversions hold
+        // the samples twice)
+        __builtin_amdgcn_sched_barrier(0);
+        double re[16], im[16];
+        // ---- the fold
+        if constexpr (PRE) {
+            fold_raw<LOGM, D, GAIN, FMT>(re, im, raw, rot);
+        } else {
+            fold_mem<LOGM, D, GAIN, FMT>(re, im, iq_rsrc(row, true), rs_w, fresh(), rot);
+        }
+        stamp(3);
+        // ---- pass 0, and the real parts leave for exchange 1
+        if constexpr (D == 1) {
+            TwC tw;
+            twisted16(re, im, tw);
+        } else {
             TwS tw;
             tw.load(tw0);
             twisted16(re, im, tw);
         }
-        wg_sync();                                      // (a) the old image has been read: LDS is free
-        // ---- exchange 1
         double xr[16], xi[16];
+        const int x1w = fresh();                         // exchange 1: writer cell n1 = t, reader cell k0 ST + u
+        const int x1r = (x1w / Q) * ST + x1w % Q;
 #pragma unroll
         for (int k = 0; k < 16; ++k) plane[x1w + k * ST] = re[brev<4>(k)];
+        stamp(4);
         wg_sync();                                      // (b)
+        [[maybe_unused]] TwS tw1s;                       // M = 16384: the wave is one k0, its pass-1 table entry in SGPRs
+        if constexpr (Q == 64) tw1s.load(tw1 + wave * 8);
 #pragma unroll
         for (int j = 0; j < 16; ++j) xr[j] = plane[x1r + Q * j];
+        stamp(5);
         wg_sync();                                      // (c) everyone has its real parts
 #pragma unroll
         for (int k = 0; k < 16; ++k) plane[x1w + k * ST] = im[brev<4>(k)];
+        stamp(6);
         wg_sync();                                      // (d)
 #pragma unroll
         for (int j = 0; j < 16; ++j) xi[j] = plane[x1r + Q * j];
         asm volatile("" ::: "memory");
+        // this thread from here on: (k0, u) in pass 1, (k0, k1, n3) in pass 2, g' = bitrev(n3) in pass 3
+        const int tr_ = fresh();
+        const int k0 = tr_ / Q, u = tr_ % Q, k1 = u & 15, n3 = u >> 4;
+        const int K1 = k0 + 16 * k1;
         // ---- pass 1.  From here to the completed image a wave touches its own territories only.
         if constexpr (Q == 64) {
-            TwS tw;                                      // the wave is one k0
-            tw.load(tw1 + wave * 8);
-            twisted16(xr, xi, tw);
+            twisted16(xr, xi, tw1s);
         } else {
             TwV tw;
             tw.load(tw1, 16, k0);
             twisted16(xr, xi, tw);
         }
+        stamp(7);
         // ---- exchange 2 (one wave's LDS instructions execute in order: no wait between its writes and its reads)
+        const int x2w = k0 * ST + u, x2r = k0 * ST + k1 * G::S2 + n3;
 #pragma unroll
         for (int k = 0; k < 16; ++k) plane[x2w + k * G::S2] = xr[brev<4>(k)];
         asm volatile("" ::: "memory");
@@ -375,36 +580,44 @@ template <int LOGM, int D, int FMT> __global__ __launch_bounds__((1 << LOGM) / 1
 #pragma unroll
         for (int j = 0; j < 16; ++j) im[j] = plane[x2r + R3 * j];
         asm volatile("" ::: "memory");
+        stamp(8);
         // ---- pass 2
         {
             TwV tw;
             tw.load(tw2, 256, K1);
             twisted16(re, im, tw);
         }
+        stamp(9);
         if constexpr (R3 > 1) {
-            // ---- exchange 3: slot k2 -> cell k2 S3 + u; thread g = n3 reads k2 = g + R3 i, all n3
+            // ---- exchange 3 without LDS: the R3 threads of one (k0, k1) sit 16 lanes apart, so a 2 x 2 transposition
+            // between a lane bit and a position bit is one v_permlane*_swap per dword
+            if constexpr (R3 == 4) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) plane[x3w + k * G::S3] = re[brev<4>(k)];
-            asm volatile("" ::: "memory");
+                for (int p = 0; p < 8; ++p) {
+                    lane_swap<5>(re[p], re[p + 8]);
+                    lane_swap<5>(im[p], im[p + 8]);
+                }
 #pragma unroll
-            for (int i = 0; i < 16 / R3; ++i)
+                for (int p = 0; p < 16; ++p)
+                    if (!(p & 4)) {
+                        lane_swap<4>(re[p], re[p + 4]);
+                        lane_swap<4>(im[p], im[p + 4]);
+                    }
+            } else {
 #pragma unroll
-                for (int m = 0; m < R3; ++m) xr[i * R3 + m] = plane[x3r + i * R3 * G::S3 + m];
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int k = 0; k < 16; ++k) plane[x3w + k * G::S3] = im[brev<4>(k)];
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < 16 / R3; ++i)
-#pragma unroll
-                for (int m = 0; m < R3; ++m) xi[i * R3 + m] = plane[x3r + i * R3 * G::S3 + m];
-            asm volatile("" ::: "memory");
-            // ---- pass 3: butterfly i has twist theta = a' W_16^i, a' = W_N^(q + D (K1 + 256 g)) (table: {a', a'^2})
+                for (int p = 0; p < 8; ++p) {
+                    lane_swap<4>(re[p], re[p + 8]);
+                    lane_swap<4>(im[p], im[p + 8]);
+                }
+            }
+            stamp(10);
+            // ---- pass 3: butterfly i has twist theta = a' W_16^i, a' = W_N^(q + D (K1 + 256 g')) (table: {a', a'^2})
             d2 a1, a2;
             {
+                const int gp = R3 == 4 ? (n3 >> 1) + 2 * (n3 & 1) : n3;
                 const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.tw3 + (int64_t)q * 256 * R3 * 2, 256 * R3 * 32);
-                const u32x4 c1 = __builtin_amdgcn_raw_buffer_load_b128(rs, (K1 * R3 + n3) * 32, 0, 0);
-                const u32x4 c2 = __builtin_amdgcn_raw_buffer_load_b128(rs, (K1 * R3 + n3) * 32, 16, 0);
+                const u32x4 c1 = __builtin_amdgcn_raw_buffer_load_b128(rs, (K1 * R3 + gp) * 32, 0, 0);
+                const u32x4 c2 = __builtin_amdgcn_raw_buffer_load_b128(rs, (K1 * R3 + gp) * 32, 16, 0);
                 a1 = (d2){__hiloint2double((int)c1.y, (int)c1.x), __hiloint2double((int)c1.w, (int)c1.z)};
                 a2 = (d2){__hiloint2double((int)c2.y, (int)c2.x), __hiloint2double((int)c2.w, (int)c2.z)};
             }
@@ -415,34 +628,72 @@ template <int LOGM, int D, int FMT> __global__ __launch_bounds__((1 << LOGM) / 1
 #pragma unroll
             for (int i = 0; i < 16 / R3; ++i) {
                 // theta = a1 (c - i s), c + i s = exp(2 pi i i / 16)
-                const double c = C16[i], s = S16[i];
-                const double tr = i == 0 ? a1.x : a1.x * c + a1.y * s, ti = i == 0 ? a1.y : a1.y * c - a1.x * s;
+                const double c = C16[i], sn = S16[i];
+                const double tr = i == 0 ? a1.x : a1.x * c + a1.y * sn, ti = i == 0 ? a1.y : a1.y * c - a1.x * sn;
                 if constexpr (R3 == 2) {
-                    bfly<0>(xr[2 * i], xi[2 * i], xr[2 * i + 1], xi[2 * i + 1], tr, ti);
+                    const int r = brev<3>(i);                       // inputs n3 = 0, 1 at positions r, 8 + r
+                    bfly<0>(re[r], im[r], re[8 + r], im[8 + r], tr, ti);
                 } else {
-                    // theta^2 = a2 W_8^i
+                    // inputs n3 at positions 8 (n3 >> 1) + 4 (n3 & 1) + 2 (i & 1) + (i >> 1); theta^2 = a2 W_8^i
+                    const int b = 2 * (i & 1) + (i >> 1);
                     const double c2 = C16[2 * i], s2 = S16[2 * i];
                     const double ur = i == 0 ? a2.x : a2.x * c2 + a2.y * s2, ui = i == 0 ? a2.y : a2.y * c2 - a2.x * s2;
-                    bfly<0>(xr[4 * i], xi[4 * i], xr[4 * i + 2], xi[4 * i + 2], ur, ui);
-                    bfly<0>(xr[4 * i + 1], xi[4 * i + 1], xr[4 * i + 3], xi[4 * i + 3], ur, ui);
-                    bfly<0>(xr[4 * i], xi[4 * i], xr[4 * i + 1], xi[4 * i + 1], tr, ti);
-                    bfly<1>(xr[4 * i + 2], xi[4 * i + 2], xr[4 * i + 3], xi[4 * i + 3], tr, ti);
+                    bfly<0>(re[b], im[b], re[b + 8], im[b + 8], ur, ui);                 // n3 = 0, 2
+                    bfly<0>(re[b + 4], im[b + 4], re[b + 12], im[b + 12], ur, ui);       // n3 = 1, 3
+                    bfly<0>(re[b], im[b], re[b + 4], im[b + 4], tr, ti);                 // n3 = 0, 1
+                    bfly<1>(re[b + 8], im[b + 8], re[b + 12], im[b + 12], tr, ti);       // n3 = 2, 3
                 }
             }
-            // ---- magnitudes into the image (own territory)
-#pragma unroll
-            for (int s = 0; s < 16; ++s) image[imw + Q * s] = magnitude(xr[s], xi[s]);
-        } else {
-#pragma unroll
-            for (int s = 0; s < 16; ++s) image[((s & 1) ? imw_odd : imw) + 16 * s] = magnitude(re[s], im[s]);
+            stamp(11);
         }
+        // ---- magnitudes into the image (own territory): cell 2 k0 ST + s Q + rot(u), see the header
+        int imw;
+        if constexpr (R3 == 1) imw = 2 * k0 * ST + ((u + 8 * (k0 >> 3)) & 15);       // + (s ^ ((k0 >> 2) & 1)) 16
+        else imw = 2 * k0 * ST + ((u + 2 * k0) & (Q - 1));                            // + s Q
+        const int imw_flip = R3 == 1 ? (k0 >> 2) & 1 : 0;
+        float mg[16];
+        magnitudes16(re, im, mg);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            if constexpr (R3 == 1) image[imw + 16 * (s ^ imw_flip)] = mg[s];
+            else image[imw + Q * s] = mg[s];
+        }
+        const float last = mg[15];
+        // The hop new samples of a later sub-row are touched (one dword per 128-byte line, value unused: it is "used" in front
+        // of the next fold) so that the requests below find them in L2: they come from HBM, every other byte of the row from
+        // L2.  Here, because loads return in order: behind this point nothing waits for a load before the next fold.
+        {
+            const int64_t far = PRE ? next + row_step : next;
+            if (far < xcd_end) {
+                const int64_t s0 = (a.first_row + far) * (int64_t)a.hop + (N - a.hop);
+                const __amdgpu_buffer_rsrc_t rs_new = make_rsrc(iq + s0 * S::BYTES, (unsigned)a.hop * S::BYTES);
+                const int tt = after(fresh(), last);
+#pragma unroll
+                for (int i = 0; i < D; ++i) touch[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_new, tt * 128, i * T * 128, 0);
+            }
+        }
+        stamp(12);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- the next sub-row's samples and window: asked for now, needed behind the barrier and the read-out.  (The
+        // requests may not start before the last magnitude exists: their registers are the transform's.)
+        if constexpr (PRE) raw_load<LOGM, D, FMT>(raw, iq_rsrc(has_next ? next : row, has_next), rs_w, after(fresh(), last));
         wg_sync();                                      // (e) the image of this sub-row is complete
-        have_prev = true;
-        prev_row = row;
-        row += row_step;
-        if (row >= xcd_end) break;
+        stamp(13);
+        // ---- the image: out of LDS, then LDS is free for the next sub-row's exchange, then on its way to the row
+        readout_lds();
+        stamp(0);
+        wg_sync();                                      // (a) the image has been read
+        stamp(1);
+        readout_store(row);
+        stamp(2);
+        if constexpr (RO_F64R_STAMPS) st_acc[15] += 1;
+        if (!has_next) break;
+        row = next;
     }
-    readout(prev_row);
+    if constexpr (RO_F64R_STAMPS) {
+        if (a.stamps && (t & 63) == 0)
+            for (int k = 0; k < 16; ++k) a.stamps[((size_t)blockIdx.x * (T / 64) + wave) * 16 + k] = st_acc[k];
+    }
 }
 
 template <int LOGM, int D, int FMT> static hipError_t launch_one(const Args &a, hipStream_t s)
@@ -459,8 +710,10 @@ template <int LOGM, int D, int FMT> static hipError_t launch_one(const Args &a, 
     {
         std::lock_guard<std::mutex> g(lock);
         if (!ready[dev]) {
-            const void *fn = reinterpret_cast<const void *>(&f64r_kernel<LOGM, D, FMT>);
-            if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES)) != hipSuccess) return e;
+            const void *fn[2] = {reinterpret_cast<const void *>(&f64r_kernel<LOGM, D, FMT, false>),
+                                 reinterpret_cast<const void *>(&f64r_kernel<LOGM, D, FMT, true>)};
+            for (int i = 0; i < 2; ++i)
+                if ((e = hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES)) != hipSuccess) return e;
             if ((e = hipDeviceGetAttribute(&cus_of[dev], hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
             ready[dev] = true;
         }
@@ -472,7 +725,9 @@ template <int LOGM, int D, int FMT> static hipError_t launch_one(const Args &a, 
     if (slots > per_xcd * D) slots = per_xcd * D;
     slots = slots / D * D;
     if (slots < D) slots = D;
-    hipLaunchKernelGGL((f64r_kernel<LOGM, D, FMT>), dim3((unsigned)(slots * 8)), dim3(G::T), G::LDS_BYTES, s, a);
+    // (the reference's "iq_gain" is 0 in every shipped config: the additions exist only in the kernel that needs them)
+    if (a.gain != 0.0) hipLaunchKernelGGL((f64r_kernel<LOGM, D, FMT, true>), dim3((unsigned)(slots * 8)), dim3(G::T), G::LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((f64r_kernel<LOGM, D, FMT, false>), dim3((unsigned)(slots * 8)), dim3(G::T), G::LDS_BYTES, s, a);
     return hipGetLastError();
 }
 
@@ -578,6 +833,7 @@ hipError_t launch_f64reg(int bins, int fmt, const F64RegArgs &a, hipStream_t s)
     b.row_stride = a.row_stride;
     b.hop = a.hop;
     b.gain = a.gain;
+    b.stamps = a.stamps;
     if (fmt == RO_FMT_F32) return f64r::launch_fmt<RO_FMT_F32>(m_log2, dec, b, s);
     if (fmt == RO_FMT_I16) return f64r::launch_fmt<RO_FMT_I16>(m_log2, dec, b, s);
     return hipErrorInvalidValue;

@@ -115,6 +115,7 @@ struct F64RegArgs {
     int64_t        first_row, rows, row_stride;
     int            hop;
     double         gain;
+    unsigned long long *stamps; // diagnostic builds only (RO_F64R_STAMPS), else nullptr
 };
 bool       f64reg_supported(int bins);           // 4096 ... 65536
 void       f64reg_tables(int bins, const float *window, F64RegTables &t);
