@@ -32,7 +32,7 @@ extern "C" {
 #define RO_ERR_NOMEM       (-4)
 #define RO_ERR_STATE       (-5)   /* call not valid in the handle's current state */
 
-#define RO_ABI_VERSION 4
+#define RO_ABI_VERSION 5
 
 /* window function; the reference hard-codes the 4-term Nuttall
  * (src/FFTBackend.cpp:165-184) and keeps Hann as dead code (:157-163). */
@@ -50,15 +50,14 @@ enum { RO_IQ_F32 = 0, RO_IQ_I16 = 1, RO_IQ_F64 = 2 };
  *  F32: float32 butterflies on float32 samples -- the fast path; rows within 1e-5 of the ROW MAXIMUM of the
  *       reference's double-precision rows (measured 1-3e-7), which is the norm-wise reading of "1e-5 relative".
  *  F64: the reference's own arithmetic type -- double window multiply, double transform, double sqrt, one
- *       narrowing to the float row (src/FFTBackend.cpp:117-120,229-236, src/WaterfallBackend.cpp:492-505) -- as a
- *       multi-pass transform through HBM scratch.  Rows within 1e-5 of the reference PER BIN (measured ~1e-12 at
- *       60 dB of dynamic range); several times slower.  Complex-spectra output is F32 only.
- *  F64_ONE_LAUNCH: F64's arithmetic and bits with all four passes of a row in ONE persistent launch, the
- *       complex-double intermediate handed between workgroups of one XCD through that XCD's L2 (8192 ... 65536
- *       bins; other sizes run as F64).  Measured SLOWER than F64's two launches (profiles/r05_f64_one_launch.txt:
- *       the L2 keeps the hand-off only while at most two rows per XCD are in flight); kept selectable for that
- *       record and its tests, never a default. */
-enum { RO_PRECISION_F32 = 0, RO_PRECISION_F64 = 1, RO_PRECISION_F64_ONE_LAUNCH = 2 };
+ *       narrowing to the float row (src/FFTBackend.cpp:117-120,229-236, src/WaterfallBackend.cpp:492-505).  Bins
+ *       4096 ... 65536 keep the complex-double row in a compute unit's registers (samples read once, row written
+ *       once); the other powers of two are passes through HBM scratch.  Rows within 1e-5 of the reference PER BIN
+ *       (measured <= 1.2e-7: one float32 ulp, at 60 dB of dynamic range); 2.5 times slower than F32 at 32768 bins.
+ *       Complex-spectra output is F32 only.
+ *  (Value 2 was ABI 4's RO_PRECISION_F64_ONE_LAUNCH, an experiment that measured slower; ro_stft_create answers
+ *  RO_ERR_UNSUPPORTED for it.) */
+enum { RO_PRECISION_F32 = 0, RO_PRECISION_F64 = 1 };
 
 /* bin ranges of BolidRecorder::start (src/BolidRecorder.cpp:84-102), in
  * fft-shifted row columns. */
@@ -165,6 +164,15 @@ int     ro_allgather_rows(void *nccl_comm, const void *d_local, int64_t local_ro
  * Asynchronous on `stream`. */
 int     ro_allgather_rows_direct(void *nccl_comm, const void *d_local, int64_t local_rows, int64_t total_rows, int world,
                                  int rank, size_t row_bytes, void *d_out, void *stream);
+/* The schedule of that direct exchange, one step of it: in step k (1 .. world - 1) rank `rank` sends its own rows to
+ * *to = (rank + k) mod world and receives the rows of *from = (rank - k) mod world, which are rows
+ * [*recv_first_row, +*recv_rows) of the stitched result -- every ordered pair of ranks meets in exactly one step, and
+ * in every step every rank sends once and receives once (each xGMI link pair is used once per step).  k = 0 is the
+ * rank's own copy (to = from = rank).  ro_allgather_rows_direct, ro_gather_rows (root: every step's receive; the
+ * others: the one step whose `to` is the root) and timeshard.gather_rows_direct all walk this one function.
+ * Pure host arithmetic. */
+int     ro_direct_schedule(int world, int rank, int64_t total_rows, int k, int *to, int *from,
+                           int64_t *recv_first_row, int64_t *recv_rows);
 /* The same exchange when only ONE rank consumes the rows -- the reference's FITS writer and detector are one process
  * (src/WaterfallBackend.cpp:141-211, src/BolidRecorder.cpp:171-273): every rank sends its local_rows x row_bytes
  * straight to `root` (ncclSend / ncclRecv in one group: world - 1 transfers over world - 1 different links), where

@@ -18,7 +18,7 @@ from .capi import (  # noqa: F401
     row_count, window_table, bins_supported, device_count, shard_rows, shard_samples, shard_max_rows,
     stitch_rows, ln_levels,
     RO_WINDOW_NUTTALL, RO_WINDOW_HANN, RO_WINDOW_CUSTOM, RO_IQ_F32, RO_IQ_I16, RO_IQ_F64,
-    RO_PRECISION_F32, RO_PRECISION_F64, RO_PRECISION_F64_ONE_LAUNCH,
+    RO_PRECISION_F32, RO_PRECISION_F64,
 )
 
 def sharding():

@@ -10,8 +10,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libro_stft.so")
-SOURCES = ["ro_kernels.hip", "ro_stft32k.hip", "ro_fourstep.hip", "ro_f64fused.hip", "ro_f64reg.hip", "ro_stft_capi.cpp"]
-HEADERS = ["ro_kernels.h", "ro_fft_device.h", "ro_fft_planar.h", "ro_k32_lds.h", "ro_device_util.h", "ro_f64_device.h", "ro_narrow.h", os.path.join("..", "..", "include", "ro_stft.h")]
+SOURCES = ["ro_kernels.hip", "ro_stft32k.hip", "ro_fourstep.hip", "ro_f64reg.hip", "ro_stft_capi.cpp", "ro_abi_helpers.cpp",
+           "ro_exchange.cpp", "ro_stream.cpp", "ro_czt.cpp"]
+HEADERS = ["ro_kernels.h", "ro_host.h", "ro_fft_device.h", "ro_fft_planar.h", "ro_k32_lds.h", "ro_device_util.h", "ro_f64_device.h", "ro_narrow.h", os.path.join("..", "..", "include", "ro_stft.h")]
 
 # -fno-slp-vectorize: the SLP vectoriser turns the twiddle multiplies into v_pk_* ops whose
 # constant operands must sit in VGPR pairs; that costs ~28 VGPRs and makes the 1024-thread

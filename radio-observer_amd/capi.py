@@ -13,7 +13,7 @@ from . import build as _build
 
 RO_WINDOW_NUTTALL, RO_WINDOW_HANN, RO_WINDOW_CUSTOM = 0, 1, 2
 RO_IQ_F32, RO_IQ_I16, RO_IQ_F64 = 0, 1, 2
-RO_PRECISION_F32, RO_PRECISION_F64, RO_PRECISION_F64_ONE_LAUNCH = 0, 1, 2
+RO_PRECISION_F32, RO_PRECISION_F64 = 0, 1
 
 RO_OK = 0
 _ERR_NAMES = {-1: "RO_ERR_INVALID", -2: "RO_ERR_UNSUPPORTED", -3: "RO_ERR_HIP", -4: "RO_ERR_NOMEM",
@@ -76,6 +76,8 @@ _EXPORTS = {
                                    C.POINTER(C.c_int64)]),
     "ro_shard_max_rows": (C.c_int64, [C.c_int64, C.c_int]),
     "ro_stitch_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_void_p]),
+    "ro_direct_schedule": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                     C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ro_allgather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_size_t,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "ro_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_size_t,
@@ -256,6 +258,14 @@ def shard_max_rows(total_rows, world):
     if n < 0:
         _check(int(n))
     return int(n)
+
+
+def direct_schedule(world, rank, total_rows, k):
+    """(to, from, recv_first_row, recv_rows) of step k of the direct exchange -- ro_direct_schedule"""
+    to, frm = C.c_int(), C.c_int()
+    f, n = C.c_int64(), C.c_int64()
+    _check(library().ro_direct_schedule(world, rank, int(total_rows), k, C.byref(to), C.byref(frm), C.byref(f), C.byref(n)))
+    return to.value, frm.value, f.value, n.value
 
 
 def stitch_rows(gathered, total_rows, world):

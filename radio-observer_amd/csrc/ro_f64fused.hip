@@ -35,6 +35,9 @@
 // two rows in flight (16.3 B per point across the fabric instead of 38.7), but its 32 CUs hold four, and at that ring
 // only the read side is saved (28.4); this first version also spends ~18k cycles per tile where arithmetic is ~3.5k.
 // Selectable as RO_PRECISION_F64_ONE_LAUNCH; RO_PRECISION_F64 runs f64_pair_kernel.
+// ROUND 5 EXPERIMENT, measured slower than the two launches it replaces (profiles/r05_f64_one_launch.txt): compiled in
+// -DRO_DIAG=1 builds only (tools/ab_build.sh), not part of the product library.
+#ifdef RO_DIAG
 #include "ro_kernels.h"
 #include "ro_f64_device.h"
 
@@ -282,3 +285,4 @@ hipError_t launch_f64_fused(int fmt, const BigArgsD &a, double2 *ring, unsigned 
 }
 
 }  // namespace ro
+#endif  // RO_DIAG

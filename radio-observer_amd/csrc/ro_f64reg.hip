@@ -50,6 +50,22 @@
 #define RO_F64R_SQRT_EXACT 0
 #endif
 
+// Between barrier (d) and barrier (e) a wave is on its own for two thirds of the sub-row's work, and the arbiter serves the
+// oldest wave of a SIMD first: the youngest finishes last and runs its last passes alone, at half the FP64 issue rate
+// one wave gets.  1: a wave's priority falls as it gets through the stretch (pass 1: 3, pass 2: 2, pass 3: 1,
+// magnitudes: 0), so the waves of a SIMD arrive together.  Measured (tools/r6/f64r_ab.sh, profiles/r06_f64r_ab.txt):
+// 2-4 % SLOWER at M = 16384 (the magnitudes then wait behind everything), 2 % faster at M = 4096: off.
+#ifndef RO_F64R_PRIO
+#define RO_F64R_PRIO 0
+#endif
+
+// Cache policy of the 4-byte row stores at D > 1 (a sub-row owns every D-th column: the D workgroups of a row write the
+// same lines a few microseconds apart and the line should wait for all of them in L2): gfx950 aux bits, 0 = default,
+// 2 = nt like every other row store of the library.
+#ifndef RO_F64R_STORE_AUX_D
+#define RO_F64R_STORE_AUX_D 0
+#endif
+
 // The ONE diagnostic switch of this file.  A -DRO_DIAG=1 build (tools/ab_build.sh) may set RO_F64R_STAMPS=1: s_memtime
 // deltas per phase of the sub-row loop, every wave of every workgroup, accumulated into Args::stamps
 // (tools/r6/f64r_stamps.py).  Never timed, never shipped.
@@ -170,6 +186,10 @@ struct TwV {
         load4<4>();
     }
 };
+template <int P> __device__ __forceinline__ void set_prio()
+{
+    if constexpr (RO_F64R_PRIO) __builtin_amdgcn_s_setprio(P);
+}
 struct TwS {
     d2 t[8];
     __device__ __forceinline__ double re(int i) const { return t[i].x; }
@@ -207,21 +227,26 @@ struct TwC {
 __device__ __forceinline__ void magnitudes16(const double *re, const double *im, float *out)
 {
     double s[16];
-    bool odd = false;
+    float sf[16];
+    float lo = __builtin_inff(), hi = 0.f;            // (float min / max: 32-bit operations; a NaN fails both tests below)
+    bool nan = false;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         s[i] = __builtin_fma(im[i], im[i], re[i] * re[i]);
-        odd = odd || !(s[i] > 0x1p-100 && s[i] < 0x1p100);
+        sf[i] = (float)s[i];
+        lo = __builtin_fminf(lo, sf[i]);
+        hi = __builtin_fmaxf(hi, sf[i]);
+        nan = nan || sf[i] != sf[i];
     }
+    const bool odd = nan || !(lo > 0x1p-100f && hi < 0x1p100f);
     if (RO_F64R_SQRT_EXACT || __builtin_amdgcn_ballot_w64(odd) != 0) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) out[i] = (float)sqrt(s[i]);
     } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float sf = (float)s[i];
-            const float y = __builtin_amdgcn_rsqf(sf);
-            const float r = sf * y;
+            const float y = __builtin_amdgcn_rsqf(sf[i]);
+            const float r = sf[i] * y;
             const double rd = (double)r;
             const float e = (float)__builtin_fma(-rd, rd, s[i]);
             out[i] = __builtin_fmaf(e * y, 0.5f, r);
@@ -496,7 +521,7 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
             const int voff = (q + D * (rk0 + 16 * (ru & 15) + 256 * rg)) * 4;
 #pragma unroll
             for (int s = 0; s < 16; ++s)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[s]), rs, voff, ((D * slot_bin(s)) ^ (N / 2)) * 4, RO_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[s]), rs, voff, ((D * slot_bin(s)) ^ (N / 2)) * 4, RO_F64R_STORE_AUX_D);
         }
     };
 
@@ -553,6 +578,7 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
 #pragma unroll
         for (int j = 0; j < 16; ++j) xi[j] = plane[x1r + Q * j];
         asm volatile("" ::: "memory");
+        set_prio<3>();
         // this thread from here on: (k0, u) in pass 1, (k0, k1, n3) in pass 2, g' = bitrev(n3) in pass 3
         const int tr_ = fresh();
         const int k0 = tr_ / Q, u = tr_ % Q, k1 = u & 15, n3 = u >> 4;
@@ -566,7 +592,11 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
             twisted16(xr, xi, tw);
         }
         stamp(7);
-        // ---- exchange 2 (one wave's LDS instructions execute in order: no wait between its writes and its reads)
+        set_prio<2>();
+        // ---- exchange 2 (one wave's LDS instructions execute in order: no wait between its writes and its reads); the first
+        // half of pass 2's table entry is asked for in front of it
+        TwV tw2v;
+        tw2v.load(tw2, 256, K1);
         const int x2w = k0 * ST + u, x2r = k0 * ST + k1 * G::S2 + n3;
 #pragma unroll
         for (int k = 0; k < 16; ++k) plane[x2w + k * G::S2] = xr[brev<4>(k)];
@@ -582,11 +612,8 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
         asm volatile("" ::: "memory");
         stamp(8);
         // ---- pass 2
-        {
-            TwV tw;
-            tw.load(tw2, 256, K1);
-            twisted16(re, im, tw);
-        }
+        twisted16(re, im, tw2v);
+        set_prio<1>();
         stamp(9);
         if constexpr (R3 > 1) {
             // ---- exchange 3 without LDS: the R3 threads of one (k0, k1) sit 16 lanes apart, so a 2 x 2 transposition
@@ -646,6 +673,7 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
             }
             stamp(11);
         }
+        set_prio<0>();
         // ---- magnitudes into the image (own territory): cell 2 k0 ST + s Q + rot(u), see the header
         int imw;
         if constexpr (R3 == 1) imw = 2 * k0 * ST + ((u + 8 * (k0 >> 3)) & 15);       // + (s ^ ((k0 >> 2) & 1)) 16

@@ -121,6 +121,8 @@ bool       f64reg_supported(int bins);           // 4096 ... 65536
 void       f64reg_tables(int bins, const float *window, F64RegTables &t);
 hipError_t launch_f64reg(int bins, int fmt, const F64RegArgs &a, hipStream_t s);
 
+#ifdef RO_DIAG
+// (diagnostic builds only: round 5's experiment, not in the product library)
 // all four passes of a row in one persistent launch, the intermediate in one XCD's L2 (ro_f64fused.hip):
 // bins = 16 x 16 x 16 x r2.  ring = 8 x ring_rows x n complex doubles, ctl = f64_fused_ctl_bytes() bytes (zeroed by the
 // launch); a.in / a.out / a.ns are not used.  ctl word [1] != 0 after the launch: a bounded wait gave up.
@@ -128,6 +130,7 @@ bool       f64_fused_supported(int bins);
 size_t     f64_fused_ctl_bytes();
 int        f64_fused_max_ring_rows();
 hipError_t launch_f64_fused(int fmt, const BigArgsD &a, double2 *ring, unsigned *ctl, int ring_rows, int wgs_per_cu, hipStream_t s);
+#endif
 
 // ---- large transforms as a four-step FFT (bins = n1 x 1024), ro_fourstep.hip
 struct FourArgs {

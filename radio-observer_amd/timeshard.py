@@ -92,8 +92,9 @@ def gather_rows(local, total_rows, group=None, async_op=False, root=None):
 def gather_rows_direct(local, total_rows, group=None, out=None):
     """The all-gather as a DIRECT exchange (xGMI is point to point): every rank sends its rows to each peer
     and receives each peer's rows at their stitched place -- the torch.distributed form of ro_allgather_rows_direct
-    (same schedule: to rank + k, from rank - k, k = 1 .. world - 1, one batch of point-to-point operations).  No
-    padding, no stitch.  Returns [total_rows, C] in row order (written into `out` when given)."""
+    (the SAME schedule, step by step out of ro_direct_schedule: to rank + k, from rank - k, k = 1 .. world - 1, one batch
+    of point-to-point operations).  No padding, no stitch.  Returns [total_rows, C] in row order (written into `out`
+    when given)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     shards = all_shards(total_rows, world)
@@ -105,8 +106,7 @@ def gather_rows_direct(local, total_rows, group=None, out=None):
     out[first:first + mine].copy_(src)
     ops = []
     for k in range(1, world):
-        to, frm = (rank + k) % world, (rank - k) % world
-        f, n = shards[frm]
+        to, frm, f, n = capi.direct_schedule(world, rank, total_rows, k)
         if mine > 0:
             ops.append(dist.P2POp(dist.isend, src, to, group))
         if n > 0:

@@ -27,7 +27,11 @@ def test_header_symbols_are_exported(ro):
         assert hasattr(lib, n), "libro_stft.so does not export %s" % n
     # and the binding covers exactly the header
     assert sorted(ro.capi.exported_symbols()) == names
-    assert lib.ro_abi_version() == 4
+    assert lib.ro_abi_version() == 5
+    # nothing undeclared: every ro_* the library exports is in the header (diagnostic hooks live in -DRO_DIAG=1 builds only)
+    out = subprocess.run(["nm", "-D", "--defined-only", ro.capi.library_path()], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(re.findall(r" T (ro_[a-z0-9_]+)$", out, flags=re.M)))
+    assert exported == names, sorted(set(exported) ^ set(names))
 
 
 def test_struct_layouts(ro):
@@ -79,7 +83,7 @@ def test_config_is_validated_before_any_device_work(ro):
     for kw, code in ((dict(bins=1001), -2), (dict(bins=1000, precision=1), -2), (dict(bins=1024, iq_phase_shift=1), -2),
                      (dict(bins=1024, sample_rate=0), -1), (dict(bins=1024, spare_cus_per_xcd=17), -1),
                      (dict(bins=1024, spare_cus_per_xcd=-1), -1), (dict(bins=1024, precision=3), -1),
-                     (dict(bins=1000, precision=2), -2)):
+                     (dict(bins=1000, precision=2), -2), (dict(bins=32768, precision=2), -2)):   # 2: the retired one-launch form
         with pytest.raises(ro.StftError) as e:
             ro.Stft(**kw)
         assert e.value.code == code, (kw, str(e.value))
@@ -96,6 +100,45 @@ def test_config_is_validated_before_any_device_work(ro):
     assert rc in (0, -3), rc                                 # RO_OK on a GPU box, RO_ERR_HIP here
     if rc == 0:
         ro.library().ro_stft_destroy(h)
+
+
+def test_direct_schedule_is_a_perfect_exchange(ro):
+    """ro_direct_schedule (the one schedule ro_allgather_rows_direct, ro_gather_rows and timeshard.gather_rows_direct walk):
+    for every world and row count, every rank receives every other rank's rows exactly once at their stitched place, every
+    send of a step is matched by a receive of the SAME step, and in every step every rank sends once and receives once."""
+    for world in (1, 2, 3, 7, 8):
+        for total in (0, 7, 168747):
+            shards = [ro.capi.shard_rows(total, world, g) for g in range(world)]
+            assert sum(n for _, n in shards) == total
+            got = [dict() for _ in range(world)]                 # rank -> {first_row: rows} it receives
+            for k in range(0 if world == 1 else 1, world):
+                step = [ro.capi.direct_schedule(world, r, total, k) for r in range(world)]
+                assert sorted(s[0] for s in step) == list(range(world))       # every rank is sent to once
+                assert sorted(s[1] for s in step) == list(range(world))       # ... and sent from once
+                for r, (to, frm, f, n) in enumerate(step):
+                    assert to == (r + k) % world and frm == (r - k) % world
+                    assert step[frm][0] == r                                   # my source sends to me in this very step
+                    assert (f, n) == shards[frm]                               # ... and what arrives is its shard, in place
+                    if k > 0 and n > 0:
+                        assert f not in got[r]                                 # ... once
+                        got[r][f] = n
+            for r in range(world):
+                want = {f: n for g, (f, n) in enumerate(shards) if g != r}
+                if world > 1:
+                    assert {f: n for f, n in got[r].items() if n} == {f: n for f, n in want.items() if n}
+            # the gather to one rank: the root receives every step, rank r sends in the step whose `to` is the root
+            for root in range(world):
+                for r in range(world):
+                    if r != root:
+                        ks = [k for k in range(1, world) if ro.capi.direct_schedule(world, r, total, k)[0] == root]
+                        assert ks == [(root - r) % world]
+                        assert ro.capi.direct_schedule(world, root, total, ks[0])[1] == r
+    lib = ro.library()
+    z = C.c_int()
+    z64 = C.c_int64()
+    assert lib.ro_direct_schedule(4, 4, 10, 1, C.byref(z), C.byref(z), C.byref(z64), C.byref(z64)) == -1
+    assert lib.ro_direct_schedule(4, 0, 10, 4, C.byref(z), C.byref(z), C.byref(z64), C.byref(z64)) == -1
+    assert lib.ro_direct_schedule(4, 0, 10, 1, None, C.byref(z), C.byref(z64), C.byref(z64)) == -1
 
 
 def test_no_cpu_fallback(ro):

@@ -5,7 +5,10 @@ The bar here is the PER-BIN reading of north_star's "1e-5 relative on spectral m
 |row_gpu[k] - row_oracle[k]| <= 1e-5 * row_oracle[k] for every bin k of every row, which float32 butterflies miss on
 bins 60 dB under a carrier (tests/test_gpu_stft.py::test_c3_carrier_60db prints that) and the FP64 mode meets with
 seven orders of magnitude to spare.  The oracle's transform is an FP64 radix-2 FFT; two correct double transforms
-differ by a few 1e-16 of the row maximum, so most float rows come out bit-identical."""
+differ by a few 1e-16 of the row maximum, so most float rows come out bit-identical.
+
+Bins 4096 ... 65536 run csrc/ro_f64reg.hip (the complex-double row in a CU's registers), the other powers of two the
+passes through HBM scratch (ro_kernels.hip)."""
 import numpy as np
 import pytest
 
@@ -111,49 +114,50 @@ def test_scan_records_and_tile_in_strict_mode(ro, oracle, torch_cuda):
     assert np.array_equal(rec["peak"], p) and np.array_equal(rec["noise"], n) and np.array_equal(rec["average"], a)
 
 
-def test_one_launch_form_many_rows_and_any_split(ro, oracle, torch_cuda):
-    """RO_PRECISION_F64_ONE_LAUNCH: bins = 16^3 r2 run all four passes in ONE persistent launch, a row's complex-double intermediate handed from the
-    workgroups of its first two passes to those of its last two through the L2 of the XCD they share
-    (csrc/ro_f64fused.hip).  Enough rows that every workgroup draws many tickets and every ring slot is reused dozens of
-    times: every bin of every row against the oracle (any stale or torn hand-off is a wrong bin), and the same bits
-    whatever the launch's row range (rows are handed out dynamically: row r must not depend on who made it)."""
+@pytest.mark.parametrize("bins,overlap,R", [(4096, 2048, 5000), (8192, 6144, 1500), (16384, 12288, 900), (32768, 24576, 1500),
+                                            (65536, 49152, 300)])
+def test_register_form_many_rows_and_any_split(ro, oracle, torch_cuda, bins, overlap, R):
+    """f64r_kernel is persistent: a workgroup takes many sub-rows in a row, the samples of the next one requested while
+    the image of this one is still in LDS, and the D sub-rows of a stream row come from D workgroups.  Enough rows that
+    every workgroup loops many times: every bin of every row against the oracle, and the same bits whatever the launch's
+    row range (uneven cuts: first rows of an XCD's run, a single row, a launch smaller than the grid)."""
     torch = torch_cuda
-    bins, overlap, R = 32768, 24576, 1500
     hop = bins - overlap
-    rng = np.random.default_rng(0xF64)
+    rng = np.random.default_rng(bins + R)
     iq = add_tone(noise_iq(rng, bins + (R - 1) * hop), 10600.0, 30.0)
-    got = strict_rows(ro, torch, iq, bins, overlap, precision=ro.RO_PRECISION_F64_ONE_LAUNCH)
+    got = strict_rows(ro, torch, iq, bins, overlap)
     want = oracle.stft(iq, bins, overlap)
     assert per_bin(got, want).max() <= 2e-7
-    assert np.array_equal(got, strict_rows(ro, torch, iq, bins, overlap))          # the two-launch form: the same bits
     d_iq = torch.from_numpy(iq).cuda()
-    with ro.Stft(bins=bins, overlap=overlap, precision=ro.RO_PRECISION_F64_ONE_LAUNCH) as st:
+    with ro.Stft(bins=bins, overlap=overlap, precision=ro.RO_PRECISION_F64) as st:
         s = torch.cuda.current_stream().cuda_stream
-        for first, n in ((0, 1), (1, 7), (8, 700), (708, R - 708)):
-            part = torch.full((n, bins), float("nan"), dtype=torch.float32, device="cuda")
-            st.run_resident(d_iq, ro.RO_IQ_F32, iq.shape[0], first, n, part, stream=s)
+        cuts = ((0, 1), (1, 7), (8, R // 2), (8 + R // 2, R - 8 - R // 2))
+        for first, n in cuts:
+            part = torch.full((n, bins + 3), float("nan"), dtype=torch.float32, device="cuda")     # (a padded row stride too)
+            st.run_resident(d_iq, ro.RO_IQ_F32, iq.shape[0], first, n, part, row_stride=bins + 3, stream=s)
             torch.cuda.synchronize()
-            assert np.array_equal(part.cpu().numpy(), got[first:first + n])
+            p = part.cpu().numpy()
+            assert np.array_equal(p[:, :bins], got[first:first + n])
+            assert np.isnan(p[:, bins:]).all()                  # nothing written beside the rows
 
 
-def test_one_launch_form_beside_another_kernel(ro, oracle, torch_cuda):
-    """The hand-offs must not depend on all workgroups being resident or evenly placed: the same launch while the
-    float32 transform of another handle keeps the CUs busy on a second stream (workgroups of the FP64 launch start
-    late and unevenly over the XCDs), three sizes; every bin against the oracle."""
+def test_register_form_beside_another_kernel(ro, oracle, torch_cuda):
+    """the persistent grid assumes nothing about residency or placement: the same launches while the float32 transform of
+    another handle keeps the CUs busy on a second stream; every bin against the oracle."""
     torch = torch_cuda
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(78)
     busy_bins, busy_rows = 32768, 4096
     busy_iq = torch.from_numpy(noise_iq(rng, busy_bins + 8192 * (busy_rows - 1))).cuda()
     busy_out = torch.empty((busy_rows, busy_bins), dtype=torch.float32, device="cuda")
     side = torch.cuda.Stream()
     with ro.Stft(bins=busy_bins, overlap=24576) as busy:
-        for bins, overlap, R in ((32768, 24576, 600), (8192, 4096, 900), (65536, 49152, 200)):
+        for bins, overlap, R in ((32768, 24576, 600), (4096, 2048, 3000), (65536, 49152, 200)):
             hop = bins - overlap
             iq = add_tone(noise_iq(rng, bins + (R - 1) * hop), 7000.0, 300.0)
             d_iq = torch.from_numpy(iq).cuda()
             out = torch.full((R, bins), float("nan"), dtype=torch.float32, device="cuda")
             torch.cuda.synchronize()
-            with ro.Stft(bins=bins, overlap=overlap, precision=ro.RO_PRECISION_F64_ONE_LAUNCH) as st:
+            with ro.Stft(bins=bins, overlap=overlap, precision=ro.RO_PRECISION_F64) as st:
                 for _ in range(3):
                     busy.run_resident(busy_iq, ro.RO_IQ_F32, busy_iq.shape[0], 0, busy_rows, busy_out, stream=side.cuda_stream)
                 st.run_resident(d_iq, ro.RO_IQ_F32, iq.shape[0], 0, R, out, stream=torch.cuda.current_stream().cuda_stream)
@@ -164,15 +168,23 @@ def test_one_launch_form_beside_another_kernel(ro, oracle, torch_cuda):
             assert per_bin(out.cpu().numpy(), want).max() <= 2e-7, bins
 
 
-def test_one_launch_form_int16_gain_and_custom_window(ro, oracle, torch_cuda):
-    """the one-launch form's first half takes the WAV format too (int16 frames, un-normalised), the I/Q gain and a caller's
-    window: every bin against the oracle, and the two-launch form's bits"""
-    bins, overlap = 8192, 6144
+@pytest.mark.parametrize("bins", [4096, 16384, 32768, 65536])
+def test_register_form_int16_gain_and_custom_window(ro, oracle, torch_cuda, bins):
+    """int16 frames (un-normalised, WAVStream), the I/Q gain (its own kernel instantiation) and a caller's window; magnitudes
+    beyond float32's range of squares take the plain square root (the fast one works on float(re^2 + im^2))"""
+    overlap = bins - bins // 8
     rng = np.random.default_rng(5)
-    i16 = rng.integers(-20000, 20000, size=(bins + 40 * 2048, 2), dtype=np.int16)
+    i16 = rng.integers(-20000, 20000, size=(bins + 40 * (bins // 8), 2), dtype=np.int16)
     w = rng.random(bins).astype(np.float32)
-    got = strict_rows(ro, torch_cuda, i16, bins, overlap, fmt=ro.RO_IQ_I16, precision=ro.RO_PRECISION_F64_ONE_LAUNCH,
-                      window_table=w, iq_gain=-77.25)
+    got = strict_rows(ro, torch_cuda, i16, bins, overlap, fmt=ro.RO_IQ_I16, window_table=w, iq_gain=-77.25)
     want = oracle.stft(i16.astype(np.float64), bins, overlap, w=w, gain=-77.25)
     assert per_bin(got, want).max() <= 2e-7
-    assert np.array_equal(got, strict_rows(ro, torch_cuda, i16, bins, overlap, fmt=ro.RO_IQ_I16, window_table=w, iq_gain=-77.25))
+    # huge and tiny samples: re^2 + im^2 leaves the range where its float is a normal number with headroom
+    for scale in (1e17, 1e-17, 0.0):
+        iq = (noise_iq(np.random.default_rng(7), bins + 3 * (bins // 8)) * scale).astype(np.float32)
+        got = strict_rows(ro, torch_cuda, iq, bins, overlap)
+        want = oracle.stft(iq, bins, overlap)
+        assert np.isfinite(got).all()
+        ok = want > 0
+        assert per_bin(got[ok], want[ok]).max() <= 2e-7 if ok.any() else True
+        assert np.array_equal(got[~ok], want[~ok])

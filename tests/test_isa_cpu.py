@@ -13,7 +13,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SOURCES = [os.path.join(ROOT, "radio-observer_amd", "csrc", f) for f in ("ro_kernels.hip", "ro_stft32k.hip", "ro_fourstep.hip", "ro_f64fused.hip")]
+SOURCES = [os.path.join(ROOT, "radio-observer_amd", "csrc", f) for f in ("ro_kernels.hip", "ro_stft32k.hip", "ro_fourstep.hip", "ro_f64reg.hip")]
 
 
 def compile_isa(dirname, sources, extra=()):
@@ -82,6 +82,21 @@ def test_lds_traffic_between_consecutive_barriers(isa):
                 # a branch between two barriers (stft32k_kernel's image-complete barrier sits in both arms of "has work
                 # on the image or not"): what follows in the text is not what follows in time
                 seen = False
+
+
+def test_f64r_kernels(isa):
+    """the register-resident FP64 kernel: five plans x two sample formats x {no gain, gain}; exchange 3 is lane swaps, not
+    LDS (M = 8192: v_permlane16_swap, M = 16384: both); 128 VGPRs at the most (16 waves per CU)"""
+    ks = {k: b for k, b in kernels(isa).items() if "f64r_kernel" in k}
+    assert len(ks) == 20
+    for name, body in ks.items():
+        text = "\n".join(body)
+        logm = int(re.search(r"f64r_kernelILi(\d+)E", name).group(1))
+        n32, n16 = text.count("v_permlane32_swap"), text.count("v_permlane16_swap")
+        assert (n32, n16) == {12: (0, 0), 13: (0, 32), 14: (32, 32)}[logm], (name, n32, n16)
+        assert text.count("s_barrier") == 5, name
+    vg = dict(re.findall(r"\.name:\s*(\S*f64r_kernel\S*)[\s\S]*?\.vgpr_count:\s*(\d+)", isa))
+    assert len(vg) == 20 and max(int(v) for v in vg.values()) <= 128, vg
 
 
 def test_addtid_writes_are_waited_for_before_the_barrier(isa):

@@ -44,3 +44,17 @@ def test_the_general_form_agrees_at_32_points_per_wave_column():
     out = run("emu_wl.py", "32")
     assert "S=32 read-back = fft-shifted row; conflict-free: True" in out
     assert "S=32 closed-form image address: True; LDS bytes 131200" in out
+
+
+def test_f64r_maps_reproduce_the_fft_without_bank_conflicts():
+    """tools/r6/emu_f64r.py: the register-resident FP64 kernel (csrc/ro_f64reg.hip) -- twisted radix-16 butterflies with merged
+    twiddles, every thread map, exchange cell, lane swap, table index and read-out column for each (M, D) the library
+    routes to it -- against numpy's FFT, with every LDS access pattern conflict-free; and the constants it was run with
+    are the kernel's"""
+    out = run("emu_f64r.py", where="r6")
+    assert "butterflies ok" in out
+    for m, d in ((4096, 1), (8192, 1), (16384, 1), (16384, 2), (16384, 4)):
+        assert "M = %5d  D = %d" % (m, d) in out
+    assert "all maps ok, every LDS access conflict-free" in out
+    src = open(os.path.join(ROOT, "radio-observer_amd", "csrc", "ro_f64reg.hip")).read()
+    assert "ST = T + 16 * R3" in src and "S2 = Q + (R3 == 1 ? 1 : 2)" in src

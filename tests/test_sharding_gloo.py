@@ -99,6 +99,45 @@ def test_sharded_equals_single(tmp_path, oracle, ro, world, total_rows):
         assert (a.astype(np.float64) > 2.0 * n.astype(np.float64)).any()
 
 
+def _worker_c5(rank, world, port, total_rows, out_dir):
+    """every rank holds its shard of C5's 168 747 scan records (three words a row: the row's index and two functions of
+    it) and of a narrow tile; the direct exchange and the gather to one rank must leave them stitched on the receiver"""
+    sys.path.insert(0, ROOT)
+    import importlib
+    ro = importlib.import_module("radio-observer_amd")
+    sh = ro.sharding()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        first, rows = sh.shard_rows(total_rows, world, rank)
+        idx = torch.arange(first, first + rows, dtype=torch.int64)
+        recs = torch.stack([idx.to(torch.float32), (idx % 977).to(torch.float32), (idx * 3 % 1013).to(torch.float32)], dim=1)
+        want_idx = torch.arange(total_rows, dtype=torch.int64)
+        want = torch.stack([want_idx.to(torch.float32), (want_idx % 977).to(torch.float32), (want_idx * 3 % 1013).to(torch.float32)], dim=1)
+        got = sh.gather_rows_direct(recs, total_rows)
+        ok = torch.equal(got, want)
+        padded, _ = sh.gather_rows(recs, total_rows)                    # the equal-block all-gather + stitch: the same rows
+        ok = ok and torch.equal(padded, want)
+        rooted, _ = sh.gather_rows(recs, total_rows, root=world - 1)
+        ok = ok and ((rooted is None) if rank != world - 1 else torch.equal(rooted, want))
+        open(os.path.join(out_dir, "ok%d" % rank), "w").write("1" if ok else "0")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_c5_split_over_eight_ranks(tmp_path, ro):
+    """BASELINE config 5's geometry on eight gloo ranks: 168 747 rows = 8 x 21 093 + 3, so three shards are a row longer --
+    the direct exchange (ro_direct_schedule step by step), the padded all-gather and the gather to one rank all end with
+    the rows in stream order on their receivers."""
+    world, total_rows = 8, 168747
+    port = _free_port()
+    mp.spawn(_worker_c5, args=(world, port, total_rows, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(os.path.join(str(tmp_path), "ok%d" % r)).read() == "1", r
+
+
 def test_shard_arithmetic(ro):
     sh = ro.sharding()
     for total in (0, 1, 7, 8, 168747):

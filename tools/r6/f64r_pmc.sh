@@ -9,10 +9,13 @@ cd /tmp && export TMPDIR=/tmp
 RUN="python3 $ROOT/tools/r6/f64r_run.py $BINS $OVL $ROWS 6"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $RUN > $OUT/trace.log 2>&1 || { echo "trace failed"; exit 1; }
 i=0
-for C in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES" \
+# TRAFFIC_ONLY=1: the HBM-side byte counters alone (and the kernel trace)
+if [ -n "$TRAFFIC_ONLY" ]; then SETS=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"); else SETS=(
+"SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES" \
          "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM SQ_INSTS_SMEM" \
          "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_WAVES SQ_INSTS_FLAT SQ_ACTIVE_INST_MISC" \
-         "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+         "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"); fi
+for C in "${SETS[@]}"; do
   i=$((i+1))
   timeout -k 10 200 rocprofv3 --pmc $C --output-format csv -d $OUT/p$i -- $RUN > $OUT/p$i.log 2>&1 || { echo "pmc pass $i failed"; exit 1; }
 done
