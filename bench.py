@@ -297,6 +297,71 @@ def pcie_copy_rates(torch, dev, mib=256):
     return both[0], both[1], alone[0], alone[1]
 
 
+def strict_leg(torch, ro, dev, local_rank, parity, bins, overlap, rows, fs, bands, window, steps, iq=None, rows_buf=None,
+               recs_buf=None):
+    """RO_PRECISION_F64 on one shape, inputs resident: rows/s and the fraction of the HBM peak its algorithmic bytes make,
+    every kernel of the mode included (the transform's; the band scan's when `bands`), HIP events by ro_stft_time_resident."""
+    hop = bins - overlap
+    samples = bins + hop * (rows - 1)
+    own = iq is None
+    if own:
+        iq = synth_iq(torch, samples, 0xC2 if bins == 4096 else 0x64, dev)
+        rows_buf = torch.empty((rows, bins), dtype=torch.float32, device=dev)
+    if bands is not None and recs_buf is None:
+        recs_buf = torch.zeros((rows, 3), dtype=torch.float32, device=dev)
+    sptr = torch.cuda.current_stream(dev).cuda_stream
+    alg = hop * 8 + bins * 4
+    reg = bins in (4096, 8192, 16384, 32768, 65536)
+    with ro.Stft(bins=bins, overlap=overlap, sample_rate=fs, device=local_rank, bands=bands, window=window,
+                 precision=ro.RO_PRECISION_F64) as st64:
+        n64 = steps + 2
+        ms64, _, _ = st64.time_resident(iq, ro.RO_IQ_F32, samples, 0, rows, rows_buf, n64,
+                                        d_records=recs_buf if bands is not None else None, stream=sptr)
+        torch.cuda.synchronize(dev)
+        ms_strict = float(np.mean(ms64[2:]))                  # (the first two launches warm the tables and the clocks)
+        entry = {"mode": "RO_PRECISION_F64 (double window multiply, double transform, double sqrt, one narrowing: the "
+                         "reference's arithmetic type)%s" % ("; the complex-double row stays in a CU's registers, no HBM scratch"
+                                                            if reg else "; passes through HBM scratch"),
+                 "workload": "bins %d, overlap %d, %d rows per launch%s" % (bins, overlap, rows, ", band scan included" if bands is not None else ""),
+                 "value": rows / (ms_strict * 1e-3), "unit": "rows/s", "rows_per_step": rows, "steps": n64 - 2,
+                 "ms_per_step": ms_strict, "dtype": "f64",
+                 "roofline": {"bound": "hbm", "limiter": "FP64 issue + LDS exchanges of one workgroup per CU (csrc/ro_f64reg.hip)" if reg
+                                                        else "HBM scratch between the passes",
+                              "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                              "achieved": alg * rows / (ms_strict * 1e-3) / 1e9,
+                              "frac": alg * rows / (ms_strict * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "algorithmic_bytes_per_row": alg,
+                              "kernel": ("f64r_kernel (csrc/ro_f64reg.hip)" if reg else "f64_pair_kernel (two launches per chunk)")
+                                        + (" + scan_kernel" if bands is not None else ""),
+                              "traffic": None}}
+        # bytes per launch by FETCH_SIZE / WRITE_SIZE from a committed rocprofv3 --pmc record of this shape (tools/r6/
+        # f64r_pmc.sh), scaled to this launch's rows: counters cannot be read from inside the run
+        rec_name = "r06_traffic_f64_%d.json" % bins
+        try:
+            with open(os.path.join(ROOT, "profiles", rec_name)) as fh:
+                rec = json.load(fh)
+            per_row = rec["traffic_bytes_per_launch"] / (rec["algorithmic_bytes_per_launch"] / alg)
+            entry["roofline"]["traffic"] = per_row * rows
+            entry["roofline"]["traffic_over_algorithmic"] = per_row / alg
+            entry["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this shape)" % rec_name
+        except Exception as e:
+            entry["roofline"]["traffic_source"] = "profiles/%s unreadable: %s" % (rec_name, str(e)[:80])
+        if parity:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import ro_oracle as O
+            worst = 0.0
+            for r in (0, rows - 1):
+                seg = iq[r * hop:r * hop + bins].cpu().numpy()
+                want = O.stft(seg, bins, overlap, w=st64.window)[0].astype(np.float64)
+                got = rows_buf[r].cpu().numpy().astype(np.float64)
+                worst = max(worst, float((np.abs(got - want) / np.maximum(want, 1e-300)).max()))
+            entry["parity"] = {"rows_checked": [0, rows - 1], "max_err_per_bin_relative": worst, "tolerance_per_bin": 1e-5}
+    if own:
+        del iq, rows_buf
+        torch.cuda.empty_cache()
+    return entry
+
+
 def large_leg(torch, ro, dev, local_rank, parity, bins, overlap, rows, cite, kernels, traffic):
     """A station config's shape above 32768 bins on the resident path: rows/s and the fraction of the HBM peak its
     algorithmic bytes (hop 8 + bins 4 per row) make, all kernels of the size included (the transform's + the band
@@ -874,7 +939,11 @@ def main():
                        **({"c5_hash_of_stitched_band_and_records": c5_hash} if c5_hash else {}),
                        **({"rank0_scan_records_hash": rank0_hash} if rank0_hash and not c5 else {}),
                        **({"exchange_legs_rows_per_s": legs} if legs else {})},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm",
+                         # what holds the kernel below that bound (profiles/r05_stft_c3_summary.txt, r04_ledgers.md): the
+                         # package's power cap under 3 N log2 N packed FMAs per row, not HBM (traffic = 1.01 x algorithmic)
+                         "limiter": "package power cap (VALU)" if BINS == 32768 else "see DESIGN.md 4",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          # the same bytes over the wall-clock step of the timed region (host gaps and exchange included)
                          "frac_step": ALG_BYTES_PER_ROW * R / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
@@ -948,48 +1017,15 @@ def main():
                              "per_bin": {"max_rel": pb_max, "frac_over_1e-5": pb_over / max(1, pb_bins), "met": pb_max <= 1e-5},
                              "scan_records_bit_exact": bool(scan_ok)}
 
-        # ---- the strict-precision mode next to the headline (never the headline): same input, fewer rows
+        # ---- the strict-precision mode next to the headline (never the headline): the same input and rows per step, then
+        # the C2 shape
         if world == 1 and not a.no_strict:
-            r64 = R                                           # the headline's rows per step
-            with ro.Stft(bins=BINS, overlap=OVERLAP, sample_rate=FS, device=local_rank, bands=bands,
-                         window=ro.RO_WINDOW_HANN if a.window == "hann" else ro.RO_WINDOW_NUTTALL,
-                         precision=ro.RO_PRECISION_F64) as st64:
-                n64 = max(a.steps, 20) + 2
-                ms64, k64, s64 = st64.time_resident(iq, ro.RO_IQ_F32, samples, 0, r64, rows, n64, d_records=recs[1],
-                                                    stream=sptr)
-                torch.cuda.synchronize(dev)
-                ms_strict = float(np.mean(ms64[2:]))          # (the first two launches allocate and warm the scratch)
-                # traffic model of the two-trip form at bins = 32768: trip 1 reads the row's samples
-                # (8 B per point, overlap re-reads from L2) and writes complex doubles (16 B); trip 2 reads them
-                # (16 B) and writes the float row (4 B): 44 B per point against 6 B algorithmic
-                model = 44.0 * BINS
-                entry = {"mode": "RO_PRECISION_F64 (double window multiply, double transform in two trips through HBM "
-                                 "scratch, double sqrt, one narrowing: the reference's arithmetic type)",
-                         "value": r64 / (ms_strict * 1e-3), "unit": "rows/s", "rows_per_step": r64, "steps": n64 - 2,
-                         "ms_per_step": ms_strict, "dtype": "f64",
-                         "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                                      "achieved": ALG_BYTES_PER_ROW * r64 / (ms_strict * 1e-3) / 1e9,
-                                      "frac": ALG_BYTES_PER_ROW * r64 / (ms_strict * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                      "kernel": "f64_pair_kernel (two launches per step) + scan_kernel",
-                                      "traffic_model_bytes_per_row": model,
-                                      "traffic_model_GBs": model * r64 / (ms_strict * 1e-3) / 1e9,
-                                      "traffic_model_frac_of_peak": model * r64 / (ms_strict * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                      # FETCH_SIZE x 1.994 + WRITE_SIZE of this mode's kernels, per point x points of a step
-                                      # (profiles/r05_f64_one_launch.txt section 2: 38.7 B per point)
-                                      "traffic": 38.70 * BINS * r64 if BINS == 32768 else None,
-                                      "traffic_source": "profiles/r05_f64_one_launch.txt (rocprofv3 --pmc passes, two-launch form)"}}
-                if not a.no_parity:
-                    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-                    import ro_oracle as O
-                    worst = 0.0
-                    for r in (0, r64 - 1):
-                        seg = iq[r * HOP:r * HOP + BINS].cpu().numpy()
-                        want = O.stft(seg, BINS, OVERLAP, w=st64.window)[0].astype(np.float64)
-                        got = rows[r].cpu().numpy().astype(np.float64)
-                        worst = max(worst, float((np.abs(got - want) / np.maximum(want, 1e-300)).max()))
-                    entry["parity"] = {"rows_checked": [0, r64 - 1], "max_err_per_bin_relative": worst,
-                                       "tolerance_per_bin": 1e-5}
-            out["strict_precision"] = entry
+            out["strict_precision"] = strict_leg(torch, ro, dev, local_rank, not a.no_parity, BINS, OVERLAP, R, FS, bands,
+                                                 ro.RO_WINDOW_HANN if a.window == "hann" else ro.RO_WINDOW_NUTTALL,
+                                                 max(a.steps, 20), iq=iq, rows_buf=rows, recs_buf=recs[1])
+            if (BINS, OVERLAP) == (32768, 24576) and not c5:
+                out["strict_precision"]["c2"] = strict_leg(torch, ro, dev, local_rank, not a.no_parity, 4096, 2048, 65536, FS,
+                                                           None, ro.RO_WINDOW_NUTTALL, max(a.steps, 20))
 
         # ---- the station configs' own shapes next to the headline (never the headline), inputs resident:
         # Ionozor.json:27-28 on the four-step pair of kernels, Bolidozor.json:45-46 on the one-kernel large form
@@ -1000,6 +1036,9 @@ def main():
             out["bolidozor"] = large_leg(torch, ro, dev, local_rank, not a.no_parity, 65536, 49152, 8192, "Bolidozor.json:45-46",
                                          "stft_kernel<Plan32768, ., 3> (two workgroups per stream row) + scan_kernel",
                                          "r05_traffic_65536.json")
+            if not a.no_strict:                              # ... and the same shape in the reference's arithmetic type
+                out["bolidozor"]["f64"] = strict_leg(torch, ro, dev, local_rank, not a.no_parity, 65536, 49152, 8192, 96000,
+                                                     None, ro.RO_WINDOW_NUTTALL, 12)
 
         # ---- the drop-in path at full speed (never the headline): Frontend::process -> HipWaterfallBackend::process
         # with 4096-sample vector<Complex> calls (src/RawStream.cpp:44-66) -> kernels -> full rows back to the host row

@@ -50,12 +50,16 @@ def test_bench_line_has_the_contract_fields(ro, torch_cuda):
     assert d["parity"]["max_err_rel_to_row_max"] <= 1e-5 and d["parity"]["scan_records_bit_exact"]
     sp = d["strict_precision"]
     assert sp["dtype"] == "f64" and sp["parity"]["max_err_per_bin_relative"] <= 1e-5
-    assert sp["roofline"]["frac"] == pytest.approx(sp["roofline"]["achieved"] / 8000.0) and "f64_pair_kernel" in sp["roofline"]["kernel"]
+    assert sp["roofline"]["frac"] == pytest.approx(sp["roofline"]["achieved"] / 8000.0) and "f64r_kernel" in sp["roofline"]["kernel"]
+    assert sp["parity"]["max_err_per_bin_relative"] <= 2e-7 and "4096" in sp["c2"]["workload"]
+    assert sp["c2"]["dtype"] == "f64" and sp["c2"]["parity"]["max_err_per_bin_relative"] <= 2e-7 and sp["c2"]["value"] > sp["value"]
+    assert rf["limiter"].startswith("package power cap")
     io = d["ionozor"]                   # the four-step form at Ionozor.json:27-28, never the headline
     assert io["unit"] == "rows/s" and io["value"] > 0 and io["parity"]["max_err_rel_to_row_max"] <= 1e-5
     assert io["roofline"]["frac"] == pytest.approx(io["roofline"]["achieved"] / 8000.0) and "four_cols_kernel" in io["roofline"]["kernel"]
     bo = d["bolidozor"]                 # Bolidozor.json:45-46 on the one-kernel large form
     assert bo["value"] > io["value"] and bo["parity"]["max_err_rel_to_row_max"] <= 1e-5 and "65536" in bo["workload"]
+    assert bo["f64"]["dtype"] == "f64" and bo["f64"]["parity"]["max_err_per_bin_relative"] <= 2e-7 and 0 < bo["f64"]["value"] < bo["value"]
     for k in ("streaming", "streaming_batch256"):
         st = d[k]
         assert "error" not in st, st

@@ -234,6 +234,46 @@ def test_row_sink_receives_the_rows_in_ring_order(ro, oracle, bins, overlap, bat
     small.close()
 
 
+@pytest.mark.parametrize("batch", [1, 2])
+def test_four_step_sizes_back_to_back_with_a_sink(ro, torch_cuda, batch):
+    """bins = 262144 hands Z from its column kernel to its row kernel through ONE scratch block per handle: batches of such
+    a handle may never run side by side on the slots' streams (they are not graphed; every batch is ordered on the handle's
+    stream).  Many small batches pushed in ONE call, no fetch in between, against the resident rows of the same samples."""
+    torch = torch_cuda
+    bins, overlap = 262144, 196608
+    hop = bins - overlap
+    R = 12
+    rng = np.random.default_rng(batch)
+    iq = noise_iq(rng, bins + (R - 1) * hop)
+    d_iq = torch.from_numpy(iq).cuda()
+    want = torch.empty((R, bins), dtype=torch.float32, device="cuda")
+    with ro.Stft(bins=bins, overlap=overlap) as st:
+        st.run_resident(d_iq, ro.RO_IQ_F32, iq.shape[0], 0, R, want, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    want = want.cpu().numpy()
+    pinned = ro.PinnedArray(R + 2, bins)
+    ring = pinned.array
+    ring[:] = np.nan
+    with ro.Stft(bins=bins, overlap=overlap, max_batch_rows=batch) as st:
+        st.set_row_sink(ring, 0)
+        for rep in range(2):                                 # (the second time every slot has run before)
+            st.push(iq)                                      # R rows = R / batch launches queued back to back
+            st.flush()
+            seen = 0
+            while True:
+                first, got, _ = st.fetch_records(100)
+                if got == 0:
+                    break
+                seen += got
+            assert seen == R
+            assert np.array_equal(ring[:R], want), rep
+            ring[:] = np.nan
+            st.reset()
+            st.set_row_sink(ring, 0)
+    del ring
+    pinned.close()
+
+
 def test_one_hip_runtime_in_the_test_process(ro, torch_cuda):
     """The GPU tests import torch first (conftest), so libro_stft.so resolves `libamdhip64.so.7` against the copy torch
     has loaded: ONE HIP runtime in the process, device pointers, streams and page-locked memory mean the same thing to

@@ -61,5 +61,15 @@ if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
     print("HBM side: fetch %.4g B (x 1.994) + write %.4g B = %.4g B per launch = %.3f x algorithmic (%.4g B); TCC hit %.3f"
           % (fetch, write, fetch + write, (fetch + write) / alg, alg, v.get("TCC_HIT_sum", 0) / max(1.0, v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0))))
     print("achieved: %.1f GB/s algorithmic = %.3f of 8 TB/s" % (alg / avg_ns, alg / avg_ns / 8000))
+    import json
+    hit = v.get("TCC_HIT_sum", 0) / max(1.0, v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0))
+    json.dump({"round": 6, "kernel": "f64r_kernel (csrc/ro_f64reg.hip: RO_PRECISION_F64, the complex-double row in a CU's registers)",
+               "workload": "bins %d, overlap %d, %d rows per launch" % (bins, ovl, rows),
+               "fetch_size_raw_bytes": v["FETCH_SIZE"] * 1024, "fetch_calibration": 1.994, "write_size_bytes": write,
+               "traffic_bytes_per_launch": fetch + write, "algorithmic_bytes_per_launch": float(alg), "ratio": (fetch + write) / alg,
+               "tcc_hit_rate": hit, "kernel_avg_us_under_the_profiler": avg_ns / 1e3,
+               "method": "rocprofv3 --pmc, one counter set per run of tools/r6/f64r_run.py (tools/r6/f64r_pmc.sh); FETCH_SIZE x 1.994 as "
+                         "calibrated on stft32k_kernel; with nt row stores (no line fills) this kernel's FETCH_SIZE x 1.994 is its input bytes within 1.1 %: profiles/r06_f64r_store_policy.txt"},
+              open(os.path.join(out, "traffic.json"), "w"), indent=1)
 PY
 cat $OUT/SUMMARY.txt
