@@ -66,6 +66,22 @@
 #define RO_F64R_STORE_AUX_D 0
 #endif
 
+// 1: the exchanges' LDS reads are volatile, which keeps hipcc from fusing two ds_read_b64 into one ds_read2_b64 /
+// ds_read2st64_b64: the fused forms run at half the bytes per clock (MI355X_MICROARCH.md, LDS table: 128 against 256
+// B/clk/CU) and bank their lanes in groups of 16 over 32 banks, for which the strides below are not chosen.
+#ifndef RO_F64R_PLAIN_READS
+#define RO_F64R_PLAIN_READS 1
+#endif
+
+// 1 = the per-lane table entries of passes 2 and 3 are asked for right behind barrier (d), in front of pass 1 (pass 1's own,
+// where it is per lane: behind barrier (b)) -- the POWERS {w^8, w^4, w^2, w} only, 16 registers per pass; the other four
+// entries are made from them inside the transform.  Later they queue behind the older waves' requests for the
+// next sub-row's samples (24 KiB per wave through one in-order memory pipeline): the youngest wave of a SIMD then waited
+// ~10k cycles for 160 bytes in the middle of pass 2 (profiles/r06_f64r_stamps.txt).
+#ifndef RO_F64R_EARLY_TABLES
+#define RO_F64R_EARLY_TABLES 1
+#endif
+
 // The ONE diagnostic switch of this file.  A -DRO_DIAG=1 build (tools/ab_build.sh) may set RO_F64R_STAMPS=1: s_memtime
 // deltas per phase of the sub-row loop, every wave of every workgroup, accumulated into Args::stamps
 // (tools/r6/f64r_stamps.py).  Never timed, never shipped.
@@ -156,7 +172,7 @@ template <typename TW> __device__ __forceinline__ void twisted16(double *re, dou
 }
 
 // eight twiddles in VGPRs (per-lane table entry) or SGPRs (an entry the whole wave shares)
-struct TwV {
+template <bool LAZY> struct TwVT {
     d2 t[8];
     __device__ __forceinline__ double re(int i) const { return t[i].x; }
     __device__ __forceinline__ double im(int i) const { return t[i].y; }
@@ -178,14 +194,35 @@ struct TwV {
         rs = make_rsrc(table, (unsigned)entries * 128u);
         voff = index * 128;
         __builtin_amdgcn_sched_barrier(0);
-        load4<0>();
+        if constexpr (LAZY) {
+            load4<0>();
+        } else {
+            // the powers only: {w^8, w^4, w^2, w}; second_half() makes the other four from them
+#pragma unroll
+            for (int i : {0, 1, 2, 4}) {
+                const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, i * 16, 0);
+                t[i] = (d2){__hiloint2double((int)u.y, (int)u.x), __hiloint2double((int)u.w, (int)u.z)};
+            }
+        }
     }
     __device__ __forceinline__ void second_half()
     {
-        __builtin_amdgcn_sched_barrier(0);
-        load4<4>();
+        if constexpr (LAZY) {
+            __builtin_amdgcn_sched_barrier(0);
+            load4<4>();
+        } else {
+            // w^2 W_8 and w W_16^e, e = 1, 2, 3, in double from the loaded powers (exp(-2 pi i e / 16) = (c, -s)): the
+            // table's own entries are these products rounded once, these are rounded twice -- 1e-16 against a bar of 2e-7
+            constexpr double C[4] = {1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173};
+            constexpr double S[4] = {0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128675613};
+            t[3] = (d2){(t[2].x + t[2].y) * C[2], (t[2].y - t[2].x) * C[2]};
+#pragma unroll
+            for (int e = 1; e < 4; ++e)
+                t[4 + e] = (d2){__builtin_fma(t[4].y, S[e], t[4].x * C[e]), __builtin_fma(-t[4].x, S[e], t[4].y * C[e])};
+        }
     }
 };
+typedef TwVT<true> TwV;
 template <int P> __device__ __forceinline__ void set_prio()
 {
     if constexpr (RO_F64R_PRIO) __builtin_amdgcn_s_setprio(P);
@@ -421,6 +458,12 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *plane = reinterpret_cast<double *>(smem);
     float *image = reinterpret_cast<float *>(smem);
+#if RO_F64R_PLAIN_READS
+    typedef const volatile __attribute__((address_space(3))) double lds_vdouble;
+    lds_vdouble *rplane = (lds_vdouble *)plane;
+#else
+    const double *rplane = plane;
+#endif
 
     // XCD-aware placement (speed only): workgroups b and b + 8 share an XCD under round-robin dispatch; each XCD takes
     // a contiguous run of rows, its workgroups take the D sub-rows of consecutive rows at the same time
@@ -566,9 +609,11 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
         stamp(4);
         wg_sync();                                      // (b)
         [[maybe_unused]] TwS tw1s;                       // M = 16384: the wave is one k0, its pass-1 table entry in SGPRs
+        [[maybe_unused]] TwVT<!RO_F64R_EARLY_TABLES> tw1v;   // M < 16384: per lane (its powers asked for here)
         if constexpr (Q == 64) tw1s.load(tw1 + wave * 8);
+        else if constexpr (RO_F64R_EARLY_TABLES) tw1v.load(tw1, 16, fresh() / Q);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) xr[j] = plane[x1r + Q * j];
+        for (int j = 0; j < 16; ++j) xr[j] = rplane[x1r + Q * j];
         stamp(5);
         wg_sync();                                      // (c) everyone has its real parts
 #pragma unroll
@@ -576,39 +621,54 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
         stamp(6);
         wg_sync();                                      // (d)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) xi[j] = plane[x1r + Q * j];
+        for (int j = 0; j < 16; ++j) xi[j] = rplane[x1r + Q * j];
         asm volatile("" ::: "memory");
         set_prio<3>();
         // this thread from here on: (k0, u) in pass 1, (k0, k1, n3) in pass 2, g' = bitrev(n3) in pass 3
         const int tr_ = fresh();
         const int k0 = tr_ / Q, u = tr_ % Q, k1 = u & 15, n3 = u >> 4;
         const int K1 = k0 + 16 * k1;
+        constexpr bool EARLY = RO_F64R_EARLY_TABLES;
+        TwVT<!EARLY> tw2v;
+        [[maybe_unused]] d2 a1, a2;                      // pass 3's {a', a'^2}, a' = W_N^(q + D (K1 + 256 g'))
+        auto load_tw3 = [&]() {
+            if constexpr (R3 > 1) {
+                const int gp = R3 == 4 ? (n3 >> 1) + 2 * (n3 & 1) : n3;
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.tw3 + (int64_t)q * 256 * R3 * 2, 256 * R3 * 32);
+                const u32x4 c1 = __builtin_amdgcn_raw_buffer_load_b128(rs, (K1 * R3 + gp) * 32, 0, 0);
+                const u32x4 c2 = __builtin_amdgcn_raw_buffer_load_b128(rs, (K1 * R3 + gp) * 32, 16, 0);
+                a1 = (d2){__hiloint2double((int)c1.y, (int)c1.x), __hiloint2double((int)c1.w, (int)c1.z)};
+                a2 = (d2){__hiloint2double((int)c2.y, (int)c2.x), __hiloint2double((int)c2.w, (int)c2.z)};
+            }
+        };
+        if constexpr (EARLY) {
+            tw2v.load(tw2, 256, K1);
+            load_tw3();
+        }
         // ---- pass 1.  From here to the completed image a wave touches its own territories only.
         if constexpr (Q == 64) {
             twisted16(xr, xi, tw1s);
         } else {
-            TwV tw;
-            tw.load(tw1, 16, k0);
-            twisted16(xr, xi, tw);
+            if constexpr (!RO_F64R_EARLY_TABLES) tw1v.load(tw1, 16, k0);
+            twisted16(xr, xi, tw1v);
         }
         stamp(7);
         set_prio<2>();
         // ---- exchange 2 (one wave's LDS instructions execute in order: no wait between its writes and its reads); the first
         // half of pass 2's table entry is asked for in front of it
-        TwV tw2v;
-        tw2v.load(tw2, 256, K1);
+        if constexpr (!EARLY) tw2v.load(tw2, 256, K1);
         const int x2w = k0 * ST + u, x2r = k0 * ST + k1 * G::S2 + n3;
 #pragma unroll
         for (int k = 0; k < 16; ++k) plane[x2w + k * G::S2] = xr[brev<4>(k)];
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int j = 0; j < 16; ++j) re[j] = plane[x2r + R3 * j];
+        for (int j = 0; j < 16; ++j) re[j] = rplane[x2r + R3 * j];
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int k = 0; k < 16; ++k) plane[x2w + k * G::S2] = xi[brev<4>(k)];
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int j = 0; j < 16; ++j) im[j] = plane[x2r + R3 * j];
+        for (int j = 0; j < 16; ++j) im[j] = rplane[x2r + R3 * j];
         asm volatile("" ::: "memory");
         stamp(8);
         // ---- pass 2
@@ -639,15 +699,7 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
             }
             stamp(10);
             // ---- pass 3: butterfly i has twist theta = a' W_16^i, a' = W_N^(q + D (K1 + 256 g')) (table: {a', a'^2})
-            d2 a1, a2;
-            {
-                const int gp = R3 == 4 ? (n3 >> 1) + 2 * (n3 & 1) : n3;
-                const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.tw3 + (int64_t)q * 256 * R3 * 2, 256 * R3 * 32);
-                const u32x4 c1 = __builtin_amdgcn_raw_buffer_load_b128(rs, (K1 * R3 + gp) * 32, 0, 0);
-                const u32x4 c2 = __builtin_amdgcn_raw_buffer_load_b128(rs, (K1 * R3 + gp) * 32, 16, 0);
-                a1 = (d2){__hiloint2double((int)c1.y, (int)c1.x), __hiloint2double((int)c1.w, (int)c1.z)};
-                a2 = (d2){__hiloint2double((int)c2.y, (int)c2.x), __hiloint2double((int)c2.w, (int)c2.z)};
-            }
+            if constexpr (!EARLY) load_tw3();
             constexpr double C16[8] = {1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173,
                                        0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128675613};
             constexpr double S16[8] = {0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128675613,
