@@ -297,13 +297,13 @@ template <int D, int FMT> struct Raw {
     v2f x[D][16];
     v4f w[D][4];
 };
-template <int LOGM, int D, int FMT>
-__device__ __forceinline__ void raw_load(Raw<D, FMT> &r, const __amdgpu_buffer_rsrc_t &rs_iq, const __amdgpu_buffer_rsrc_t &rs_w, int t)
+template <int LOGM, int PR, int FMT>
+__device__ __forceinline__ void raw_load(Raw<PR, FMT> &r, const __amdgpu_buffer_rsrc_t &rs_iq, const __amdgpu_buffer_rsrc_t &rs_w, int t)
 {
     using G = Geo<LOGM>;
     using S = Sample<FMT>;
 #pragma unroll
-    for (int rr = 0; rr < D; ++rr) {
+    for (int rr = 0; rr < PR; ++rr) {
 #pragma unroll
         for (int n0 = 0; n0 < 16; ++n0) r.x[rr][n0] = S::load(rs_iq, t * S::BYTES, (G::T * n0 + G::M * rr) * S::BYTES);
 #pragma unroll
@@ -363,33 +363,35 @@ __device__ __forceinline__ void fold_term(double &sr, double &si, v2f x, float w
         si = __builtin_fma(xi, wd, si);
     }
 }
-template <int D, bool GAIN, int... Rs>
+// terms R0 + Rs of a slot (term 0 starts the sum, the others add to it)
+template <int D, bool GAIN, int R0, int... Rs>
 __device__ __forceinline__ void fold_slot(double &sr, double &si, const v2f (&x)[D], const float (&w)[D], const Rot<D> &rot,
                                           std::integer_sequence<int, Rs...>)
 {
-    (fold_term<D, GAIN, Rs>(sr, si, x[Rs], w[Rs], rot), ...);
+    (fold_term<D, GAIN, R0 + Rs>(sr, si, x[R0 + Rs], w[R0 + Rs], rot), ...);
 }
 
-// From the registers of raw_load ...
-template <int LOGM, int D, bool GAIN, int FMT>
-__device__ __forceinline__ void fold_raw(double *re, double *im, const Raw<D, FMT> &r, const Rot<D> &rot)
+// Blocks 0 .. PR - 1 from the registers of raw_load ...
+template <int LOGM, int D, int PR, bool GAIN, int FMT>
+__device__ __forceinline__ void fold_raw(double *re, double *im, const Raw<PR, FMT> &r, const Rot<D> &rot)
 {
 #pragma unroll
     for (int n0 = 0; n0 < 16; ++n0) {
         v2f x[D];
         float w[D];
 #pragma unroll
-        for (int rr = 0; rr < D; ++rr) {
+        for (int rr = 0; rr < PR; ++rr) {
             x[rr] = r.x[rr][n0];
             w[rr] = r.w[rr][n0 / 4][n0 % 4];
         }
-        fold_slot<D, GAIN>(re[n0], im[n0], x, w, rot, std::make_integer_sequence<int, D>{});
+        fold_slot<D, GAIN, 0>(re[n0], im[n0], x, w, rot, std::make_integer_sequence<int, PR>{});
         // (two slots at a time: left to itself the scheduler converts all the samples first and the doubles do not fit)
         if (n0 & 1) __builtin_amdgcn_sched_barrier(0);
     }
 }
-// ... or straight from memory, four slots at a time (D = 4)
-template <int LOGM, int D, bool GAIN, int FMT>
+// ... blocks R0 .. D - 1 straight from memory, four slots at a time (D = 4: two blocks of samples fit the registers ahead
+// of time, the other two are asked for here)
+template <int LOGM, int D, int R0, bool GAIN, int FMT>
 __device__ __forceinline__ void fold_mem(double *re, double *im, const __amdgpu_buffer_rsrc_t &rs_iq,
                                          const __amdgpu_buffer_rsrc_t &rs_w, int t, const Rot<D> &rot)
 {
@@ -401,7 +403,7 @@ __device__ __forceinline__ void fold_mem(double *re, double *im, const __amdgpu_
         v2f x[4][D];
         v4f w[D];
 #pragma unroll
-        for (int r = 0; r < D; ++r) {
+        for (int r = R0; r < D; ++r) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) x[e][r] = S::load(rs_iq, t * S::BYTES, (T * (4 * sg + e) + M * r) * S::BYTES);
             const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs_w, t * 16, (r * 4 + sg) * T * 16, 0);
@@ -411,8 +413,8 @@ __device__ __forceinline__ void fold_mem(double *re, double *im, const __amdgpu_
         for (int e = 0; e < 4; ++e) {
             float we[D];
 #pragma unroll
-            for (int r = 0; r < D; ++r) we[r] = w[r][e];
-            fold_slot<D, GAIN>(re[4 * sg + e], im[4 * sg + e], x[e], we, rot, std::make_integer_sequence<int, D>{});
+            for (int r = R0; r < D; ++r) we[r] = w[r][e];
+            fold_slot<D, GAIN, R0>(re[4 * sg + e], im[4 * sg + e], x[e], we, rot, std::make_integer_sequence<int, D - R0>{});
         }
     }
 }
@@ -454,7 +456,7 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
     using G = Geo<LOGM>;
     using S = Sample<FMT>;
     [[maybe_unused]] constexpr int M = G::M, T = G::T, R3 = G::R3, Q = G::Q, ST = G::ST, N = M * D;
-    constexpr bool PRE = D <= 2;                        // the samples of the next sub-row are requested a barrier ahead
+    constexpr int PR = D <= 2 ? D : 2;                  // blocks of the next sub-row's samples requested a barrier ahead
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *plane = reinterpret_cast<double *>(smem);
     float *image = reinterpret_cast<float *>(smem);
@@ -572,25 +574,23 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
     auto iq_rsrc = [&](int64_t r, bool valid) {
         return make_rsrc(iq + (a.first_row + r) * (int64_t)a.hop * S::BYTES, valid ? (unsigned)N * S::BYTES : 0u);
     };
-    Raw<PRE ? D : 1, FMT> raw;
-    if constexpr (PRE) raw_load<LOGM, D, FMT>(raw, iq_rsrc(row, true), rs_w, t);
+    Raw<PR, FMT> raw;
+    raw_load<LOGM, PR, FMT>(raw, iq_rsrc(row, true), rs_w, t);
 
-    unsigned touch[D] = {};
+    constexpr int TOUCHES = D < 2 ? D : 2;               // x T x 128 bytes of new samples touched ahead (hop <= N / 2 whole)
+    unsigned touch[TOUCHES] = {};
     for (;;) {
         const int64_t next = row + row_step;
         const bool has_next = next < xcd_end;
 #pragma unroll
-        for (int i = 0; i < D; ++i) asm volatile("" ::"v"(touch[i]));   // the "use" of the touches below (long complete)
+        for (int i = 0; i < TOUCHES; ++i) asm volatile("" ::"v"(touch[i]));   // the "use" of the touches below (long complete)
         // (nothing of the fold in front of this point: hoisted above the barrier and the read-out, its conversions hold
         // the samples twice)
         __builtin_amdgcn_sched_barrier(0);
         double re[16], im[16];
         // ---- the fold
-        if constexpr (PRE) {
-            fold_raw<LOGM, D, GAIN, FMT>(re, im, raw, rot);
-        } else {
-            fold_mem<LOGM, D, GAIN, FMT>(re, im, iq_rsrc(row, true), rs_w, fresh(), rot);
-        }
+        fold_raw<LOGM, D, PR, GAIN, FMT>(re, im, raw, rot);
+        if constexpr (PR < D) fold_mem<LOGM, D, PR, GAIN, FMT>(re, im, iq_rsrc(row, true), rs_w, fresh(), rot);
         stamp(3);
         // ---- pass 0, and the real parts leave for exchange 1
         if constexpr (D == 1) {
@@ -743,20 +743,20 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
         // of the next fold) so that the requests below find them in L2: they come from HBM, every other byte of the row from
         // L2.  Here, because loads return in order: behind this point nothing waits for a load before the next fold.
         {
-            const int64_t far = PRE ? next + row_step : next;
+            const int64_t far = next + row_step;
             if (far < xcd_end) {
                 const int64_t s0 = (a.first_row + far) * (int64_t)a.hop + (N - a.hop);
                 const __amdgpu_buffer_rsrc_t rs_new = make_rsrc(iq + s0 * S::BYTES, (unsigned)a.hop * S::BYTES);
                 const int tt = after(fresh(), last);
 #pragma unroll
-                for (int i = 0; i < D; ++i) touch[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_new, tt * 128, i * T * 128, 0);
+                for (int i = 0; i < TOUCHES; ++i) touch[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_new, tt * 128, i * T * 128, 0);
             }
         }
         stamp(12);
         __builtin_amdgcn_sched_barrier(0);
         // ---- the next sub-row's samples and window: asked for now, needed behind the barrier and the read-out.  (The
         // requests may not start before the last magnitude exists: their registers are the transform's.)
-        if constexpr (PRE) raw_load<LOGM, D, FMT>(raw, iq_rsrc(has_next ? next : row, has_next), rs_w, after(fresh(), last));
+        raw_load<LOGM, PR, FMT>(raw, iq_rsrc(has_next ? next : row, has_next), rs_w, after(fresh(), last));
         wg_sync();                                      // (e) the image of this sub-row is complete
         stamp(13);
         // ---- the image: out of LDS, then LDS is free for the next sub-row's exchange, then on its way to the row
