@@ -41,9 +41,13 @@ enum { RO_WINDOW_NUTTALL = 0, RO_WINDOW_HANN = 1, RO_WINDOW_CUSTOM = 2 };
 /* sample formats accepted by push / resident runs.
  *  F32: interleaved float32 I,Q -- RawStream's wire format (src/RawStream.cpp:33,61-62)
  *  I16: interleaved int16 I,Q, un-normalised -- WAVStream (src/WAVStream.cpp:119-120)
- *  F64: {double real; double imag;} -- struct Complex (src/Backend.h:26-29);
- *       host-side only, narrowed to float32 while staging (lossless for every
- *       frontend the reference has: int16 WAV, float32 raw/JACK). */
+ *  F64: {double real; double imag;} -- struct Complex (src/Backend.h:26-29).
+ *       RO_PRECISION_F64 handles of 4096 ... 65536 bins stage, upload and multiply
+ *       the doubles themselves ((double)sample x (double)w, src/FFTBackend.cpp:
+ *       229-232) and also take them device-resident; every other handle accepts
+ *       them through ro_stft_push only and narrows them to float32 while staging
+ *       (lossless for every frontend the reference has: int16 WAV, float32 raw /
+ *       JACK). */
 enum { RO_IQ_F32 = 0, RO_IQ_I16 = 1, RO_IQ_F64 = 2 };
 
 /* arithmetic of the transform.

@@ -291,17 +291,35 @@ __device__ __forceinline__ void magnitudes16(const double *re, const double *im,
     }
 }
 
-// The raw material of one sub-row in registers: 16 D samples and their window coefficients per thread, requested a whole
-// barrier wait ahead of the fold (D <= 2; at D = 4 they would not fit and the fold asks for them itself)
-template <int D, int FMT> struct Raw {
-    v2f x[D][16];
-    v4f w[D][4];
+// Sample formats: float32 and int16 pairs as everywhere in the library (Sample<>: a float pair per sample), and, for this
+// kernel only, the reference's own struct Complex {double real; double imag;} (src/Backend.h:26-29) -- RO_IQ_F64 samples
+// multiplied as (double)sample x (double)w like src/FFTBackend.cpp:229-232, with nothing narrowed on the way.
+#define RO_FMT_F64 RO_IQ_F64
+template <int FMT> struct Smp : Sample<FMT> {
+    typedef v2f type;
+};
+template <> struct Smp<RO_FMT_F64> {
+    typedef d2 type;
+    static constexpr int BYTES = 16;
+    static __device__ __forceinline__ d2 load(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+    {
+        const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+        return (d2){__hiloint2double((int)u.y, (int)u.x), __hiloint2double((int)u.w, (int)u.z)};
+    }
+};
+
+// The raw material of one sub-row in registers: the samples of PR blocks (16 each) and their window coefficients per
+// thread, requested a whole barrier wait ahead of the fold (PR = D for D <= 2, 2 of the 4 blocks at D = 4, none for
+// double samples: they would not fit, and the fold asks for what is missing itself)
+template <int PR, int FMT> struct Raw {
+    typename Smp<FMT>::type x[PR > 0 ? PR : 1][16];
+    v4f w[PR > 0 ? PR : 1][4];
 };
 template <int LOGM, int PR, int FMT>
 __device__ __forceinline__ void raw_load(Raw<PR, FMT> &r, const __amdgpu_buffer_rsrc_t &rs_iq, const __amdgpu_buffer_rsrc_t &rs_w, int t)
 {
     using G = Geo<LOGM>;
-    using S = Sample<FMT>;
+    using S = Smp<FMT>;
 #pragma unroll
     for (int rr = 0; rr < PR; ++rr) {
 #pragma unroll
@@ -317,8 +335,9 @@ __device__ __forceinline__ void raw_load(Raw<PR, FMT> &r, const __amdgpu_buffer_
 // The fold of sub-row q: slot n0 of thread t = sum_r W_D^(r q) w[i + M r] (x[i + M r] + i gain), i = t + T n0
 // (src/FFTBackend.cpp:78-79: Q += gain; :229-232: the window multiply, double x (double)float).  Products of a float32 or
 // int16 sample and a float32 coefficient are exact in double.  W_D^(r q) = (-i)^ph, ph = r q (4 / D) mod 4, is a swap and
-// two sign flips of the FLOAT sample (exact), the same for the whole workgroup: no copy of the fold per q (hipcc hoists
-// what such copies have in common -- every conversion -- in front of them, and the doubles of a whole sub-row do not fit).
+// two sign flips of the sample AS IT ARRIVED (exact), the same for the whole workgroup: no copy of the fold per q (hipcc
+// hoists what such copies have in common -- every conversion -- in front of them, and the doubles of a whole sub-row do
+// not fit).
 template <int D> struct Rot {
     unsigned swap[D], sign_r[D], sign_i[D];      // per term r: exchange the halves; xor masks of the new real / imaginary half
     double   gain_r[D], gain_i[D];               // what the reference's Q += gain becomes behind the rotation
@@ -336,8 +355,8 @@ template <int D> struct Rot {
         }
     }
 };
-template <int D, bool GAIN, int R>
-__device__ __forceinline__ void fold_term(double &sr, double &si, v2f x, float w, const Rot<D> &rot)
+// (-i)^ph x as a pair of doubles
+template <int D, int R> __device__ __forceinline__ d2 rotated(v2f x, const Rot<D> &rot)
 {
     float fr = x.x, fi = x.y;
     if constexpr (R > 0 && D > 1) {
@@ -349,7 +368,27 @@ __device__ __forceinline__ void fold_term(double &sr, double &si, v2f x, float w
         fr = __uint_as_float(__float_as_uint(fr) ^ rot.sign_r[R]);
         fi = __uint_as_float(__float_as_uint(fi) ^ rot.sign_i[R]);
     }
-    double xr = (double)fr, xi = (double)fi;
+    return (d2){(double)fr, (double)fi};
+}
+template <int D, int R> __device__ __forceinline__ d2 rotated(d2 x, const Rot<D> &rot)
+{
+    double dr = x.x, di = x.y;
+    if constexpr (R > 0 && D > 1) {
+        if constexpr (D > 2) {
+            const double a = rot.swap[R] ? di : dr, b = rot.swap[R] ? dr : di;
+            dr = a;
+            di = b;
+        }
+        dr = __hiloint2double(__double2hiint(dr) ^ (int)rot.sign_r[R], __double2loint(dr));
+        di = __hiloint2double(__double2hiint(di) ^ (int)rot.sign_i[R], __double2loint(di));
+    }
+    return (d2){dr, di};
+}
+template <int D, bool GAIN, int R, typename X>
+__device__ __forceinline__ void fold_term(double &sr, double &si, X x, float w, const Rot<D> &rot)
+{
+    const d2 xd = rotated<D, R>(x, rot);
+    double xr = xd.x, xi = xd.y;
     if constexpr (GAIN) {
         if constexpr (D > 2) xr += rot.gain_r[R];
         xi += rot.gain_i[R];                      // (D <= 2: the rotation is a sign, the gain stays on the imaginary half)
@@ -364,8 +403,8 @@ __device__ __forceinline__ void fold_term(double &sr, double &si, v2f x, float w
     }
 }
 // terms R0 + Rs of a slot (term 0 starts the sum, the others add to it)
-template <int D, bool GAIN, int R0, int... Rs>
-__device__ __forceinline__ void fold_slot(double &sr, double &si, const v2f (&x)[D], const float (&w)[D], const Rot<D> &rot,
+template <int D, bool GAIN, int R0, typename X, int... Rs>
+__device__ __forceinline__ void fold_slot(double &sr, double &si, const X (&x)[D], const float (&w)[D], const Rot<D> &rot,
                                           std::integer_sequence<int, Rs...>)
 {
     (fold_term<D, GAIN, R0 + Rs>(sr, si, x[R0 + Rs], w[R0 + Rs], rot), ...);
@@ -375,9 +414,10 @@ __device__ __forceinline__ void fold_slot(double &sr, double &si, const v2f (&x)
 template <int LOGM, int D, int PR, bool GAIN, int FMT>
 __device__ __forceinline__ void fold_raw(double *re, double *im, const Raw<PR, FMT> &r, const Rot<D> &rot)
 {
+    typedef typename Smp<FMT>::type X;
 #pragma unroll
     for (int n0 = 0; n0 < 16; ++n0) {
-        v2f x[D];
+        X x[D];
         float w[D];
 #pragma unroll
         for (int rr = 0; rr < PR; ++rr) {
@@ -389,32 +429,41 @@ __device__ __forceinline__ void fold_raw(double *re, double *im, const Raw<PR, F
         if (n0 & 1) __builtin_amdgcn_sched_barrier(0);
     }
 }
-// ... blocks R0 .. D - 1 straight from memory, four slots at a time (D = 4: two blocks of samples fit the registers ahead
-// of time, the other two are asked for here)
+// ... blocks R0 .. D - 1 straight from memory, CH slots at a time (D = 4: two blocks of samples fit the registers ahead of
+// time, the other two are asked for here; double samples: all of them)
 template <int LOGM, int D, int R0, bool GAIN, int FMT>
 __device__ __forceinline__ void fold_mem(double *re, double *im, const __amdgpu_buffer_rsrc_t &rs_iq,
                                          const __amdgpu_buffer_rsrc_t &rs_w, int t, const Rot<D> &rot)
 {
     using G = Geo<LOGM>;
-    using S = Sample<FMT>;
+    using S = Smp<FMT>;
+    typedef typename S::type X;
     constexpr int M = G::M, T = G::T;
+    constexpr int CH = (sizeof(X) * (D - R0) > 32) ? 2 : 4;          // slots per request group: at most 32 VGPRs of samples
 #pragma unroll
     for (int sg = 0; sg < 4; ++sg) {
-        v2f x[4][D];
         v4f w[D];
 #pragma unroll
         for (int r = R0; r < D; ++r) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) x[e][r] = S::load(rs_iq, t * S::BYTES, (T * (4 * sg + e) + M * r) * S::BYTES);
             const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs_w, t * 16, (r * 4 + sg) * T * 16, 0);
             w[r] = (v4f){__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z), __uint_as_float(c.w)};
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float we[D];
+        for (int h = 0; h < 4 / CH; ++h) {
+            X x[CH][D];
 #pragma unroll
-            for (int r = R0; r < D; ++r) we[r] = w[r][e];
-            fold_slot<D, GAIN, R0>(re[4 * sg + e], im[4 * sg + e], x[e], we, rot, std::make_integer_sequence<int, D - R0>{});
+            for (int r = R0; r < D; ++r)
+#pragma unroll
+                for (int e = 0; e < CH; ++e) x[e][r] = S::load(rs_iq, t * S::BYTES, (T * (4 * sg + CH * h + e) + M * r) * S::BYTES);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                float we[D];
+#pragma unroll
+                for (int r = R0; r < D; ++r) we[r] = w[r][CH * h + e];
+                fold_slot<D, GAIN, R0>(re[4 * sg + CH * h + e], im[4 * sg + CH * h + e], x[e], we, rot,
+                                       std::make_integer_sequence<int, D - R0>{});
+            }
+            if constexpr (CH < 4) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -454,9 +503,10 @@ struct Args {
 template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 << LOGM) / 16, 4) void f64r_kernel(Args a)
 {
     using G = Geo<LOGM>;
-    using S = Sample<FMT>;
+    using S = Smp<FMT>;
     [[maybe_unused]] constexpr int M = G::M, T = G::T, R3 = G::R3, Q = G::Q, ST = G::ST, N = M * D;
-    constexpr int PR = D <= 2 ? D : 2;                  // blocks of the next sub-row's samples requested a barrier ahead
+    // blocks of the next sub-row's samples requested a barrier ahead (double samples: none, 64 VGPRs a block)
+    constexpr int PR = FMT == RO_FMT_F64 ? 0 : D <= 2 ? D : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *plane = reinterpret_cast<double *>(smem);
     float *image = reinterpret_cast<float *>(smem);
@@ -589,7 +639,7 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
         __builtin_amdgcn_sched_barrier(0);
         double re[16], im[16];
         // ---- the fold
-        fold_raw<LOGM, D, PR, GAIN, FMT>(re, im, raw, rot);
+        if constexpr (PR > 0) fold_raw<LOGM, D, PR, GAIN, FMT>(re, im, raw, rot);
         if constexpr (PR < D) fold_mem<LOGM, D, PR, GAIN, FMT>(re, im, iq_rsrc(row, true), rs_w, fresh(), rot);
         stamp(3);
         // ---- pass 0, and the real parts leave for exchange 1
@@ -916,6 +966,7 @@ hipError_t launch_f64reg(int bins, int fmt, const F64RegArgs &a, hipStream_t s)
     b.stamps = a.stamps;
     if (fmt == RO_FMT_F32) return f64r::launch_fmt<RO_FMT_F32>(m_log2, dec, b, s);
     if (fmt == RO_FMT_I16) return f64r::launch_fmt<RO_FMT_I16>(m_log2, dec, b, s);
+    if (fmt == RO_IQ_F64) return f64r::launch_fmt<RO_IQ_F64>(m_log2, dec, b, s);
     return hipErrorInvalidValue;
 }
 

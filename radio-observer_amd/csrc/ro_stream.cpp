@@ -51,7 +51,10 @@ void release_batch(ro_stft *h, Batch *b)
     h->batch_pool.push_back(b);
 }
 
-size_t stage_sample_bytes(const ro_stft *h) { return h->stage_fmt == RO_IQ_I16 ? 4 : 8; }
+size_t stage_sample_bytes(const ro_stft *h) { return h->stage_fmt == RO_IQ_I16 ? 4 : h->stage_fmt == RO_IQ_F64 ? 16 : 8; }
+// bytes per sample the slots are sized for: doubles only where the handle's kernel takes them (RO_PRECISION_F64 at
+// 4096 ... 65536 bins)
+size_t slot_sample_bytes(const ro_stft *h) { return h->f64reg ? 16 : 8; }
 
 // streaming buffers, all or nothing: a failure half way frees what was allocated, and the next push tries again
 int ensure_stream_slots(ro_stft *h)
@@ -67,10 +70,10 @@ int ensure_stream_slots(ro_stft *h)
     // for its whole upload -> kernel -> download chain, ~90 us; with three streams a second batch in flight overlaps it.)
     ok(hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking)) && ok(hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
     for (auto &sl : h->slot) {
-        ok(hipMalloc(&sl.d_iq, in_samples * 2 * sizeof(float))) &&
+        ok(hipMalloc(&sl.d_iq, in_samples * slot_sample_bytes(h))) &&
             ok(hipMalloc(&sl.d_rows, (size_t)h->batch_rows * h->bins * sizeof(float))) &&
             ok(hipMalloc(&sl.d_records, (size_t)h->batch_rows * sizeof(ro_scan_record_t))) &&
-            ok(hipHostMalloc(&sl.h_in, in_samples * 2 * sizeof(float), hipHostMallocDefault)) &&
+            ok(hipHostMalloc(&sl.h_in, in_samples * slot_sample_bytes(h), hipHostMallocDefault)) &&
             ok(hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming)) &&
             ok(hipEventCreateWithFlags(&sl.computed, hipEventDisableTiming)) &&
             ok(hipEventCreateWithFlags(&sl.drained, hipEventDisableTiming));
@@ -379,20 +382,35 @@ extern "C" int ro_stft_push(ro_stft_t *h, const void *iq, int format, int64_t sa
 
     // The caller's buffer is only valid during the call (src/WAVStream.cpp:113,123): copy now.  int16 samples stay
     // int16 all the way to the kernel (half the staging memory and PCIe bytes: src/WAVStream.cpp:119-120 hands them
-    // over un-normalised, the kernel widens them); float32 and the double Complex are staged as float32 (lossless for
-    // every frontend of the reference).  A stream that changes format mid-way is widened to float32 once.
+    // over un-normalised, the kernel widens them); float32 stays float32; the double Complex is staged as float32
+    // (lossless for every frontend of the reference) -- except on a handle whose kernel multiplies doubles
+    // (RO_PRECISION_F64 at 4096 ... 65536 bins), where it stays what src/Backend.h:26-29 says it is.  A stream that
+    // changes format mid-way is widened once to the wider of the two.
     const bool in_i16 = format == RO_IQ_I16;
+    const int want_fmt = in_i16 ? RO_IQ_I16 : (format == RO_IQ_F64 && h->f64reg) ? RO_IQ_F64 : RO_IQ_F32;
     const size_t cap = (size_t)(h->batch_rows - 1) * h->hop + h->bins;        // samples one slot's staging buffer holds
+    auto rank_of = [](int f) { return f == RO_IQ_I16 ? 0 : f == RO_IQ_F32 ? 1 : 2; };
     if (!h->stage_fmt_set) {
-        h->stage_fmt = in_i16 ? RO_IQ_I16 : RO_IQ_F32;
+        h->stage_fmt = want_fmt;
         h->stage_fmt_set = true;
-    } else if (h->stage_fmt == RO_IQ_I16 && !in_i16) {
-        // widen what is staged, in place and from the back (the buffer is sized for 8 bytes per sample)
+    } else if (rank_of(want_fmt) > rank_of(h->stage_fmt)) {
+        // widen what is staged, in place and from the back (the buffer is sized for the widest format the handle stages)
         char *base = static_cast<char *>(h->slot[h->batch_seq % RO_STREAM_SLOTS].h_in);
-        const int16_t *src = reinterpret_cast<const int16_t *>(base);
-        float *dst = reinterpret_cast<float *>(base);
-        for (size_t i = h->staged_have * 2; i-- > 0;) dst[i] = (float)src[i];
-        h->stage_fmt = RO_IQ_F32;
+        const size_t n = h->staged_have * 2;
+        if (h->stage_fmt == RO_IQ_I16 && want_fmt == RO_IQ_F32) {
+            const int16_t *src = reinterpret_cast<const int16_t *>(base);
+            float *dst = reinterpret_cast<float *>(base);
+            for (size_t i = n; i-- > 0;) dst[i] = (float)src[i];
+        } else if (h->stage_fmt == RO_IQ_I16) {
+            const int16_t *src = reinterpret_cast<const int16_t *>(base);
+            double *dst = reinterpret_cast<double *>(base);
+            for (size_t i = n; i-- > 0;) dst[i] = (double)src[i];
+        } else {
+            const float *src = reinterpret_cast<const float *>(base);
+            double *dst = reinterpret_cast<double *>(base);
+            for (size_t i = n; i-- > 0;) dst[i] = (double)src[i];
+        }
+        h->stage_fmt = want_fmt;
     }
     // With a row sink a push is all or nothing: the batches this call would complete are counted BEFORE anything is
     // staged, and a call whose rows would lap rows that still wait to be fetched is refused whole -- no sample taken,
@@ -423,6 +441,17 @@ extern "C" int ro_stft_push(ro_stft_t *h, const void *iq, int format, int64_t sa
         const int64_t take = std::min<int64_t>(left, (int64_t)(cap - h->staged_have));
         if (h->stage_fmt == RO_IQ_I16) {
             std::memcpy(dstb, in, (size_t)take * 4);
+        } else if (h->stage_fmt == RO_IQ_F64) {
+            double *dst = reinterpret_cast<double *>(dstb);
+            if (format == RO_IQ_F64) {
+                std::memcpy(dst, in, (size_t)take * 2 * sizeof(double));
+            } else if (in_i16) {
+                const int16_t *src = reinterpret_cast<const int16_t *>(in);
+                for (int64_t i = 0; i < take * 2; ++i) dst[i] = (double)src[i];
+            } else {
+                const float *src = reinterpret_cast<const float *>(in);
+                for (int64_t i = 0; i < take * 2; ++i) dst[i] = (double)src[i];
+            }
         } else {
             float *dst = reinterpret_cast<float *>(dstb);
             if (format == RO_IQ_F32) {

@@ -188,3 +188,54 @@ def test_register_form_int16_gain_and_custom_window(ro, oracle, torch_cuda, bins
         ok = want > 0
         assert per_bin(got[ok], want[ok]).max() <= 2e-7 if ok.any() else True
         assert np.array_equal(got[~ok], want[~ok])
+
+
+@pytest.mark.parametrize("bins,overlap", [(4096, 2048), (16384, 8192), (32768, 24576), (65536, 32768)])
+def test_true_double_samples(ro, oracle, torch_cuda, bins, overlap):
+    """struct Complex is two doubles (src/Backend.h:26-29) and the reference multiplies them as such (src/FFTBackend.cpp:
+    229-232): with RO_PRECISION_F64 at these sizes RO_IQ_F64 samples reach the kernel un-narrowed, resident and through
+    ro_stft_push.  The input is built so that narrowing it to float32 shows while two correct double transforms still
+    agree per bin: a carrier 3000 x the noise -- float32 quantises the sum in steps of 2e-4 of the noise, 1e-4 of a noise
+    bin's magnitude, and the rounding of a double transform stays 1e-10 of it."""
+    torch = torch_cuda
+    hop = bins - overlap
+    R = 9
+    T = bins + (R - 1) * hop
+    n = np.arange(T, dtype=np.float64)
+    rng = np.random.default_rng(bins)
+    z = 3000.0 * np.exp(2j * np.pi * 0.11 * n) + (rng.standard_normal(T) + 1j * rng.standard_normal(T))
+    iq = np.ascontiguousarray(np.stack([z.real, z.imag], axis=1))           # float64 [T, 2]
+    want = oracle.stft(iq, bins, overlap)
+    # resident doubles
+    d_iq = torch.from_numpy(iq).cuda()
+    d_rows = torch.full((R, bins), float("nan"), dtype=torch.float32, device="cuda")
+    with ro.Stft(bins=bins, overlap=overlap, precision=ro.RO_PRECISION_F64) as st:
+        st.run_resident(d_iq, ro.RO_IQ_F64, T, 0, R, d_rows, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = d_rows.cpu().numpy()
+        assert per_bin(got, want).max() <= 2e-7
+        # the same samples narrowed to float32 first: far outside the bar somewhere (the test can tell the difference)
+        f32 = iq.astype(np.float32)
+        st.run_resident(torch.from_numpy(f32).cuda(), ro.RO_IQ_F32, T, 0, R, d_rows, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert per_bin(d_rows.cpu().numpy(), want).max() > 1e-5
+    # call by call: pieces of float64, with an int16 and a float32 piece in front (the staged samples are widened in place)
+    lead = 1000
+    head16 = rng.integers(-3000, 3000, size=(lead, 2), dtype=np.int16)
+    head32 = rng.standard_normal((lead, 2)).astype(np.float32)
+    full = np.concatenate([head16.astype(np.float64), head32.astype(np.float64), iq], axis=0)
+    want2 = oracle.stft(full, bins, overlap)
+    with ro.Stft(bins=bins, overlap=overlap, precision=ro.RO_PRECISION_F64, max_batch_rows=2) as st:
+        st.push(head16)
+        st.push(head32)
+        for at in range(0, T, 7777):
+            st.push(iq[at:at + 7777])
+        st.flush()
+        first, rows, _ = st.fetch(1000)
+        assert first == 0 and rows.shape[0] == want2.shape[0]
+        assert per_bin(rows, want2).max() <= 2e-7
+    # a float32 handle, or an FP64 handle of another size, refuses resident doubles and narrows pushed ones as ever
+    with ro.Stft(bins=bins, overlap=overlap) as st:
+        with pytest.raises(ro.StftError) as e:
+            st.run_resident(d_iq, ro.RO_IQ_F64, T, 0, R, d_rows)
+        assert e.value.code == -2
