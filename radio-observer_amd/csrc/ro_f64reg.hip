@@ -82,6 +82,13 @@
 #define RO_F64R_EARLY_TABLES 1
 #endif
 
+// 1: the new samples of the sub-row AFTER the next one are touched into L2 ahead of time (the next one's are requested into
+// registers a barrier ahead anyway).  Measured (profiles/r06_f64r_ab.txt): the touched lines are gone again before they
+// are asked for -- FETCH_SIZE doubles (1.33 x algorithmic in all against 1.00 x) and the kernel is 2-3 % slower: off.
+#ifndef RO_F64R_TOUCH
+#define RO_F64R_TOUCH 0
+#endif
+
 // The ONE diagnostic switch of this file.  A -DRO_DIAG=1 build (tools/ab_build.sh) may set RO_F64R_STAMPS=1: s_memtime
 // deltas per phase of the sub-row loop, every wave of every workgroup, accumulated into Args::stamps
 // (tools/r6/f64r_stamps.py).  Never timed, never shipped.
@@ -794,7 +801,7 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
         // L2.  Here, because loads return in order: behind this point nothing waits for a load before the next fold.
         {
             const int64_t far = next + row_step;
-            if (far < xcd_end) {
+            if (RO_F64R_TOUCH && far < xcd_end) {
                 const int64_t s0 = (a.first_row + far) * (int64_t)a.hop + (N - a.hop);
                 const __amdgpu_buffer_rsrc_t rs_new = make_rsrc(iq + s0 * S::BYTES, (unsigned)a.hop * S::BYTES);
                 const int tt = after(fresh(), last);
