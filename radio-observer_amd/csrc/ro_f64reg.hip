@@ -51,12 +51,16 @@
 #endif
 
 // Between barrier (d) and barrier (e) a wave is on its own for two thirds of the sub-row's work, and the arbiter serves the
-// oldest wave of a SIMD first: the youngest finishes last and runs its last passes alone, at half the FP64 issue rate
-// one wave gets.  1: a wave's priority falls as it gets through the stretch (pass 1: 3, pass 2: 2, pass 3: 1,
-// magnitudes: 0), so the waves of a SIMD arrive together.  Measured (tools/r6/f64r_ab.sh, profiles/r06_f64r_ab.txt):
-// 2-4 % SLOWER at M = 16384 (the magnitudes then wait behind everything), 2 % faster at M = 4096: off.
+// oldest wave of a SIMD first.  RO_F64R_PRIO = 1: a wave's priority falls as it gets through the stretch (pass 1: 3,
+// pass 2: 2, pass 3: 1, magnitudes: 0) in the kernels of M <= 2^RO_F64R_PRIO_MAX_LOGM.  Measured (tools/r6/f64r_ab.sh,
+// profiles/r06_f64r_ab.txt): +3.5 % at M = 4096, where the four waves of a SIMD belong to four workgroups at different
+// places of their sub-rows (the one that is furthest behind goes first); -7 % at M = 16384, where they belong to one
+// workgroup and meet at its barriers anyway (the magnitudes then wait behind everything).
 #ifndef RO_F64R_PRIO
-#define RO_F64R_PRIO 0
+#define RO_F64R_PRIO 1
+#endif
+#ifndef RO_F64R_PRIO_MAX_LOGM
+#define RO_F64R_PRIO_MAX_LOGM 12
 #endif
 
 // Cache policy of the 4-byte row stores at D > 1 (a sub-row owns every D-th column: the D workgroups of a row write the
@@ -230,9 +234,9 @@ template <bool LAZY> struct TwVT {
     }
 };
 typedef TwVT<true> TwV;
-template <int P> __device__ __forceinline__ void set_prio()
+template <int LOGM, int P> __device__ __forceinline__ void set_prio()
 {
-    if constexpr (RO_F64R_PRIO) __builtin_amdgcn_s_setprio(P);
+    if constexpr (RO_F64R_PRIO && LOGM <= RO_F64R_PRIO_MAX_LOGM) __builtin_amdgcn_s_setprio(P);
 }
 struct TwS {
     d2 t[8];
@@ -680,7 +684,7 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
 #pragma unroll
         for (int j = 0; j < 16; ++j) xi[j] = rplane[x1r + Q * j];
         asm volatile("" ::: "memory");
-        set_prio<3>();
+        set_prio<LOGM, 3>();
         // this thread from here on: (k0, u) in pass 1, (k0, k1, n3) in pass 2, g' = bitrev(n3) in pass 3
         const int tr_ = fresh();
         const int k0 = tr_ / Q, u = tr_ % Q, k1 = u & 15, n3 = u >> 4;
@@ -710,7 +714,7 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
             twisted16(xr, xi, tw1v);
         }
         stamp(7);
-        set_prio<2>();
+        set_prio<LOGM, 2>();
         // ---- exchange 2 (one wave's LDS instructions execute in order: no wait between its writes and its reads); the first
         // half of pass 2's table entry is asked for in front of it
         if constexpr (!EARLY) tw2v.load(tw2, 256, K1);
@@ -730,7 +734,7 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
         stamp(8);
         // ---- pass 2
         twisted16(re, im, tw2v);
-        set_prio<1>();
+        set_prio<LOGM, 1>();
         stamp(9);
         if constexpr (R3 > 1) {
             // ---- exchange 3 without LDS: the R3 threads of one (k0, k1) sit 16 lanes apart, so a 2 x 2 transposition
@@ -782,7 +786,7 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
             }
             stamp(11);
         }
-        set_prio<0>();
+        set_prio<LOGM, 0>();
         // ---- magnitudes into the image (own territory): cell 2 k0 ST + s Q + rot(u), see the header
         int imw;
         if constexpr (R3 == 1) imw = 2 * k0 * ST + ((u + 8 * (k0 >> 3)) & 15);       // + (s ^ ((k0 >> 2) & 1)) 16
