@@ -212,7 +212,8 @@ int ro_stft_set_bands(ro_stft_t *h, const ro_bands_t *bands);
  * Replaces, for rows [first_row, first_row+rows) of a stream that is already in
  * HBM, the whole of FFTBackend::process's row loop (src/FFTBackend.cpp:211-257)
  * and WaterfallBackend::processFFT's magnitude/shift (src/WaterfallBackend.cpp:485-505).
- *   d_iq        device pointer to sample 0 of the stream, `format` F32 or I16
+ *   d_iq        device pointer to sample 0 of the stream, `format` F32 or I16 (F64 too on RO_PRECISION_F64 handles of
+ *               4096 ... 65536 bins; RO_ERR_UNSUPPORTED elsewhere)
  *   samples     number of complex samples addressable at d_iq
  *   d_rows      device, rows x row_stride floats (row_stride >= bins); required
  *   d_tile      device, rows x tile_cols floats (compact copy of columns
@@ -220,7 +221,7 @@ int ro_stft_set_bands(ro_stft_t *h, const ro_bands_t *bands);
  *   d_records   device, rows records, or NULL (needs enable_scan)
  *   stream      hipStream_t as void* (NULL = the default stream, with its usual ordering rules)
  * The call is asynchronous on `stream`.  One handle = one stream: the handle owns scratch that some paths use
- * (bins > 131072, chirp-z lengths, RO_PRECISION_F64, tile_ln), so two launches of ONE handle may only be in flight
+ * (bins > 131072, chirp-z lengths, RO_PRECISION_F64 outside 4096 ... 65536 bins, tile_ln), so two launches of ONE handle may only be in flight
  * together when they are ordered on one stream -- like FFTBackend::process, which one thread calls at a time
  * (src/JackFrontend.cpp:19-22 only logs a re-entry).  Use one handle per concurrent stream. */
 int ro_stft_run_resident(ro_stft_t *h, const void *d_iq, int format, int64_t samples,
