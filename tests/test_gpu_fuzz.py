@@ -18,8 +18,7 @@ CASES = None if SECONDS is not None else int(os.environ.get("RO_FUZZ_CASES", "60
 @pytest.mark.parametrize("seed", SEEDS)
 def test_random_configurations_match_oracle(ro, oracle, torch_cuda, seed):
     n, worst = fuzz_parity.fuzz(ro, oracle, torch_cuda, seed, seconds=SECONDS, cases=CASES)
-    print("seed %d: %d cases, worst row error f32 %.3g / f64 %.3g / one launch %.3g" %
-          (seed, n, worst[0], worst[1], worst[2]))
+    print("seed %d: %d cases, worst row error f32 %.3g / f64 %.3g" % (seed, n, worst[0], worst[1]))
     assert n >= 1
 
 
