@@ -1,6 +1,6 @@
 """A short fixed-seed slice of tests/fuzz_parity.py in the GPU suite: whole random configurations of the resident entry
 points (size, overlap, row range, format, gain, window, precision, bands, tile, stride, base offset) against the oracle.
-RO_FUZZ_CASES / RO_FUZZ_SECONDS / RO_FUZZ_SEEDS (comma-separated) widen it; profiles/r05_fuzz.txt holds a long run."""
+RO_FUZZ_CASES / RO_FUZZ_SECONDS / RO_FUZZ_SEEDS (comma-separated) widen it; profiles/r06_fuzz.txt (round 5: r05_fuzz.txt) holds a long run."""
 import os
 
 import pytest
