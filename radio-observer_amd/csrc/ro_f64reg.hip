@@ -182,6 +182,18 @@ template <typename TW> __device__ __forceinline__ void twisted16(double *re, dou
     level16<3>(re, im, tw, std::make_integer_sequence<int, 8>{});
 }
 
+// its first LEVELS levels only: sixteen / 2^LEVELS twisted radix-2^LEVELS transforms over the TOP bits of the position, one
+// per value of the low bits (rows batched into a workgroup: see f64r_kernel's LOGB); result kd at top bits = bitrev(kd)
+template <int LEVELS, typename TW> __device__ __forceinline__ void twisted16_top(double *re, double *im, TW &&tw)
+{
+    if constexpr (LEVELS >= 1) level16<0>(re, im, tw, std::make_integer_sequence<int, 1>{});
+    if constexpr (LEVELS >= 2) level16<1>(re, im, tw, std::make_integer_sequence<int, 2>{});
+    if constexpr (LEVELS >= 3) {
+        tw.second_half();                               // (w^2 W_8, where it is made from w^2)
+        level16<2>(re, im, tw, std::make_integer_sequence<int, 4>{});
+    }
+}
+
 // eight twiddles in VGPRs (per-lane table entry) or SGPRs (an entry the whole wave shares)
 template <bool LAZY> struct TwVT {
     d2 t[8];
@@ -326,18 +338,20 @@ template <int PR, int FMT> struct Raw {
     typename Smp<FMT>::type x[PR > 0 ? PR : 1][16];
     v4f w[PR > 0 ? PR : 1][4];
 };
-template <int LOGM, int PR, int FMT>
-__device__ __forceinline__ void raw_load(Raw<PR, FMT> &r, const __amdgpu_buffer_rsrc_t &rs_iq, const __amdgpu_buffer_rsrc_t &rs_w, int t)
+// (TS = samples between two slots of a thread, MS = samples between two blocks; voff_iq / voff_w = the lane's byte offsets
+// into the samples and into the window table)
+template <int TS, int MS, int PR, int FMT>
+__device__ __forceinline__ void raw_load(Raw<PR, FMT> &r, const __amdgpu_buffer_rsrc_t &rs_iq, const __amdgpu_buffer_rsrc_t &rs_w,
+                                         int voff_iq, int voff_w)
 {
-    using G = Geo<LOGM>;
     using S = Smp<FMT>;
 #pragma unroll
     for (int rr = 0; rr < PR; ++rr) {
 #pragma unroll
-        for (int n0 = 0; n0 < 16; ++n0) r.x[rr][n0] = S::load(rs_iq, t * S::BYTES, (G::T * n0 + G::M * rr) * S::BYTES);
+        for (int n0 = 0; n0 < 16; ++n0) r.x[rr][n0] = S::load(rs_iq, voff_iq, (TS * n0 + MS * rr) * S::BYTES);
 #pragma unroll
         for (int sg = 0; sg < 4; ++sg) {
-            const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs_w, t * 16, (rr * 4 + sg) * G::T * 16, 0);
+            const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs_w, voff_w, (rr * 4 + sg) * TS * 16, 0);
             r.w[rr][sg] = (v4f){__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z), __uint_as_float(c.w)};
         }
     }
@@ -422,7 +436,7 @@ __device__ __forceinline__ void fold_slot(double &sr, double &si, const X (&x)[D
 }
 
 // Blocks 0 .. PR - 1 from the registers of raw_load ...
-template <int LOGM, int D, int PR, bool GAIN, int FMT>
+template <int D, int PR, bool GAIN, int FMT>
 __device__ __forceinline__ void fold_raw(double *re, double *im, const Raw<PR, FMT> &r, const Rot<D> &rot)
 {
     typedef typename Smp<FMT>::type X;
@@ -442,21 +456,19 @@ __device__ __forceinline__ void fold_raw(double *re, double *im, const Raw<PR, F
 }
 // ... blocks R0 .. D - 1 straight from memory, CH slots at a time (D = 4: two blocks of samples fit the registers ahead of
 // time, the other two are asked for here; double samples: all of them)
-template <int LOGM, int D, int R0, bool GAIN, int FMT>
+template <int TS, int MS, int D, int R0, bool GAIN, int FMT>
 __device__ __forceinline__ void fold_mem(double *re, double *im, const __amdgpu_buffer_rsrc_t &rs_iq,
-                                         const __amdgpu_buffer_rsrc_t &rs_w, int t, const Rot<D> &rot)
+                                         const __amdgpu_buffer_rsrc_t &rs_w, int voff_iq, int voff_w, const Rot<D> &rot)
 {
-    using G = Geo<LOGM>;
     using S = Smp<FMT>;
     typedef typename S::type X;
-    constexpr int M = G::M, T = G::T;
     constexpr int CH = (sizeof(X) * (D - R0) > 32) ? 2 : 4;          // slots per request group: at most 32 VGPRs of samples
 #pragma unroll
     for (int sg = 0; sg < 4; ++sg) {
         v4f w[D];
 #pragma unroll
         for (int r = R0; r < D; ++r) {
-            const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs_w, t * 16, (r * 4 + sg) * T * 16, 0);
+            const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs_w, voff_w, (r * 4 + sg) * TS * 16, 0);
             w[r] = (v4f){__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z), __uint_as_float(c.w)};
         }
 #pragma unroll
@@ -465,7 +477,7 @@ __device__ __forceinline__ void fold_mem(double *re, double *im, const __amdgpu_
 #pragma unroll
             for (int r = R0; r < D; ++r)
 #pragma unroll
-                for (int e = 0; e < CH; ++e) x[e][r] = S::load(rs_iq, t * S::BYTES, (T * (4 * sg + CH * h + e) + M * r) * S::BYTES);
+                for (int e = 0; e < CH; ++e) x[e][r] = S::load(rs_iq, voff_iq, (TS * (4 * sg + CH * h + e) + MS * r) * S::BYTES);
 #pragma unroll
             for (int e = 0; e < CH; ++e) {
                 float we[D];
@@ -511,11 +523,19 @@ struct Args {
     unsigned long long *stamps;  // diagnostic builds only (RO_F64R_STAMPS), else nullptr
 };
 
-template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 << LOGM) / 16, 4) void f64r_kernel(Args a)
+template <int LOGM, int D, int FMT, bool GAIN, int LOGB = 0>
+__global__ __launch_bounds__((1 << LOGM) / 16, 4) void f64r_kernel(Args a)
 {
     using G = Geo<LOGM>;
     using S = Smp<FMT>;
     [[maybe_unused]] constexpr int M = G::M, T = G::T, R3 = G::R3, Q = G::Q, ST = G::ST, N = M * D;
+    // LOGB > 0: bins NB = 4096 >> LOGB (2048 ... 256), B = 2^LOGB ROWS in the M = 4096 workgroup.  The workgroup's index
+    // i = n2 + 16 j1 + 256 n0 carries the row in the low bits of n2 = b + B m and sample m + R j1 + 16 R n0 of row b
+    // (R = 16 / B): passes 0 and 1 are the 4096-point transform's own, with its own tables, and the row's last digit m is
+    // what the first LV = log2 R levels of pass 2 transform -- with the 4096-point table again, W_4096^(K1 B m) =
+    // W_NB^(K1 m); slot p of the result is row p mod B, k2 = bitrev(p / B).  A "row" of the loop below is then a tile of B.
+    static_assert(LOGB == 0 || (LOGM == 12 && D == 1 && LOGB <= 4), "rows are batched into the M = 4096 workgroup only");
+    [[maybe_unused]] constexpr int B = 1 << LOGB, NB = N >> LOGB, TS = T >> LOGB, LV = 4 - LOGB;
     // blocks of the next sub-row's samples requested a barrier ahead (double samples: none, 64 VGPRs a block)
     constexpr int PR = FMT == RO_FMT_F64 ? 0 : D <= 2 ? D : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -530,9 +550,10 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
 
     // XCD-aware placement (speed only): workgroups b and b + 8 share an XCD under round-robin dispatch; each XCD takes
     // a contiguous run of rows, its workgroups take the D sub-rows of consecutive rows at the same time
-    const int64_t per_xcd = (a.rows + 7) / 8;
+    const int64_t units = (a.rows + B - 1) >> LOGB;
+    const int64_t per_xcd = (units + 7) / 8;
     const int64_t xcd_first = (int64_t)(blockIdx.x & 7) * per_xcd;
-    const int64_t xcd_end = xcd_first + per_xcd < a.rows ? xcd_first + per_xcd : a.rows;
+    const int64_t xcd_end = xcd_first + per_xcd < units ? xcd_first + per_xcd : units;
     const int slots = gridDim.x >> 3;                  // a multiple of D
     const int slot = blockIdx.x >> 3;
     const int q = slot % D;
@@ -606,9 +627,23 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
         }
     };
     auto readout_store = [&](int64_t prow) {
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.rows_out + prow * a.row_stride, N * 4);
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.rows_out + prow * a.row_stride, LOGB == 0 ? N * 4 : 0);
         const int lane = fresh() & 63;
-        if constexpr (D == 1) {
+        if constexpr (LOGB > 0) {
+            // slot s = wave + 4 it of the image belongs to row s mod B of the tile and holds its bins 256 bitrev(s / B) + 0 .. 255
+            const int rc = lane & 3, ul = lane >> 2;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int s = wave + 4 * it;
+                const int64_t orow = prow * B + (s & (B - 1));
+                const __amdgpu_buffer_rsrc_t rsb = make_rsrc(a.rows_out + orow * a.row_stride, orow < a.rows ? NB * 4 : 0);
+                int sb = 0;
+#pragma unroll
+                for (int p = 0; p < 16; ++p) sb = s == p ? 256 * brev<LV>(p >> LOGB) : sb;
+                const int col = ((4 * rc + 16 * ul + sb) + NB / 2) & (NB - 1);
+                buf_store_f4(m[4 * it], m[4 * it + 1], m[4 * it + 2], m[4 * it + 3], rsb, col * 4, 0);
+            }
+        } else if constexpr (D == 1) {
             const int rc = lane & 3, ul = lane >> 2;
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
@@ -631,12 +666,35 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
         }
     };
 
-    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(a.window_k, (unsigned)N * 4);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(a.window_k, (unsigned)NB * 4);
     auto iq_rsrc = [&](int64_t r, bool valid) {
-        return make_rsrc(iq + (a.first_row + r) * (int64_t)a.hop * S::BYTES, valid ? (unsigned)N * S::BYTES : 0u);
+        if constexpr (LOGB == 0) {
+            return make_rsrc(iq + (a.first_row + r) * (int64_t)a.hop * S::BYTES, valid ? (unsigned)N * S::BYTES : 0u);
+        } else {
+            // the tile's rows as ONE range (they overlap or follow one another): rows r B .. r B + vb - 1, vb = the valid ones
+            const int64_t left = a.rows - r * B;
+            const unsigned vb = left < B ? (unsigned)left : (unsigned)B;
+            return make_rsrc(iq + (a.first_row + r * B) * (int64_t)a.hop * S::BYTES,
+                             valid ? ((vb - 1u) * (unsigned)a.hop + (unsigned)NB) * S::BYTES : 0u);
+        }
+    };
+    // the lane's place in the samples and in the window table, from its thread number
+    auto lane_off = [&](int th, int &voff_iq, int &voff_w) {
+        if constexpr (LOGB == 0) {
+            voff_iq = th * S::BYTES;
+            voff_w = th * 16;
+        } else {
+            const int b = th & (B - 1), ti = ((th & 15) >> LOGB) + (16 >> LOGB) * (th >> 4);
+            voff_iq = (b * a.hop + ti) * S::BYTES;
+            voff_w = ti * 16;
+        }
     };
     Raw<PR, FMT> raw;
-    raw_load<LOGM, PR, FMT>(raw, iq_rsrc(row, true), rs_w, t);
+    {
+        int vi, vw;
+        lane_off(t, vi, vw);
+        raw_load<TS, M, PR, FMT>(raw, iq_rsrc(row, true), rs_w, vi, vw);
+    }
 
     constexpr int TOUCHES = D < 2 ? D : 2;               // x T x 128 bytes of new samples touched ahead (hop <= N / 2 whole)
     unsigned touch[TOUCHES] = {};
@@ -650,8 +708,12 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
         __builtin_amdgcn_sched_barrier(0);
         double re[16], im[16];
         // ---- the fold
-        if constexpr (PR > 0) fold_raw<LOGM, D, PR, GAIN, FMT>(re, im, raw, rot);
-        if constexpr (PR < D) fold_mem<LOGM, D, PR, GAIN, FMT>(re, im, iq_rsrc(row, true), rs_w, fresh(), rot);
+        if constexpr (PR > 0) fold_raw<D, PR, GAIN, FMT>(re, im, raw, rot);
+        if constexpr (PR < D) {
+            int vi, vw;
+            lane_off(fresh(), vi, vw);
+            fold_mem<TS, M, D, PR, GAIN, FMT>(re, im, iq_rsrc(row, true), rs_w, vi, vw, rot);
+        }
         stamp(3);
         // ---- pass 0, and the real parts leave for exchange 1
         if constexpr (D == 1) {
@@ -703,7 +765,7 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
             }
         };
         if constexpr (EARLY) {
-            tw2v.load(tw2, 256, K1);
+            if constexpr (LV > 0) tw2v.load(tw2, 256, K1);
             load_tw3();
         }
         // ---- pass 1.  From here to the completed image a wave touches its own territories only.
@@ -717,7 +779,7 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
         set_prio<LOGM, 2>();
         // ---- exchange 2 (one wave's LDS instructions execute in order: no wait between its writes and its reads); the first
         // half of pass 2's table entry is asked for in front of it
-        if constexpr (!EARLY) tw2v.load(tw2, 256, K1);
+        if constexpr (!EARLY && LV > 0) tw2v.load(tw2, 256, K1);
         const int x2w = k0 * ST + u, x2r = k0 * ST + k1 * G::S2 + n3;
 #pragma unroll
         for (int k = 0; k < 16; ++k) plane[x2w + k * G::S2] = xr[brev<4>(k)];
@@ -732,8 +794,9 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
         for (int j = 0; j < 16; ++j) im[j] = rplane[x2r + R3 * j];
         asm volatile("" ::: "memory");
         stamp(8);
-        // ---- pass 2
-        twisted16(re, im, tw2v);
+        // ---- pass 2 (rows batched into the workgroup: what is left of their transform)
+        if constexpr (LOGB == 0) twisted16(re, im, tw2v);
+        else twisted16_top<LV>(re, im, tw2v);
         set_prio<LOGM, 1>();
         stamp(9);
         if constexpr (R3 > 1) {
@@ -817,7 +880,11 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
         __builtin_amdgcn_sched_barrier(0);
         // ---- the next sub-row's samples and window: asked for now, needed behind the barrier and the read-out.  (The
         // requests may not start before the last magnitude exists: their registers are the transform's.)
-        raw_load<LOGM, PR, FMT>(raw, iq_rsrc(has_next ? next : row, has_next), rs_w, after(fresh(), last));
+        {
+            int vi, vw;
+            lane_off(after(fresh(), last), vi, vw);
+            raw_load<TS, M, PR, FMT>(raw, iq_rsrc(has_next ? next : row, has_next), rs_w, vi, vw);
+        }
         wg_sync();                                      // (e) the image of this sub-row is complete
         stamp(13);
         // ---- the image: out of LDS, then LDS is free for the next sub-row's exchange, then on its way to the row
@@ -837,7 +904,7 @@ template <int LOGM, int D, int FMT, bool GAIN> __global__ __launch_bounds__((1 <
     }
 }
 
-template <int LOGM, int D, int FMT> static hipError_t launch_one(const Args &a, hipStream_t s)
+template <int LOGM, int D, int FMT, int LOGB = 0> static hipError_t launch_one(const Args &a, hipStream_t s)
 {
     using G = Geo<LOGM>;
     static std::mutex lock;
@@ -851,8 +918,8 @@ template <int LOGM, int D, int FMT> static hipError_t launch_one(const Args &a, 
     {
         std::lock_guard<std::mutex> g(lock);
         if (!ready[dev]) {
-            const void *fn[2] = {reinterpret_cast<const void *>(&f64r_kernel<LOGM, D, FMT, false>),
-                                 reinterpret_cast<const void *>(&f64r_kernel<LOGM, D, FMT, true>)};
+            const void *fn[2] = {reinterpret_cast<const void *>(&f64r_kernel<LOGM, D, FMT, false, LOGB>),
+                                 reinterpret_cast<const void *>(&f64r_kernel<LOGM, D, FMT, true, LOGB>)};
             for (int i = 0; i < 2; ++i)
                 if ((e = hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES)) != hipSuccess) return e;
             if ((e = hipDeviceGetAttribute(&cus_of[dev], hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
@@ -861,21 +928,25 @@ template <int LOGM, int D, int FMT> static hipError_t launch_one(const Args &a, 
         cus = cus_of[dev];
     }
     // persistent grid: 1024 / T workgroups per CU, per XCD a multiple of D, never more than the XCD's share of sub-rows
-    const int64_t per_xcd = (a.rows + 7) / 8;
+    const int64_t per_xcd = (((a.rows + (1 << LOGB) - 1) >> LOGB) + 7) / 8;      // (LOGB > 0: tiles of 2^LOGB rows)
     int64_t slots = (int64_t)(cus / 8) * (1024 / G::T);
     if (slots > per_xcd * D) slots = per_xcd * D;
     slots = slots / D * D;
     if (slots < D) slots = D;
     // (the reference's "iq_gain" is 0 in every shipped config: the additions exist only in the kernel that needs them)
-    if (a.gain != 0.0) hipLaunchKernelGGL((f64r_kernel<LOGM, D, FMT, true>), dim3((unsigned)(slots * 8)), dim3(G::T), G::LDS_BYTES, s, a);
-    else hipLaunchKernelGGL((f64r_kernel<LOGM, D, FMT, false>), dim3((unsigned)(slots * 8)), dim3(G::T), G::LDS_BYTES, s, a);
+    if (a.gain != 0.0) hipLaunchKernelGGL((f64r_kernel<LOGM, D, FMT, true, LOGB>), dim3((unsigned)(slots * 8)), dim3(G::T), G::LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((f64r_kernel<LOGM, D, FMT, false, LOGB>), dim3((unsigned)(slots * 8)), dim3(G::T), G::LDS_BYTES, s, a);
     return hipGetLastError();
 }
 
-template <int FMT> static hipError_t launch_fmt(int m_log2, int dec, const Args &a, hipStream_t s)
+template <int FMT> static hipError_t launch_fmt(int m_log2, int dec, int logb, const Args &a, hipStream_t s)
 {
 #define RO_F64R_CASE(LM, DD) \
     if (m_log2 == LM && dec == DD) return launch_one<LM, DD, FMT>(a, s)
+    if (logb == 1) return launch_one<12, 1, FMT, 1>(a, s);
+    if (logb == 2) return launch_one<12, 1, FMT, 2>(a, s);
+    if (logb == 3) return launch_one<12, 1, FMT, 3>(a, s);
+    if (logb == 4) return launch_one<12, 1, FMT, 4>(a, s);
     RO_F64R_CASE(12, 1);
     RO_F64R_CASE(13, 1);
     RO_F64R_CASE(14, 1);
@@ -885,9 +956,14 @@ template <int FMT> static hipError_t launch_fmt(int m_log2, int dec, const Args 
     return hipErrorInvalidValue;
 }
 
-static bool plan(int bins, int &m_log2, int &dec)
+static bool plan(int bins, int &m_log2, int &dec, int &logb)
 {
+    logb = 0;
     switch (bins) {
+    case 256: m_log2 = 12; dec = 1; logb = 4; return true;       // 16 rows in the 4096-point workgroup
+    case 512: m_log2 = 12; dec = 1; logb = 3; return true;
+    case 1024: m_log2 = 12; dec = 1; logb = 2; return true;
+    case 2048: m_log2 = 12; dec = 1; logb = 1; return true;
     case 4096: m_log2 = 12; dec = 1; return true;
     case 8192: m_log2 = 13; dec = 1; return true;
     case 16384: m_log2 = 14; dec = 1; return true;
@@ -922,15 +998,17 @@ static void tw8(int64_t n, int64_t e, double2 *out)
 
 bool f64reg_supported(int bins)
 {
-    int m, d;
-    return f64r::plan(bins, m, d);
+    int m, d, b;
+    return f64r::plan(bins, m, d, b);
 }
 
 void f64reg_tables(int bins, const float *window, F64RegTables &t)
 {
-    int m_log2 = 0, D = 0;
-    if (!f64r::plan(bins, m_log2, D)) return;
-    const int M = 1 << m_log2, T = M / 16, R3 = M / 4096;
+    int m_log2 = 0, D = 0, logb = 0;
+    if (!f64r::plan(bins, m_log2, D, logb)) return;
+    // (rows batched into the workgroup, logb > 0: the window in the order of ONE row's threads, T = bins / 16; the twiddle
+    // tables are the 4096-point ones)
+    const int M = (1 << m_log2) >> logb, T = M / 16, R3 = (1 << m_log2) / 4096;
     t.window_k.assign((size_t)bins, 0.f);
     for (int r = 0; r < D; ++r)
         for (int sg = 0; sg < 4; ++sg)
@@ -959,8 +1037,8 @@ void f64reg_tables(int bins, const float *window, F64RegTables &t)
 hipError_t launch_f64reg(int bins, int fmt, const F64RegArgs &a, hipStream_t s)
 {
     if (a.rows <= 0) return hipSuccess;
-    int m_log2 = 0, dec = 0;
-    if (!f64r::plan(bins, m_log2, dec)) return hipErrorInvalidValue;
+    int m_log2 = 0, dec = 0, logb = 0;
+    if (!f64r::plan(bins, m_log2, dec, logb)) return hipErrorInvalidValue;
     f64r::Args b;
     b.iq = a.iq;
     b.window_k = a.window_k;
@@ -975,9 +1053,9 @@ hipError_t launch_f64reg(int bins, int fmt, const F64RegArgs &a, hipStream_t s)
     b.hop = a.hop;
     b.gain = a.gain;
     b.stamps = a.stamps;
-    if (fmt == RO_FMT_F32) return f64r::launch_fmt<RO_FMT_F32>(m_log2, dec, b, s);
-    if (fmt == RO_FMT_I16) return f64r::launch_fmt<RO_FMT_I16>(m_log2, dec, b, s);
-    if (fmt == RO_IQ_F64) return f64r::launch_fmt<RO_IQ_F64>(m_log2, dec, b, s);
+    if (fmt == RO_FMT_F32) return f64r::launch_fmt<RO_FMT_F32>(m_log2, dec, logb, b, s);
+    if (fmt == RO_FMT_I16) return f64r::launch_fmt<RO_FMT_I16>(m_log2, dec, logb, b, s);
+    if (fmt == RO_IQ_F64) return f64r::launch_fmt<RO_IQ_F64>(m_log2, dec, logb, b, s);
     return hipErrorInvalidValue;
 }
 

@@ -55,6 +55,8 @@ def test_f64r_maps_reproduce_the_fft_without_bank_conflicts():
     assert "butterflies ok" in out
     for m, d in ((4096, 1), (8192, 1), (16384, 1), (16384, 2), (16384, 4)):
         assert "M = %5d  D = %d" % (m, d) in out
+    for bins in (256, 512, 1024, 2048):                  # rows batched into the 4096-point workgroup
+        assert "bins %4d, %2d rows per workgroup" % (bins, 4096 // bins) in out
     assert "all maps ok, every LDS access conflict-free" in out
     src = open(os.path.join(ROOT, "radio-observer_amd", "csrc", "ro_f64reg.hip")).read()
     assert "ST = T + 16 * R3" in src and "S2 = Q + (R3 == 1 ? 1 : 2)" in src

@@ -360,6 +360,134 @@ def emulate(M, D, q, x, w, verbose=False):
     return mags, cols, lds.conf
 
 
+def twisted16_levels(v, tw, levels):
+    """the first `levels` levels of twisted16: a twisted radix-2^levels transform over the TOP bits of the position, one
+    per value of the low bits; result kd at top bits = bitrev(kd)"""
+    v = v.copy()
+    for lvl in range(levels):
+        L = 16 >> lvl
+        h = L // 2
+        for beta in range(1 << lvl):
+            e = bitrev(beta, lvl) * h
+            idx = {0: 0, 1: 1, 2: 2 + (e % 4) // 2, 3: 4 + e % 4}[lvl]
+            rot = e // 4
+            for m in range(h):
+                i0, i1 = beta * L + m, beta * L + m + h
+                v[..., i0], v[..., i1] = bfly(v[..., i0], v[..., i1], tw[..., idx], rot)
+    return v
+
+
+def emulate_tile(N, x, w):
+    """bins N = 256 R < 4096: B = 4096 / N = 16 / R ROWS in the M = 4096 workgroup (f64r_kernel<12, 1, ., ., LOGB>).  The tile
+    index i = n2 + 16 j1 + 256 n0 carries the row in the LOW bits of n2 = b + B m, and sample i' = m + R j1 + 16 R n0 of
+    row b: passes 0 and 1 are the 4096-point kernel's own, with its own tables, and the row's last digit m is what the first
+    log2(R) levels of pass 2 transform -- again with the 4096-point table: W_4096^(K1 B m) = W_N^(K1 m).
+    x [B][N] windowed-to-be rows, w [N] -> magnitudes [B][N] by bin, columns [B][N]"""
+    g = Geometry(4096, 1)
+    T, Q, ST = g.T, g.Q, g.ST
+    B = 4096 // N
+    R = 16 // B
+    r = R.bit_length() - 1
+    tb = tables(g)
+    t = np.arange(T)
+    lds = LDS(g)
+    # ---- pass 0: thread t = (b, tt), slot n0: sample tt + (N / 16) n0 of row b
+    b = t % B
+    tt = (t % 16) // B + R * (t // 16)
+    assert sorted(zip(b.tolist(), tt.tolist())) == [(bb, q) for bb in range(B) for q in range(N // 16)]
+    v = np.zeros((T, 16), dtype=np.complex128)
+    for n0 in range(16):
+        i = tt + (N // 16) * n0
+        v[:, n0] = w[i] * x[b, i]
+    # a wave's load of one slot: per row a run of consecutive samples
+    for wv in range(T // 64):
+        ln = slice(64 * wv, 64 * wv + 64)
+        for bb in range(B):
+            run_ = np.sort(tt[ln][b[ln] == bb])
+            assert np.all(np.diff(run_) == 1) and run_.size == 64 // B
+    v = twisted16(v, np.broadcast_to(tb["p0"][0], (T, 8)))
+    k0 = t // Q
+    n2 = t % Q
+    xin = np.zeros((T, 16), dtype=np.complex128)
+    for part in ("real", "imag"):
+        lds.mem[:] = np.nan
+        for kk in range(16):
+            lds.write("x1", kk * ST + t, getattr(v[:, BR4[kk]], part))
+        got = np.zeros((T, 16))
+        for j1 in range(16):
+            got[:, j1] = lds.read("x1", k0 * ST + n2 + Q * j1)
+        if part == "real":
+            xin.real = got
+        else:
+            xin.imag = got
+    lds.territory_check = True
+    v = twisted16(xin, tb["p1"][0][k0])
+    u = t % Q
+    k1 = u % 16
+    xin = np.zeros((T, 16), dtype=np.complex128)
+    for part in ("real", "imag"):
+        lds.mem[:] = np.nan
+        for kk in range(16):
+            lds.write("x2", k0 * ST + kk * g.S2 + n2, getattr(v[:, BR4[kk]], part), k0)
+        got = np.zeros((T, 16))
+        for j2 in range(16):
+            got[:, j2] = lds.read("x2", k0 * ST + k1 * g.S2 + j2, k0)
+        if part == "real":
+            xin.real = got
+        else:
+            xin.imag = got
+    # ---- pass 2, its first log2(R) levels only: position p = b + B m
+    K1 = k0 + 16 * k1
+    v = twisted16_levels(xin, tb["p2"][0][K1], r)
+    # slot s: row s % B, k2 = bitrev_r(s / B); bin k0 + 16 k1 + 256 k2
+    img = np.full(2 * g.PLANE, np.nan)
+    cell_bin = np.full(2 * g.PLANE, -1)
+    cell_row = np.full(2 * g.PLANE, -1)
+    for s_ in range(16):
+        c = image_cell(g, k0, s_, u)
+        lds._conf("img.w32", c * 4, 4)
+        img[c] = np.abs(v[:, s_])
+        cell_bin[c] = k0 + 16 * k1 + 256 * bitrev(s_ // B, r)
+        cell_row[c] = s_ % B
+    lane = t & 63
+    wv = t >> 6
+    mags = np.full((B, N), np.nan)
+    cols = np.full((B, N), -1)
+    rc, ul = lane & 3, lane >> 2
+    for it in range(4):
+        s_ = wv + 4 * it                                                  # (wave-uniform: the row of a store is, too)
+        quad = [image_cell(g, 4 * rc + e, s_, ul) for e in range(4)]
+        for c in quad:
+            lds._conf("imgw.r32", c * 4, 4)
+        kb = np.stack([cell_bin[c] for c in quad], axis=1)
+        rb = np.stack([cell_row[c] for c in quad], axis=1)
+        assert np.all(rb == (s_ % B)[:, None]) and np.all(np.diff(kb, axis=1) == 1) and np.all(kb[:, 0] % 4 == 0)
+        first = kb[:, 0].reshape(-1, 64)
+        assert np.all(np.diff(first, axis=1) == 4)
+        assert np.all(kb[:, 0] == 4 * rc + 16 * ul + 256 * np.array([bitrev(int(q) // B, r) for q in s_]))
+        for e in range(4):
+            mags[rb[:, e], kb[:, e]] = img[quad[e]]
+            cols[rb[:, e], kb[:, e]] = (kb[:, e] + N // 2) % N
+    assert not np.isnan(mags).any()
+    return mags, cols, lds.conf
+
+
+def run_tile(N, seed=0):
+    B = 4096 // N
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, N)) + 1j * rng.standard_normal((B, N))
+    w = rng.random(N)
+    mags, cols, conf = emulate_tile(N, x, w)
+    err = 0.0
+    for b in range(B):
+        want = np.abs(np.fft.fft(x[b] * w))
+        row = np.full(N, np.nan)
+        row[cols[b]] = mags[b]
+        err = max(err, np.abs(row - np.roll(want, N // 2)).max() / want.max())
+    assert err < 1e-12, (N, err)
+    return err, conf
+
+
 def run(M, D, seed=0):
     g = Geometry(M, D)
     N = g.N
@@ -390,6 +518,12 @@ def main():
                   % (M, D, M * D, err, "  ".join("%s %dx" % (k, v) for k, v in sorted(conf.items()))))
             for k, v in conf.items():
                 worst_conf[k] = max(worst_conf.get(k, 1), v)
+    for N in (256, 512, 1024, 2048):                                              # rows batched into the M = 4096 workgroup
+        err, conf = run_tile(N, seed=N)
+        print("bins %4d, %2d rows per workgroup: max err / row max %.2e   LDS cycles vs conflict-free: %s"
+              % (N, 4096 // N, err, "  ".join("%s %dx" % (k, v) for k, v in sorted(conf.items()))))
+        for k, v in conf.items():
+            worst_conf[k] = max(worst_conf.get(k, 1), v)
     # ds_read_b64 / ds_write_b64 count 2 dwords per lane: "1x" means one pass per lane group
     # (a 2-way conflict on ds_write_b32 costs nothing: the store's data transfer takes twice its LDS-array cycles)
     bad = {k: v for k, v in worst_conf.items() if v > (2 if k == "img.w32.w32" or k == "img.w32" else 1)}

@@ -49,10 +49,11 @@ def parity(sizes):
             ok = ok and nanc == 0 and e.max() <= 2e-7
         # int16 + gain + custom window
         rng = np.random.default_rng(3)
-        i16 = rng.integers(-20000, 20000, size=(bins + 9 * 1024, 2), dtype=np.int16)
+        hop = min(1024, bins // 4)
+        i16 = rng.integers(-20000, 20000, size=(bins + 37 * hop, 2), dtype=np.int16)
         w = rng.random(bins).astype(np.float32)
-        got = rows_of(i16, bins, bins - 1024, fmt=ro.RO_IQ_I16, window_table=w, iq_gain=123.5)
-        want = ro_oracle.stft(i16.astype(np.float64), bins, bins - 1024, w=w, gain=123.5)
+        got = rows_of(i16, bins, bins - hop, fmt=ro.RO_IQ_I16, window_table=w, iq_gain=123.5)
+        want = ro_oracle.stft(i16.astype(np.float64), bins, bins - hop, w=w, gain=123.5)
         e = np.abs(got.astype(np.float64) - want) / np.maximum(want.astype(np.float64), 1e-300)
         print("bins %6d int16 + gain + custom window: per-bin max %.3g" % (bins, e.max()), flush=True)
         ok = ok and e.max() <= 2e-7
@@ -86,7 +87,7 @@ def rate(bins, overlap, R, steps=12):
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--rate-only", action="store_true")
-    p.add_argument("--sizes", default="4096,8192,16384,32768,65536")
+    p.add_argument("--sizes", default="256,512,1024,2048,4096,8192,16384,32768,65536")
     a = p.parse_args()
     sizes = [int(x) for x in a.sizes.split(",")]
     ok = True
@@ -94,7 +95,7 @@ def main():
         ok = parity(sizes)
         print("parity:", "OK" if ok else "FAILED", flush=True)
     if ok:
-        shapes = {4096: (2048, 65536), 8192: (6144, 32768), 16384: (12288, 16384), 32768: (24576, 16384), 65536: (49152, 8192)}
+        shapes = {256: (128, 1 << 20), 512: (256, 1 << 19), 1024: (512, 1 << 18), 2048: (1024, 1 << 17), 4096: (2048, 65536), 8192: (6144, 32768), 16384: (12288, 16384), 32768: (24576, 16384), 65536: (49152, 8192)}
         for bins in sizes:
             rate(bins, *shapes[bins])
     return 0 if ok else 1
