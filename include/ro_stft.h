@@ -42,7 +42,7 @@ enum { RO_WINDOW_NUTTALL = 0, RO_WINDOW_HANN = 1, RO_WINDOW_CUSTOM = 2 };
  *  F32: interleaved float32 I,Q -- RawStream's wire format (src/RawStream.cpp:33,61-62)
  *  I16: interleaved int16 I,Q, un-normalised -- WAVStream (src/WAVStream.cpp:119-120)
  *  F64: {double real; double imag;} -- struct Complex (src/Backend.h:26-29).
- *       RO_PRECISION_F64 handles of 4096 ... 65536 bins stage, upload and multiply
+ *       RO_PRECISION_F64 handles of 256 ... 65536 bins stage, upload and multiply
  *       the doubles themselves ((double)sample x (double)w, src/FFTBackend.cpp:
  *       229-232) and also take them device-resident; every other handle accepts
  *       them through ro_stft_push only and narrows them to float32 while staging
@@ -55,8 +55,8 @@ enum { RO_IQ_F32 = 0, RO_IQ_I16 = 1, RO_IQ_F64 = 2 };
  *       reference's double-precision rows (measured 1-3e-7), which is the norm-wise reading of "1e-5 relative".
  *  F64: the reference's own arithmetic type -- double window multiply, double transform, double sqrt, one
  *       narrowing to the float row (src/FFTBackend.cpp:117-120,229-236, src/WaterfallBackend.cpp:492-505).  Bins
- *       4096 ... 65536 keep the complex-double row in a compute unit's registers (samples read once, row written
- *       once); the other powers of two are passes through HBM scratch.  Rows within 1e-5 of the reference PER BIN
+ *       256 ... 65536 keep the complex-double row in a compute unit's registers (samples read once, row written
+ *       once; below 4096 bins 2 ... 16 rows share a workgroup); 131072 ... 1048576 are passes through HBM scratch.  Rows within 1e-5 of the reference PER BIN
  *       (measured <= 1.2e-7: one float32 ulp, at 60 dB of dynamic range); 2.5 times slower than F32 at 32768 bins.
  *       Complex-spectra output is F32 only.
  *  (Value 2 was ABI 4's RO_PRECISION_F64_ONE_LAUNCH, an experiment that measured slower; ro_stft_create answers
@@ -213,7 +213,7 @@ int ro_stft_set_bands(ro_stft_t *h, const ro_bands_t *bands);
  * HBM, the whole of FFTBackend::process's row loop (src/FFTBackend.cpp:211-257)
  * and WaterfallBackend::processFFT's magnitude/shift (src/WaterfallBackend.cpp:485-505).
  *   d_iq        device pointer to sample 0 of the stream, `format` F32 or I16 (F64 too on RO_PRECISION_F64 handles of
- *               4096 ... 65536 bins; RO_ERR_UNSUPPORTED elsewhere)
+ *               256 ... 65536 bins; RO_ERR_UNSUPPORTED elsewhere)
  *   samples     number of complex samples addressable at d_iq
  *   d_rows      device, rows x row_stride floats (row_stride >= bins); required
  *   d_tile      device, rows x tile_cols floats (compact copy of columns
@@ -221,7 +221,7 @@ int ro_stft_set_bands(ro_stft_t *h, const ro_bands_t *bands);
  *   d_records   device, rows records, or NULL (needs enable_scan)
  *   stream      hipStream_t as void* (NULL = the default stream, with its usual ordering rules)
  * The call is asynchronous on `stream`.  One handle = one stream: the handle owns scratch that some paths use
- * (bins > 131072, chirp-z lengths, RO_PRECISION_F64 outside 4096 ... 65536 bins, tile_ln), so two launches of ONE handle may only be in flight
+ * (bins > 131072, chirp-z lengths, RO_PRECISION_F64 above 65536 bins, tile_ln), so two launches of ONE handle may only be in flight
  * together when they are ordered on one stream -- like FFTBackend::process, which one thread calls at a time
  * (src/JackFrontend.cpp:19-22 only logs a re-entry).  Use one handle per concurrent stream. */
 int ro_stft_run_resident(ro_stft_t *h, const void *d_iq, int format, int64_t samples,

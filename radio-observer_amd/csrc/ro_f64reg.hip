@@ -36,6 +36,12 @@
 //                sixteen k0 x four u: 64-byte runs of consecutive bins) is conflict-free as well
 // tools/r6/emu_f64r.py restates all of it in numpy against numpy's FFT and counts the bank conflicts (none).
 // Five workgroup barriers per sub-row.
+//
+// bins 256 ... 2048 (N = 256 R): B = 4096 / N rows share the M = 4096 workgroup (f64r_kernel's LOGB).  The workgroup's index
+// i = n2 + 16 j1 + 256 n0 carries the row in the LOW bits of the last digit, n2 = b + B m, and means sample m + R j1 + 16 R n0
+// of row b.  Passes 0 and 1 (over n0, j1) are then the 4096-point transform's own -- their twists W_256^k0 do not know N --
+// and what is left of a row, the digit m, is what the first log2 R levels of pass 2 transform, with the 4096-point table
+// again: W_4096^(K1 B m) = W_N^(K1 m).  Every map above stays; slot p of the result is row p mod B, k2 = bitrev(p / B).
 #include "ro_kernels.h"
 #include "ro_fft_device.h"
 #include "ro_device_util.h"

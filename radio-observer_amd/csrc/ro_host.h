@@ -226,7 +226,7 @@ struct ro_stft {
     // strict precision (RO_PRECISION_F64): double twiddle table + two complex-double scratch blocks
     bool     f64 = false;
     double2 *d_tw_f64 = nullptr;
-    // ... bins 4096 ... 65536: the row in a CU's registers, no scratch (ro_f64reg.hip); its window order and twiddle tables
+    // ... bins 256 ... 65536: the row in a CU's registers, no scratch (ro_f64reg.hip); its window order and twiddle tables
     bool     f64reg = false;
     float   *d_f64r_window = nullptr;
     double2 *d_f64r_tw[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -101,8 +101,8 @@ hipError_t launch_f64_pass(int radix, bool first, bool last, int fmt, const BigA
 // two consecutive passes (radix 16 with a.ns, then radix r2) in one kernel through LDS; n >= 4096
 hipError_t launch_f64_pair(int r2, bool first, bool last, int fmt, const BigArgsD &a, hipStream_t s);
 
-// ---- strict precision with the row in a CU's registers (ro_f64reg.hip): bins = D x M, M in {4096, 8192, 16384}, no
-// complex-double scratch.  Tables come from f64reg_tables (host), the caller uploads them.
+// ---- strict precision with the row in a CU's registers (ro_f64reg.hip): bins = D x M, M in {4096, 8192, 16384}, or bins
+// 256 ... 2048 as 16 ... 2 rows in the M = 4096 workgroup; no complex-double scratch.  Tables come from f64reg_tables (host), the caller uploads them.
 struct F64RegTables {
     std::vector<float>   window_k;   // bins floats in the kernel's order
     std::vector<double2> tw0, tw1, tw2, tw3;
@@ -117,7 +117,7 @@ struct F64RegArgs {
     double         gain;
     unsigned long long *stamps; // diagnostic builds only (RO_F64R_STAMPS), else nullptr
 };
-bool       f64reg_supported(int bins);           // 4096 ... 65536
+bool       f64reg_supported(int bins);           // 256 ... 65536
 void       f64reg_tables(int bins, const float *window, F64RegTables &t);
 hipError_t launch_f64reg(int bins, int fmt, const F64RegArgs &a, hipStream_t s);
 

@@ -61,7 +61,7 @@ int validate_resident(const ro_stft *h, const void *d_iq, int format, int64_t sa
 {
     if (!h) return fail(RO_ERR_INVALID, "null handle");
     if (format == RO_IQ_F64 && !h->f64reg)
-        return fail(RO_ERR_UNSUPPORTED, "resident RO_IQ_F64 samples are taken by RO_PRECISION_F64 handles of 4096 ... 65536 bins only");
+        return fail(RO_ERR_UNSUPPORTED, "resident RO_IQ_F64 samples are taken by RO_PRECISION_F64 handles of 256 ... 65536 bins only");
     if (format != RO_IQ_F32 && format != RO_IQ_I16 && format != RO_IQ_F64)
         return fail(RO_ERR_INVALID, "resident input must be RO_IQ_F32, RO_IQ_I16 or RO_IQ_F64 (got %d)", format);
     if (rows < 0 || first_row < 0) return fail(RO_ERR_INVALID, "negative row range");

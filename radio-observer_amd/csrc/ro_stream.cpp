@@ -53,7 +53,7 @@ void release_batch(ro_stft *h, Batch *b)
 
 size_t stage_sample_bytes(const ro_stft *h) { return h->stage_fmt == RO_IQ_I16 ? 4 : h->stage_fmt == RO_IQ_F64 ? 16 : 8; }
 // bytes per sample the slots are sized for: doubles only where the handle's kernel takes them (RO_PRECISION_F64 at
-// 4096 ... 65536 bins)
+// 256 ... 65536 bins)
 size_t slot_sample_bytes(const ro_stft *h) { return h->f64reg ? 16 : 8; }
 
 // streaming buffers, all or nothing: a failure half way frees what was allocated, and the next push tries again
@@ -384,7 +384,7 @@ extern "C" int ro_stft_push(ro_stft_t *h, const void *iq, int format, int64_t sa
     // int16 all the way to the kernel (half the staging memory and PCIe bytes: src/WAVStream.cpp:119-120 hands them
     // over un-normalised, the kernel widens them); float32 stays float32; the double Complex is staged as float32
     // (lossless for every frontend of the reference) -- except on a handle whose kernel multiplies doubles
-    // (RO_PRECISION_F64 at 4096 ... 65536 bins), where it stays what src/Backend.h:26-29 says it is.  A stream that
+    // (RO_PRECISION_F64 at 256 ... 65536 bins), where it stays what src/Backend.h:26-29 says it is.  A stream that
     // changes format mid-way is widened once to the wider of the two.
     const bool in_i16 = format == RO_IQ_I16;
     const int want_fmt = in_i16 ? RO_IQ_I16 : (format == RO_IQ_F64 && h->f64reg) ? RO_IQ_F64 : RO_IQ_F32;

@@ -143,9 +143,9 @@ def run_case(ro, oracle, torch, c):
     if c["tile"]:
         kw["tile"] = c["tile"]
     fmt = ro.RO_IQ_I16 if c["fmt"] == "i16" else ro.RO_IQ_F32
-    # every other FP64-mode case of the register kernel's sizes hands over struct Complex's doubles themselves
+    # every other FP64-mode case of the register kernel's sizes (256 ... 65536) hands over struct Complex's doubles themselves
     # (src/Backend.h:26-29), with bits no float32 holds (derived from the case, no extra draw: the seeds' cases stay)
-    if c["precision"] == 1 and c["fmt"] == "f32" and 4096 <= bins <= 65536 and (c["data_seed"] & 1):
+    if c["precision"] == 1 and c["fmt"] == "f32" and 256 <= bins <= 65536 and (c["data_seed"] & 1):
         iq = iq.astype(np.float64) * (1.0 + 2.0 ** -29) + 2.0 ** -31
         fmt = ro.RO_IQ_F64
     stride = bins + c["stride_extra"]

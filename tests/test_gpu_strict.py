@@ -7,8 +7,8 @@ bins 60 dB under a carrier (tests/test_gpu_stft.py::test_c3_carrier_60db prints 
 seven orders of magnitude to spare.  The oracle's transform is an FP64 radix-2 FFT; two correct double transforms
 differ by a few 1e-16 of the row maximum, so most float rows come out bit-identical.
 
-Bins 4096 ... 65536 run csrc/ro_f64reg.hip (the complex-double row in a CU's registers), the other powers of two the
-passes through HBM scratch (ro_kernels.hip)."""
+Bins 256 ... 65536 run csrc/ro_f64reg.hip (the complex-double row in a CU's registers; below 4096 bins 2 ... 16 rows share
+a workgroup), the larger powers of two the passes through HBM scratch (ro_kernels.hip)."""
 import numpy as np
 import pytest
 
@@ -114,11 +114,13 @@ def test_scan_records_and_tile_in_strict_mode(ro, oracle, torch_cuda):
     assert np.array_equal(rec["peak"], p) and np.array_equal(rec["noise"], n) and np.array_equal(rec["average"], a)
 
 
-@pytest.mark.parametrize("bins,overlap,R", [(4096, 2048, 5000), (8192, 6144, 1500), (16384, 12288, 900), (32768, 24576, 1500),
-                                            (65536, 49152, 300)])
+@pytest.mark.parametrize("bins,overlap,R", [(256, 255, 3001), (256, 128, 40003), (512, 0, 4999), (1024, 512, 20001),
+                                            (2048, 1536, 7001), (4096, 2048, 5000), (8192, 6144, 1500),
+                                            (16384, 12288, 900), (32768, 24576, 1500), (65536, 49152, 300)])
 def test_register_form_many_rows_and_any_split(ro, oracle, torch_cuda, bins, overlap, R):
     """f64r_kernel is persistent: a workgroup takes many sub-rows in a row, the samples of the next one requested while
-    the image of this one is still in LDS, and the D sub-rows of a stream row come from D workgroups.  Enough rows that
+    the image of this one is still in LDS, and the D sub-rows of a stream row come from D workgroups; below 4096 bins a
+    workgroup takes 4096 / bins rows at a time (row counts that leave the last tile part empty).  Enough rows that
     every workgroup loops many times: every bin of every row against the oracle, and the same bits whatever the launch's
     row range (uneven cuts: first rows of an XCD's run, a single row, a launch smaller than the grid)."""
     torch = torch_cuda
@@ -151,7 +153,7 @@ def test_register_form_beside_another_kernel(ro, oracle, torch_cuda):
     busy_out = torch.empty((busy_rows, busy_bins), dtype=torch.float32, device="cuda")
     side = torch.cuda.Stream()
     with ro.Stft(bins=busy_bins, overlap=24576) as busy:
-        for bins, overlap, R in ((32768, 24576, 600), (4096, 2048, 3000), (65536, 49152, 200)):
+        for bins, overlap, R in ((32768, 24576, 600), (4096, 2048, 3000), (65536, 49152, 200), (1024, 512, 9001)):
             hop = bins - overlap
             iq = add_tone(noise_iq(rng, bins + (R - 1) * hop), 7000.0, 300.0)
             d_iq = torch.from_numpy(iq).cuda()
@@ -168,7 +170,7 @@ def test_register_form_beside_another_kernel(ro, oracle, torch_cuda):
             assert per_bin(out.cpu().numpy(), want).max() <= 2e-7, bins
 
 
-@pytest.mark.parametrize("bins", [4096, 16384, 32768, 65536])
+@pytest.mark.parametrize("bins", [256, 1024, 4096, 16384, 32768, 65536])
 def test_register_form_int16_gain_and_custom_window(ro, oracle, torch_cuda, bins):
     """int16 frames (un-normalised, WAVStream), the I/Q gain (its own kernel instantiation) and a caller's window; magnitudes
     beyond float32's range of squares take the plain square root (the fast one works on float(re^2 + im^2))"""
@@ -190,7 +192,7 @@ def test_register_form_int16_gain_and_custom_window(ro, oracle, torch_cuda, bins
         assert np.array_equal(got[~ok], want[~ok])
 
 
-@pytest.mark.parametrize("bins,overlap", [(4096, 2048), (16384, 8192), (32768, 24576), (65536, 32768)])
+@pytest.mark.parametrize("bins,overlap", [(256, 64), (1024, 512), (4096, 2048), (16384, 8192), (32768, 24576), (65536, 32768)])
 def test_true_double_samples(ro, oracle, torch_cuda, bins, overlap):
     """struct Complex is two doubles (src/Backend.h:26-29) and the reference multiplies them as such (src/FFTBackend.cpp:
     229-232): with RO_PRECISION_F64 at these sizes RO_IQ_F64 samples reach the kernel un-narrowed, resident and through
