@@ -311,7 +311,7 @@ def strict_leg(torch, ro, dev, local_rank, parity, bins, overlap, rows, fs, band
         recs_buf = torch.zeros((rows, 3), dtype=torch.float32, device=dev)
     sptr = torch.cuda.current_stream(dev).cuda_stream
     alg = hop * 8 + bins * 4
-    reg = bins in (4096, 8192, 16384, 32768, 65536)
+    reg = 256 <= bins <= 65536
     with ro.Stft(bins=bins, overlap=overlap, sample_rate=fs, device=local_rank, bands=bands, window=window,
                  precision=ro.RO_PRECISION_F64) as st64:
         n64 = steps + 2
@@ -325,7 +325,7 @@ def strict_leg(torch, ro, dev, local_rank, parity, bins, overlap, rows, fs, band
                  "workload": "bins %d, overlap %d, %d rows per launch%s" % (bins, overlap, rows, ", band scan included" if bands is not None else ""),
                  "value": rows / (ms_strict * 1e-3), "unit": "rows/s", "rows_per_step": rows, "steps": n64 - 2,
                  "ms_per_step": ms_strict, "dtype": "f64",
-                 "roofline": {"bound": "hbm", "limiter": "FP64 issue + LDS exchanges of one workgroup per CU (csrc/ro_f64reg.hip)" if reg
+                 "roofline": {"bound": "hbm", "limiter": "FP64 issue + LDS exchanges (one workgroup per CU at M = 16384, four at 4096: csrc/ro_f64reg.hip)" if reg
                                                         else "HBM scratch between the passes",
                               "unit": "GB/s", "peak": HBM_PEAK_GBS,
                               "achieved": alg * rows / (ms_strict * 1e-3) / 1e9,
@@ -1025,6 +1025,9 @@ def main():
                                                  max(a.steps, 20), iq=iq, rows_buf=rows, recs_buf=recs[1])
             if (BINS, OVERLAP) == (32768, 24576) and not c5:
                 out["strict_precision"]["c2"] = strict_leg(torch, ro, dev, local_rank, not a.no_parity, 4096, 2048, 65536, FS,
+                                                           None, ro.RO_WINDOW_NUTTALL, max(a.steps, 20))
+                # ... and C1's (the reference's own CPU-runnable case: 1024 bins, 50 %), four rows to a workgroup
+                out["strict_precision"]["c1"] = strict_leg(torch, ro, dev, local_rank, not a.no_parity, 1024, 512, 262144, FS,
                                                            None, ro.RO_WINDOW_NUTTALL, max(a.steps, 20))
 
         # ---- the station configs' own shapes next to the headline (never the headline), inputs resident:

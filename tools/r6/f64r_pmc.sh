@@ -37,10 +37,10 @@ for f in glob.glob(os.path.join(out, "p*", "*", "*_counter_collection.csv")):
 v = {k: sum(x) / len(x) for k, x in acc.items()}
 for k in sorted(v):
     print("%-26s %.6g per launch" % (k, v[k]))
-D = {4096: 1, 8192: 1, 16384: 1, 32768: 2, 65536: 4}[bins]
-M = bins // D
+D = {32768: 2, 65536: 4}.get(bins, 1)
+M = max(bins // D, 4096)                          # (below 4096 bins: 4096 / bins rows share the M = 4096 workgroup)
 waves_per_sub = M // 16 // 64
-subrows = rows * D
+subrows = rows * D * bins // (D * M)
 if "SQ_WAVE_CYCLES" in v:
     wc = v["SQ_WAVE_CYCLES"]
     print("shares of SQ_WAVE_CYCLES: WAIT_ANY %.3f  WAIT_INST_ANY %.3f  ACTIVE_INST_ANY %.3f  (ACTIVE VALU %.3f  LDS %.3f  SCA %.3f  VMEM %.3f)"
