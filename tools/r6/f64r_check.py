@@ -95,7 +95,8 @@ def main():
         ok = parity(sizes)
         print("parity:", "OK" if ok else "FAILED", flush=True)
     if ok:
-        shapes = {256: (128, 1 << 20), 512: (256, 1 << 19), 1024: (512, 1 << 18), 2048: (1024, 1 << 17), 4096: (2048, 65536), 8192: (6144, 32768), 16384: (12288, 16384), 32768: (24576, 16384), 65536: (49152, 8192)}
+        shapes = {256: (128, 1 << 20), 512: (256, 1 << 19), 1024: (512, 1 << 18), 2048: (1024, 1 << 17), 4096: (2048, 65536), 8192: (6144, 32768), 16384: (12288, 16384), 32768: (24576, 16384), 65536: (49152, 8192),
+                  131072: (98304, 2048), 262144: (196608, 1024), 524288: (262144, 512), 1048576: (524288, 256)}
         for bins in sizes:
             rate(bins, *shapes[bins])
     return 0 if ok else 1
