@@ -334,6 +334,13 @@ def strict_leg(torch, ro, dev, local_rank, parity, bins, overlap, rows, fs, band
                               "kernel": ("f64r_kernel (csrc/ro_f64reg.hip)" if reg else "f64_pair_kernel (two launches per chunk)")
                                         + (" + scan_kernel" if bands is not None else ""),
                               "traffic": None}}
+        # what the limiter names, as a number: the transform's flops against the FP64 vector peak (half the FP32 vector
+        # peak of MI355X_MICROARCH.md: 157.3 / 2 TFLOP/s).  5 N log2 N is the customary count for an FFT; the kernel issues
+        # 3 N log2 N FMAs (six-FMA butterflies) plus the fold and the square roots.
+        flops = 5.0 * bins * float(np.log2(bins))
+        entry["roofline"]["fp64_valu"] = {"unit": "TFLOP/s", "peak": 78.65, "flops_per_row": flops,
+                                          "achieved": flops * rows / (ms_strict * 1e-3) / 1e12,
+                                          "frac": flops * rows / (ms_strict * 1e-3) / 1e12 / 78.65}
         # bytes per launch by FETCH_SIZE / WRITE_SIZE from a committed rocprofv3 --pmc record of this shape (tools/r6/
         # f64r_pmc.sh), scaled to this launch's rows: counters cannot be read from inside the run
         rec_name = "r06_traffic_f64_%d.json" % bins
