@@ -294,17 +294,17 @@ __device__ __forceinline__ void magnitudes16(const double *re, const double *im,
 {
     double s[16];
     float sf[16];
-    float lo = __builtin_inff(), hi = 0.f;            // (float min / max: 32-bit operations; a NaN fails both tests below)
-    bool nan = false;
+    float lo = __builtin_inff(), hi = 0.f;            // (float min / max: 32-bit operations)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         s[i] = __builtin_fma(im[i], im[i], re[i] * re[i]);
         sf[i] = (float)s[i];
         lo = __builtin_fminf(lo, sf[i]);
         hi = __builtin_fmaxf(hi, sf[i]);
-        nan = nan || sf[i] != sf[i];
     }
-    const bool odd = nan || !(lo > 0x1p-100f && hi < 0x1p100f);
+    // (a NaN passes min and max unseen and needs no watching: rsq, the products and the residual below hand it on, and NaN
+    // is what sqrt(NaN) gives)
+    const bool odd = !(lo > 0x1p-100f && hi < 0x1p100f);
     if (RO_F64R_SQRT_EXACT || __builtin_amdgcn_ballot_w64(odd) != 0) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) out[i] = (float)sqrt(s[i]);

@@ -241,3 +241,24 @@ def test_true_double_samples(ro, oracle, torch_cuda, bins, overlap):
         with pytest.raises(ro.StftError) as e:
             st.run_resident(d_iq, ro.RO_IQ_F64, T, 0, R, d_rows)
         assert e.value.code == -2
+
+
+@pytest.mark.parametrize("bins,overlap", [(512, 256), (1024, 512), (4096, 3072), (32768, 24576)])
+def test_a_nan_sample_poisons_its_rows_only(ro, oracle, torch_cuda, bins, overlap):
+    """fftw_execute and sqrt hand a NaN on to every bin of the rows that contain the sample (src/FFTBackend.cpp:229-236,
+    src/WaterfallBackend.cpp:497-503) and to no other row -- also where several rows share a workgroup (bins < 4096) and
+    where the magnitudes' fast square root decides once per wave"""
+    hop = bins - overlap
+    R = 37
+    rng = np.random.default_rng(bins)
+    iq = noise_iq(rng, bins + (R - 1) * hop)
+    at = 11 * hop + bins // 3                                  # inside rows 11 - (bins // hop - 1) + ... 11
+    iq[at, 1] = np.nan
+    got = strict_rows(ro, torch_cuda, iq, bins, overlap)
+    hit = np.array([r * hop <= at < r * hop + bins for r in range(R)])
+    assert hit.sum() >= 2 and not hit.all()
+    assert np.isnan(got[hit]).all()
+    clean = iq.copy()
+    clean[at, 1] = 0.0
+    want = oracle.stft(clean, bins, overlap)
+    assert per_bin(got[~hit], want[~hit]).max() <= 2e-7
