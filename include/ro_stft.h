@@ -58,7 +58,7 @@ enum { RO_IQ_F32 = 0, RO_IQ_I16 = 1, RO_IQ_F64 = 2 };
  *       256 ... 65536 keep the complex-double row in a compute unit's registers (samples read once, row written
  *       once; below 4096 bins 2 ... 16 rows share a workgroup); 131072 ... 1048576 are passes through HBM scratch.  Rows within 1e-5 of the reference PER BIN
  *       (measured <= 1.2e-7: one float32 ulp, at 60 dB of dynamic range); 2.5 times slower than F32 at 32768 bins.
- *       Complex-spectra output is F32 only.
+ *       Complex spectra (ro_stft_spectra_resident) up to 65536 bins.
  *  (Value 2 was ABI 4's RO_PRECISION_F64_ONE_LAUNCH, an experiment that measured slower; ro_stft_create answers
  *  RO_ERR_UNSUPPORTED for it.) */
 enum { RO_PRECISION_F32 = 0, RO_PRECISION_F64 = 1 };
@@ -249,9 +249,11 @@ int ro_ln_levels(const float *ln, int64_t count, float mn, float mx, uint8_t *le
  * int size, DataInfo, int rawMark) (src/FFTBackend.h:104) -- bin k of row r at d_spectra[r * stride + k] as
  * {float re, float im}, unshifted (k = 0 is DC), unnormalised, after gain and window like the magnitude path.
  * Same kernels with a different last step; rows x stride x 8 bytes are written.  Every size the handle supports:
- * one kernel up to 32768 bins, fold + transform + interleave through the handle's scratch above (power-of-two bins,
- * float32: RO_ERR_UNSUPPORTED for chirp-z lengths and for RO_PRECISION_F64 handles).  Asynchronous on `stream`; one launch in flight per handle
- * above 32768 bins (the scratch is the handle's). */
+ * one kernel up to 32768 bins, fold + transform + interleave through the handle's scratch above (power-of-two bins:
+ * RO_ERR_UNSUPPORTED for chirp-z lengths).  An RO_PRECISION_F64 handle of 256 ... 65536 bins hands out its double
+ * transform, each component narrowed to float once (every bin within a float32 ulp of the reference's fftw_complex,
+ * however far below the row's largest); RO_ERR_UNSUPPORTED above.  Asynchronous on `stream`; one launch in flight per
+ * handle above 32768 bins in float32 (the scratch is the handle's). */
 int ro_stft_spectra_resident(ro_stft_t *h, const void *d_iq, int format, int64_t samples,
                              int64_t first_row, int64_t rows,
                              float *d_spectra /* rows x stride x {re, im} */, int64_t stride, void *stream);

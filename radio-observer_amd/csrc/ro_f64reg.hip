@@ -527,9 +527,10 @@ struct Args {
     int            hop;
     double         gain;
     unsigned long long *stamps;  // diagnostic builds only (RO_F64R_STAMPS), else nullptr
+    int            spectra;      // 1: rows_out takes {re, im} float pairs per bin, unshifted (row_stride counts pairs)
 };
 
-template <int LOGM, int D, int FMT, bool GAIN, int LOGB = 0>
+template <int LOGM, int D, int FMT, bool GAIN, int LOGB = 0, bool SPEC = false>
 __global__ __launch_bounds__((1 << LOGM) / 16, 4) void f64r_kernel(Args a)
 {
     using G = Geo<LOGM>;
@@ -630,6 +631,51 @@ __global__ __launch_bounds__((1 << LOGM) / 16, 4) void f64r_kernel(Args a)
             const int imr = 2 * rk0 * ST + ((ru + 2 * rk0) & (Q - 1));
 #pragma unroll
             for (int s = 0; s < 16; ++s) m[s] = image[imr + Q * s];
+        }
+    };
+    // SPEC (ro_stft_spectra_resident): the image holds the real parts, then the imaginary parts, of the transform narrowed to
+    // float; bin k of the row goes to floats 2 k + part of its line of row_stride {re, im} pairs, unshifted (k = 0 is DC:
+    // what fftw_execute leaves in out_, src/FFTBackend.cpp:236), as 4-byte stores on the default cache policy (the two
+    // halves of a pair meet in L2)
+    auto spec_store = [&](int64_t prow, int part) {
+        const int lane = fresh() & 63;
+        if constexpr (LOGB > 0) {
+            const int rc = lane & 3, ul = lane >> 2;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int s = wave + 4 * it;
+                const int64_t orow = prow * B + (s & (B - 1));
+                const __amdgpu_buffer_rsrc_t rsb = make_rsrc(a.rows_out + orow * a.row_stride * 2, orow < a.rows ? NB * 8 : 0);
+                int sb = 0;
+#pragma unroll
+                for (int p = 0; p < 16; ++p) sb = s == p ? 256 * brev<LV>(p >> LOGB) : sb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[4 * it + e]), rsb, (4 * rc + 16 * ul + sb + e) * 8 + part * 4, 0, 0);
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.rows_out + prow * a.row_stride * 2, N * 8);
+            if constexpr (D == 1) {
+                const int rc = lane & 3, ul = lane >> 2;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int code = wave + (T / 64) * it, uh = code % R3, s = code / R3;
+                    const int g = R3 == 4 ? (uh >> 1) + 2 * (uh & 1) : uh;
+                    int sb = 0;
+#pragma unroll
+                    for (int p = 0; p < 16; ++p) sb = s == p ? slot_bin(p) : sb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[4 * it + e]), rs, (4 * rc + 16 * ul + 256 * g + sb + e) * 8 + part * 4, 0, 0);
+                }
+            } else {
+                const int rk0 = lane & 15, ru = (lane >> 4) | (wave << 2);
+                const int rn3 = ru >> 4, rg = R3 == 4 ? (rn3 >> 1) + 2 * (rn3 & 1) : rn3;
+                const int voff = (q + D * (rk0 + 16 * (ru & 15) + 256 * rg)) * 8 + part * 4;
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[s]), rs, voff, D * slot_bin(s) * 8, 0);
+            }
         }
     };
     auto readout_store = [&](int64_t prow) {
@@ -862,12 +908,29 @@ __global__ __launch_bounds__((1 << LOGM) / 16, 4) void f64r_kernel(Args a)
         else imw = 2 * k0 * ST + ((u + 2 * k0) & (Q - 1));                            // + s Q
         const int imw_flip = R3 == 1 ? (k0 >> 2) & 1 : 0;
         float mg[16];
-        magnitudes16(re, im, mg);
+        auto image_write = [&]() {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            if constexpr (R3 == 1) image[imw + 16 * (s ^ imw_flip)] = mg[s];
-            else image[imw + Q * s] = mg[s];
+            for (int s = 0; s < 16; ++s) {
+                if constexpr (R3 == 1) image[imw + 16 * (s ^ imw_flip)] = mg[s];
+                else image[imw + Q * s] = mg[s];
+            }
+        };
+        if constexpr (SPEC) {
+            // the real parts take the image's way out first (two barriers more per sub-row), the imaginary parts the
+            // magnitudes' place below
+#pragma unroll
+            for (int s = 0; s < 16; ++s) mg[s] = (float)re[s];
+            image_write();
+            wg_sync();
+            readout_lds();
+            wg_sync();
+            spec_store(row, 0);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) mg[s] = (float)im[s];
+        } else {
+            magnitudes16(re, im, mg);
         }
+        image_write();
         const float last = mg[15];
         // The hop new samples of a later sub-row are touched (one dword per 128-byte line, value unused: it is "used" in front
         // of the next fold) so that the requests below find them in L2: they come from HBM, every other byte of the row from
@@ -898,7 +961,8 @@ __global__ __launch_bounds__((1 << LOGM) / 16, 4) void f64r_kernel(Args a)
         stamp(0);
         wg_sync();                                      // (a) the image has been read
         stamp(1);
-        readout_store(row);
+        if constexpr (SPEC) spec_store(row, 1);
+        else readout_store(row);
         stamp(2);
         if constexpr (RO_F64R_STAMPS) st_acc[15] += 1;
         if (!has_next) break;
@@ -940,7 +1004,20 @@ template <int LOGM, int D, int FMT, int LOGB = 0> static hipError_t launch_one(c
     slots = slots / D * D;
     if (slots < D) slots = D;
     // (the reference's "iq_gain" is 0 in every shipped config: the additions exist only in the kernel that needs them)
-    if (a.gain != 0.0) hipLaunchKernelGGL((f64r_kernel<LOGM, D, FMT, true, LOGB>), dim3((unsigned)(slots * 8)), dim3(G::T), G::LDS_BYTES, s, a);
+    if (a.spectra) {
+        // (one instantiation per plan and format: with a gain of 0.0 the additions change nothing)
+        static std::mutex slock;
+        static bool sready[64];
+        {
+            std::lock_guard<std::mutex> g(slock);
+            if (!sready[dev]) {
+                if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&f64r_kernel<LOGM, D, FMT, true, LOGB, true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES)) != hipSuccess) return e;
+                sready[dev] = true;
+            }
+        }
+        hipLaunchKernelGGL((f64r_kernel<LOGM, D, FMT, true, LOGB, true>), dim3((unsigned)(slots * 8)), dim3(G::T), G::LDS_BYTES, s, a);
+    } else if (a.gain != 0.0) hipLaunchKernelGGL((f64r_kernel<LOGM, D, FMT, true, LOGB>), dim3((unsigned)(slots * 8)), dim3(G::T), G::LDS_BYTES, s, a);
     else hipLaunchKernelGGL((f64r_kernel<LOGM, D, FMT, false, LOGB>), dim3((unsigned)(slots * 8)), dim3(G::T), G::LDS_BYTES, s, a);
     return hipGetLastError();
 }
@@ -1059,6 +1136,7 @@ hipError_t launch_f64reg(int bins, int fmt, const F64RegArgs &a, hipStream_t s)
     b.hop = a.hop;
     b.gain = a.gain;
     b.stamps = a.stamps;
+    b.spectra = a.spectra;
     if (fmt == RO_FMT_F32) return f64r::launch_fmt<RO_FMT_F32>(m_log2, dec, logb, b, s);
     if (fmt == RO_FMT_I16) return f64r::launch_fmt<RO_FMT_I16>(m_log2, dec, logb, b, s);
     if (fmt == RO_IQ_F64) return f64r::launch_fmt<RO_IQ_F64>(m_log2, dec, logb, b, s);

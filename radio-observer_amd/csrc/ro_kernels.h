@@ -116,6 +116,7 @@ struct F64RegArgs {
     int            hop;
     double         gain;
     unsigned long long *stamps; // diagnostic builds only (RO_F64R_STAMPS), else nullptr
+    int            spectra;     // 1: rows_out takes the transform itself, {float re, float im} per bin, unshifted; row_stride in pairs
 };
 bool       f64reg_supported(int bins);           // 256 ... 65536
 void       f64reg_tables(int bins, const float *window, F64RegTables &t);

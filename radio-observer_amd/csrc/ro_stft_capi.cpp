@@ -875,8 +875,29 @@ extern "C" int ro_stft_spectra_resident(ro_stft_t *h, const void *d_iq, int form
     int rc = validate_resident(h, d_iq, format, samples, first_row, rows, d_spectra, stride, nullptr, nullptr);
     if (rc != RO_OK) return rc;
     if (h->czt) return fail(RO_ERR_UNSUPPORTED, "complex spectra are available for power-of-two bins");
-    if (h->f64) return fail(RO_ERR_UNSUPPORTED, "complex spectra are float32 only (RO_PRECISION_F32)");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->f64) {
+        // the double transform itself, narrowed once per component (ro_f64reg.hip's SPEC instantiations): the register
+        // kernel's sizes only
+        if (!h->f64reg)
+            return fail(RO_ERR_UNSUPPORTED, "complex spectra of RO_PRECISION_F64 handles are available up to 65536 bins");
+        ro::F64RegArgs r{};
+        r.iq = d_iq;
+        r.window_k = h->d_f64r_window;
+        r.tw0 = h->d_f64r_tw[0];
+        r.tw1 = h->d_f64r_tw[1];
+        r.tw2 = h->d_f64r_tw[2];
+        r.tw3 = h->d_f64r_tw[3];
+        r.rows_out = d_spectra;
+        r.first_row = first_row;
+        r.rows = rows;
+        r.row_stride = stride;
+        r.hop = h->hop;
+        r.gain = h->cfg.iq_gain;
+        r.spectra = 1;
+        HIP_TRY(ro::launch_f64reg(h->bins, format, r, (hipStream_t)stream));
+        return RO_OK;
+    }
     if (h->big)
         return launch_spectra_big(h, d_iq, format, first_row, rows, reinterpret_cast<float2 *>(d_spectra), stride,
                                   (hipStream_t)stream);

@@ -100,3 +100,73 @@ def test_spectra_unsupported_for_chirp_z_lengths(ro, torch_cuda):
         with pytest.raises(ro.StftError) as e:
             st.spectra_resident(d_iq, ro.RO_IQ_F32, bins, 0, 1, spec)
         assert e.value.code == -2
+
+
+def per_component(got, want):
+    """worst |component error| of a complex row against the larger component of the bin (a double transform narrowed once
+    per component is within half a float32 ulp of that)"""
+    scale = np.maximum(np.abs(want.real), np.abs(want.imag))
+    err = np.maximum(np.abs(got.real - want.real), np.abs(got.imag - want.imag))
+    ok = scale > 1e-30
+    return float((err[ok] / scale[ok]).max())
+
+
+@pytest.mark.parametrize("bins,overlap,nrows", [(256, 192, 41), (512, 0, 19), (1024, 512, 23), (2048, 1024, 9), (4096, 2048, 20),
+                                                (8192, 6144, 9), (16384, 8192, 7), (32768, 24576, 7), (65536, 49152, 5)])
+def test_fp64_mode_spectra_are_the_double_transform(ro, oracle, torch_cuda, bins, overlap, nrows):
+    """RO_PRECISION_F64 handles hand out the reference's fftw_complex row itself (src/FFTBackend.cpp:236), each component
+    narrowed to float once: EVERY bin within a float32 ulp of the oracle's double spectrum, 60 dB under a carrier too
+    (the float32 transform's bar is 1e-5 of the row's largest bin); the magnitude rows are |.| of the same values."""
+    rng = np.random.default_rng(bins + 7)
+    hop = bins - overlap
+    iq = add_tone(noise_iq(rng, bins + hop * (nrows - 1)), 9100.0, 1000.0)
+    spec, mag, w = spectra_gpu(ro, torch_cuda, iq, bins, overlap, precision=ro.RO_PRECISION_F64)
+    assert np.isfinite(spec).all()
+    z = iq[:, 0].astype(np.float64) + 1j * iq[:, 1].astype(np.float64)
+    got = spec[..., 0].astype(np.float64) + 1j * spec[..., 1].astype(np.float64)
+    worst = 0.0
+    for r in range(nrows):
+        _, want = oracle.row_with_spectrum(z[r * hop:r * hop + bins], w)
+        worst = max(worst, per_component(got[r], want))
+        m = np.roll(np.abs(want), bins // 2)
+        assert (np.abs(mag[r] - m) <= 2e-7 * m).all()
+    assert worst <= 1.2e-7, worst
+
+
+def test_fp64_mode_spectra_int16_gain_doubles_stride_and_range(ro, oracle, torch_cuda):
+    """the other sample formats (int16 with a gain; struct Complex's doubles), a padded stride and a row range in the middle
+    of the stream: nothing else written"""
+    torch = torch_cuda
+    s = torch.cuda.current_stream().cuda_stream
+    for bins, overlap in ((1024, 768), (16384, 12288), (32768, 16384)):
+        hop = bins - overlap
+        rng = np.random.default_rng(bins)
+        total = 9
+        i16 = rng.integers(-3000, 3000, size=(bins + hop * (total - 1), 2)).astype(np.int16)
+        f64 = rng.standard_normal((bins + hop * (total - 1), 2)) * (1.0 + 2.0 ** -30)
+        stride = bins + 8
+        for samples, fmt, gain in ((i16, ro.RO_IQ_I16, 2.5), (f64, ro.RO_IQ_F64, 0.0)):
+            spec = torch.full((total, stride, 2), 7.0, dtype=torch.float32, device="cuda")
+            d_iq = torch.from_numpy(samples).cuda()
+            with ro.Stft(bins=bins, overlap=overlap, iq_gain=gain, precision=ro.RO_PRECISION_F64) as st:
+                st.spectra_resident(d_iq, fmt, samples.shape[0], 2, 5, spec[2:], stride=stride, stream=s)
+                torch.cuda.synchronize()
+                w = st.window
+            out = spec.cpu().numpy()
+            assert (out[:2] == 7.0).all() and (out[7:] == 7.0).all() and (out[2:7, bins:] == 7.0).all()
+            z = samples[:, 0].astype(np.float64) + 1j * samples[:, 1].astype(np.float64)
+            for r in range(2, 7):
+                _, want = oracle.row_with_spectrum(z[r * hop:r * hop + bins], w, gain=gain)
+                got = out[r, :bins, 0].astype(np.float64) + 1j * out[r, :bins, 1]
+                assert per_component(got, want) <= 1.2e-7, (bins, fmt, r)
+
+
+def test_fp64_mode_spectra_stop_at_65536_bins(ro, torch_cuda):
+    torch = torch_cuda
+    bins = 131072
+    d_iq = torch.zeros((bins, 2), dtype=torch.float32, device="cuda")
+    spec = torch.empty((1, bins, 2), dtype=torch.float32, device="cuda")
+    with ro.Stft(bins=bins, overlap=0, precision=ro.RO_PRECISION_F64) as st:
+        with pytest.raises(ro.StftError) as e:
+            st.spectra_resident(d_iq, ro.RO_IQ_F32, bins, 0, 1, spec)
+        assert e.value.code == -2

@@ -86,18 +86,23 @@ def test_lds_traffic_between_consecutive_barriers(isa):
 
 def test_f64r_kernels(isa):
     """the register-resident FP64 kernel: nine plans (five of one row or sub-row per workgroup, four of 2 ... 16 rows in the
-    4096-point workgroup) x three sample formats x {no gain, gain}; exchange 3 is lane swaps, not LDS (M = 8192:
-    v_permlane16_swap, M = 16384: both); 128 VGPRs at the most (16 waves per CU)"""
+    4096-point workgroup) x three sample formats x {no gain, gain, complex spectra}; exchange 3 is lane swaps, not LDS
+    (M = 8192: v_permlane16_swap, M = 16384: both); five barriers per sub-row (seven where the real and the imaginary parts
+    leave through the image one after the other); 128 VGPRs at the most (16 waves per CU)"""
     ks = {k: b for k, b in kernels(isa).items() if "f64r_kernel" in k}
-    assert len(ks) == 54
+    assert len(ks) == 81
+    spec = 0
     for name, body in ks.items():
         text = "\n".join(body)
         logm = int(re.search(r"f64r_kernelILi(\d+)E", name).group(1))
+        is_spec = re.search(r"Lb([01])EEEvNS0_4ArgsE", name).group(1) == "1"
+        spec += is_spec
         n32, n16 = text.count("v_permlane32_swap"), text.count("v_permlane16_swap")
         assert (n32, n16) == {12: (0, 0), 13: (0, 32), 14: (32, 32)}[logm], (name, n32, n16)
-        assert text.count("s_barrier") == 5, name
+        assert text.count("s_barrier") == (7 if is_spec else 5), name
+    assert spec == 27
     vg = dict(re.findall(r"\.name:\s*(\S*f64r_kernel\S*)[\s\S]*?\.vgpr_count:\s*(\d+)", isa))
-    assert len(vg) == 54 and max(int(v) for v in vg.values()) <= 128, vg
+    assert len(vg) == 81 and max(int(v) for v in vg.values()) <= 128, vg
 
 
 def test_addtid_writes_are_waited_for_before_the_barrier(isa):
