@@ -60,33 +60,35 @@ def parity(sizes):
     return ok
 
 
-def rate(bins, overlap, R, steps=12):
+def rate(bins, overlap, R, steps=12, spectra=False):
     hop = bins - overlap
     T = bins + (R - 1) * hop
     g = torch.Generator(device="cuda").manual_seed(bins)
     d_iq = torch.randn((T, 2), dtype=torch.float32, device="cuda", generator=g)
-    d_rows = torch.empty((R, bins), dtype=torch.float32, device="cuda")
+    d_rows = torch.empty((R, bins, 2) if spectra else (R, bins), dtype=torch.float32, device="cuda")
     s = torch.cuda.current_stream()
     with ro.Stft(bins=bins, overlap=overlap, precision=ro.RO_PRECISION_F64) as st:
+        launch = st.spectra_resident if spectra else st.run_resident
         for _ in range(3):
-            st.run_resident(d_iq, ro.RO_IQ_F32, T, 0, R, d_rows, stream=s.cuda_stream)
+            launch(d_iq, ro.RO_IQ_F32, T, 0, R, d_rows, stream=s.cuda_stream)
         torch.cuda.synchronize()
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         evs[0].record(s)
         for i in range(steps):
-            st.run_resident(d_iq, ro.RO_IQ_F32, T, 0, R, d_rows, stream=s.cuda_stream)
+            launch(d_iq, ro.RO_IQ_F32, T, 0, R, d_rows, stream=s.cuda_stream)
             evs[i + 1].record(s)
         torch.cuda.synchronize()
     ms = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
-    alg = hop * 8 + bins * 4
-    print("bins %6d overlap %6d rows %6d: %.3f ms per launch (min %.3f)  %.3e rows/s  %.1f GB/s algorithmic = %.3f of 8 TB/s"
-          % (bins, overlap, R, ms.mean(), ms.min(), R / (ms.mean() * 1e-3), alg * R / (ms.mean() * 1e-3) / 1e9,
+    alg = hop * 8 + bins * (8 if spectra else 4)
+    print("%sbins %6d overlap %6d rows %6d: %.3f ms per launch (min %.3f)  %.3e rows/s  %.1f GB/s algorithmic = %.3f of 8 TB/s"
+          % ("complex spectra, " if spectra else "", bins, overlap, R, ms.mean(), ms.min(), R / (ms.mean() * 1e-3), alg * R / (ms.mean() * 1e-3) / 1e9,
              alg * R / (ms.mean() * 1e-3) / 8e12), flush=True)
 
 
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--rate-only", action="store_true")
+    p.add_argument("--spectra", action="store_true", help="the rates of ro_stft_spectra_resident instead (algorithmic bytes: hop 8 + bins 8)")
     p.add_argument("--sizes", default="256,512,1024,2048,4096,8192,16384,32768,65536")
     a = p.parse_args()
     sizes = [int(x) for x in a.sizes.split(",")]
@@ -98,7 +100,7 @@ def main():
         shapes = {256: (128, 1 << 20), 512: (256, 1 << 19), 1024: (512, 1 << 18), 2048: (1024, 1 << 17), 4096: (2048, 65536), 8192: (6144, 32768), 16384: (12288, 16384), 32768: (24576, 16384), 65536: (49152, 8192),
                   131072: (98304, 2048), 262144: (196608, 1024), 524288: (262144, 512), 1048576: (524288, 256)}
         for bins in sizes:
-            rate(bins, *shapes[bins])
+            rate(bins, *shapes[bins], spectra=a.spectra)
     return 0 if ok else 1
 
 
