@@ -42,6 +42,9 @@
 // of row b.  Passes 0 and 1 (over n0, j1) are then the 4096-point transform's own -- their twists W_256^k0 do not know N --
 // and what is left of a row, the digit m, is what the first log2 R levels of pass 2 transform, with the 4096-point table
 // again: W_4096^(K1 B m) = W_N^(K1 m).  Every map above stays; slot p of the result is row p mod B, k2 = bitrev(p / B).
+//
+// SPEC instantiations (ro_stft_spectra_resident on an RO_PRECISION_F64 handle): the transform itself instead of |X| -- its
+// real parts, then its imaginary parts, each narrowed to float once, take the image's way out (two barriers more), unshifted.
 #include "ro_kernels.h"
 #include "ro_fft_device.h"
 #include "ro_device_util.h"
