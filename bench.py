@@ -325,7 +325,7 @@ def strict_leg(torch, ro, dev, local_rank, parity, bins, overlap, rows, fs, band
                  "workload": "bins %d, overlap %d, %d rows per launch%s" % (bins, overlap, rows, ", band scan included" if bands is not None else ""),
                  "value": rows / (ms_strict * 1e-3), "unit": "rows/s", "rows_per_step": rows, "steps": n64 - 2,
                  "ms_per_step": ms_strict, "dtype": "f64",
-                 "roofline": {"bound": "hbm", "limiter": "FP64 issue + LDS exchanges (one workgroup per CU at M = 16384, four at 4096: csrc/ro_f64reg.hip)" if reg
+                 "roofline": {"bound": "hbm", "limiter": "FP64 issue + LDS exchanges (one workgroup per CU at M = 16384, four at 4096: csrc/ro_f64reg.hip) under the package power cap (profiles/r06_f64r_power.txt: 1382 W at C3, 1386 W / 2005 MHz at C2)" if reg
                                                         else "HBM scratch between the passes",
                               "unit": "GB/s", "peak": HBM_PEAK_GBS,
                               "achieved": alg * rows / (ms_strict * 1e-3) / 1e9,
