@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: shader clock and package power (amdgpu hwmon, bench.py's sampler) while the register-resident FP64 kernel runs
 back to back for a few seconds at one shape -- is it the package's power cap that sets its clock, as under the float32
-headline kernel?   python tools/r6/f64r_power.py [BINS OVERLAP ROWS [SECONDS]]"""
+headline kernel?   python tools/r6/f64r_power.py [BINS OVERLAP ROWS [SECONDS]] | --f32"""
 import importlib
 import os
 import sys
@@ -50,6 +50,10 @@ def run(bins, overlap, R, seconds, precision):
 
 
 def main():
+    if "--f32" in sys.argv:                                    # the float32 kernels of the station configs' shapes instead
+        for b, o, r in ((65536, 49152, 8192), (524288, 262144, 512), (4096, 2048, 65536), (16384, 12288, 16384)):
+            run(b, o, r, 3.0, ro.RO_PRECISION_F32)
+        return
     secs = float(sys.argv[4]) if len(sys.argv) > 4 else 3.0
     if len(sys.argv) > 3:
         shapes = [(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))]
