@@ -53,6 +53,8 @@ def test_bench_line_has_the_contract_fields(ro, torch_cuda):
     assert sp["roofline"]["frac"] == pytest.approx(sp["roofline"]["achieved"] / 8000.0) and "f64r_kernel" in sp["roofline"]["kernel"]
     assert sp["parity"]["max_err_per_bin_relative"] <= 2e-7 and "4096" in sp["c2"]["workload"]
     assert sp["c2"]["dtype"] == "f64" and sp["c2"]["parity"]["max_err_per_bin_relative"] <= 2e-7 and sp["c2"]["value"] > sp["value"]
+    assert "1024" in sp["c1"]["workload"] and sp["c1"]["parity"]["max_err_per_bin_relative"] <= 2e-7 and sp["c1"]["value"] > sp["c2"]["value"]
+    assert "f64r_kernel" in sp["c1"]["roofline"]["kernel"] and 0 < sp["roofline"]["fp64_valu"]["frac"] < 1
     assert rf["limiter"].startswith("package power cap")
     io = d["ionozor"]                   # the four-step form at Ionozor.json:27-28, never the headline
     assert io["unit"] == "rows/s" and io["value"] > 0 and io["parity"]["max_err_rel_to_row_max"] <= 1e-5
